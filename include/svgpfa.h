@@ -1,0 +1,157 @@
+/*
+ * svgpfa.h -- C ABI of the MI355X-native svGPFA ELBO engine (libsvgpfa_hip.so).
+ *
+ * The reference (joacorapela/svGPFA) is pure Python/PyTorch and has no FFI; the seam this
+ * library replaces is the object protocol between its EM loop and its SVLowerBound object
+ * graph.  Every entry point below names the reference method whose work it
+ * does (paths relative to /root/reference/src/svGPFA/).  Host code stays Python and binds
+ * these symbols with ctypes (svgpfa_amd/_lib.py); see INTEGRATION.md for the stub a
+ * reference maintainer would add.
+ *
+ * Conventions
+ *   - All data pointers are DEVICE pointers (hipMalloc'd / torch ROCm tensor data_ptr()),
+ *     fp64, C-contiguous, unless the parameter name ends in _host.
+ *   - Per-latent arguments are HOST arrays of n_latents device pointers.
+ *   - Every call enqueues on the engine's stream (svgpfa_set_stream) and returns without
+ *     waiting; svgpfa_sync() waits and reports device-side failures (non-PD Kzz).
+ *   - Return value: SVGPFA_OK or an SVGPFA_ERR_* code; text via svgpfa_last_error().
+ *   - One engine = one GPU = one contiguous block of trials.  Nothing here is collective:
+ *     the multi-GPU sum is ONE all-reduce of the `shared` vector done by the host
+ *     (torch.distributed / RCCL), see svgpfa_shared_len().
+ *   - Not re-entrant per engine; distinct engines are independent.
+ */
+#ifndef SVGPFA_H
+#define SVGPFA_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct svgpfa_engine svgpfa_engine;
+
+enum {
+  SVGPFA_OK = 0,
+  SVGPFA_ERR_INVALID = 1,     /* bad argument / shape / ordering                       */
+  SVGPFA_ERR_NOT_PD = 2,      /* Kzz + eps*I (or S) not positive definite: the reference
+                                 raises torch.linalg.LinAlgError at utils/miscUtils.py:215 */
+  SVGPFA_ERR_HIP = 3,         /* a HIP runtime call failed                             */
+  SVGPFA_ERR_STATE = 4,       /* call order violated (e.g. elbo before build_kernels)  */
+  SVGPFA_ERR_UNSUPPORTED = 5  /* size beyond what this build handles                   */
+};
+
+/* stats/kernels.py: ExponentialQuadraticKernel (:26-64), PeriodicKernel (:66-108) */
+enum { SVGPFA_KERNEL_RBF = 0, SVGPFA_KERNEL_PERIODIC = 1 };
+
+/* which parameter groups receive gradients -- the four closures of stats/svEM.py:218-264 */
+enum {
+  SVGPFA_GRAD_VARIATIONAL = 1, /* q(u) means + cholVecs   (_eStep)              */
+  SVGPFA_GRAD_EMBEDDING = 2,   /* C, d                    (_mStepEmbedding)     */
+  SVGPFA_GRAD_KERNELS = 4,     /* kernel hyper-parameters (_mStepKernels)       */
+  SVGPFA_GRAD_INDPOINTS = 8    /* inducing-point locations(_mStepIndPointsLocs) */
+};
+
+#define SVGPFA_MAX_IND 64      /* inducing points per latent handled by one wavefront   */
+#define SVGPFA_MAX_LATENTS 32
+
+typedef struct {
+  int32_t n_trials;            /* R (this engine's shard)                                */
+  int32_t n_neurons;           /* N                                                      */
+  int32_t n_latents;           /* K                                                      */
+  int32_t n_quad;              /* Q Gauss-Legendre nodes per trial                       */
+  const int32_t* n_ind;        /* [K] M_k, may differ per latent (utils/initUtils.py:402-415) */
+  const int32_t* kernel_type;  /* [K] SVGPFA_KERNEL_*                                    */
+  const double* scale;             /* [K] Kernel._scale            (NULL = 1.0)          */
+  const double* lengthscale_scale; /* [K] Kernel._lengthscaleScale (NULL = 1.0)          */
+  const double* period_scale;      /* [K] Kernel._periodScale      (NULL = 1.0)          */
+} svgpfa_dims;
+
+/* SVGPFAModelFactory.buildModelPyTorch (stats/svGPFAModelFactory.py:40-148), default options. */
+int svgpfa_create(const svgpfa_dims* dims, int device, svgpfa_engine** out);
+void svgpfa_destroy(svgpfa_engine* e);
+const char* svgpfa_last_error(const svgpfa_engine* e);
+
+/* Work is enqueued on this hipStream_t (pass torch.cuda.current_stream().cuda_stream). */
+int svgpfa_set_stream(svgpfa_engine* e, void* hip_stream);
+/* Wait for the stream; returns SVGPFA_ERR_NOT_PD if any enqueued factorisation failed
+ * since the last sync (then svgpfa_last_error names trial/latent). */
+int svgpfa_sync(svgpfa_engine* e);
+
+/* IndPointsLocsKMS.setRegParam (stats/kernelsMatricesStore.py:92-93). */
+int svgpfa_set_reg(svgpfa_engine* e, double eps);
+
+/* PointProcessELL.setELLCalculationParams (stats/expectedLogLikelihood.py:187-189):
+ * leg_quad_points / leg_quad_weights, R x Q each.  Copied into engine-owned HBM. */
+int svgpfa_set_quad(svgpfa_engine* e, const double* t_quad, const double* w_quad);
+
+/* PointProcessELL.setMeasurements + __stackSpikeTimes (stats/expectedLogLikelihood.py:149-173).
+ * CSR over trials; inside a trial spikes must be grouped by non-decreasing neuron index (the
+ * reference's stacking order).  offsets_host: R+1 int64 on the HOST; spike_times: S doubles,
+ * spike_neuron: S int32 on the device.  Copied into engine-owned HBM. */
+int svgpfa_set_spikes(svgpfa_engine* e, const int64_t* offsets_host,
+                      const double* spike_times, const int32_t* spike_neuron);
+
+/* SVLowerBound.buildKernelsMatrices (stats/svLowerBound.py:77-78 -> kernelsMatricesStore.py:107-117,
+ * utils/miscUtils.py:209-216): snapshot Z_k (R x M_k) and theta_k (1 or 2 doubles), build
+ * Kzz + eps*I, its Cholesky factor, and the inverse factor.  Ktz blocks are never materialised:
+ * later evaluations recompute kappa(t, Z) on the fly from this snapshot, exactly as the
+ * reference keeps using the matrices of its last buildKernelsMatrices() call. */
+int svgpfa_build_kernels(svgpfa_engine* e, const double* const* Z, const double* const* theta);
+
+/* Length (in doubles) of the `shared` output vector:
+ *   [0] ELBO  [1] ELL  [2] KL
+ *   [3 .. 3+N*K)            dELBO/dC   (row-major N x K)
+ *   [.. +N)                 dELBO/dd
+ *   [.. +sum_k ntheta_k)    dELBO/dtheta_k, latents in order
+ * These are exactly the quantities that must be summed over GPUs when trials are sharded. */
+int64_t svgpfa_shared_len(const svgpfa_engine* e);
+
+/* SVLowerBound.eval (stats/svLowerBound.py:47-54) and its autograd backward
+ * (stats/svEM.py:274-288) in one call.  Gradients are of +ELBO.  Groups not in grad_mask are
+ * neither computed nor written; their pointers may be NULL.  g_mean[k]: R x M_k,
+ * g_cholvec[k]: R x P_k (row-major tril order), g_Z[k]: R x M_k. */
+int svgpfa_elbo(svgpfa_engine* e,
+                const double* const* mean, const double* const* cholvec,
+                const double* C, const double* d,
+                unsigned grad_mask, double* shared,
+                double* const* g_mean, double* const* g_cholvec, double* const* g_Z);
+
+/* SVLowerBound.computeSVPosteriorOnLatentsStats (stats/svLowerBound.py:80-81):
+ * posterior mean/variance of every latent at the quadrature nodes and at the spikes.
+ * The results stay inside the engine (for svgpfa_ell_given_stats) and are also copied to
+ * the optional outputs: mu_quad/var_quad R x Q x K, mu_spk/var_spk S x K. */
+int svgpfa_latent_stats(svgpfa_engine* e,
+                        const double* const* mean, const double* const* cholvec,
+                        double* mu_quad, double* var_quad, double* mu_spk, double* var_spk);
+
+/* SVLowerBound.evalELLSumAcrossTrialsAndNeurons(svPosteriorOnLatentsStats=...)
+ * (stats/svLowerBound.py:72-75): ELL with the stats of the last svgpfa_latent_stats call frozen.
+ * out: [0] ELL, then dELL/dC (N x K), dELL/dd (N)  -- length 1 + N*K + N. */
+int svgpfa_ell_given_stats(svgpfa_engine* e, const double* C, const double* d,
+                           int want_grad, double* out);
+
+/* SVPosteriorOnLatentsAllTimes.predict (stats/svPosteriorOnLatents.py:57-77):
+ * times R x T (same T for every trial); mu/var R x T x K. */
+int svgpfa_predict(svgpfa_engine* e,
+                   const double* const* mean, const double* const* cholvec,
+                   const double* times, int32_t n_times, double* mu, double* var);
+
+/* KernelsMatricesStore getters used by the reference's tests
+ * (stats/kernelsMatricesStore.py:119-120,176-181): copy the matrices of latent k out.
+ * Kzz / Kzz_chol: R x M_k x M_k.  Ktz blocks are recomputed: quad R x Q x M_k, spikes S x M_k. */
+int svgpfa_get_kzz(svgpfa_engine* e, int32_t k, double* out);
+int svgpfa_get_kzz_chol(svgpfa_engine* e, int32_t k, double* out);
+int svgpfa_get_ktz_quad(svgpfa_engine* e, int32_t k, double* out);
+int svgpfa_get_ktz_spikes(svgpfa_engine* e, int32_t k, double* out);
+
+/* Timing hook for bench.py: device time (ms) of the most recent svgpfa_elbo call's dominant
+ * kernel (the spike-time pass), measured with hipEvents on the engine's stream; negative if
+ * event timing is disabled.  svgpfa_enable_timing(e, 1) turns it on. */
+int svgpfa_enable_timing(svgpfa_engine* e, int on);
+double svgpfa_last_spike_kernel_ms(svgpfa_engine* e);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SVGPFA_H */

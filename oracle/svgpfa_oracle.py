@@ -257,7 +257,7 @@ def elbo_and_grads(p, mask=GRAD_ALL):
         t.grad = None
     try:
         elbo, ell, kl = elbo_terms(p)
-        grads = torch.autograd.grad(elbo, leaves, allow_unused=True)
+        grads = torch.autograd.grad(elbo, leaves, allow_unused=True) if leaves else []
     finally:
         for t in leaves:
             t.requires_grad_(False)

@@ -1,0 +1,74 @@
+"""ctypes binding of libsvgpfa_hip.so (the C ABI declared in include/svgpfa.h).
+
+There is NO fallback: if the HIP library is missing or a symbol is absent, importing the
+engine fails loudly.  Build it with `python __graft_entry__.py` (or `make -C svgpfa_amd/csrc`).
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libsvgpfa_hip.so")
+
+OK, ERR_INVALID, ERR_NOT_PD, ERR_HIP, ERR_STATE, ERR_UNSUPPORTED = range(6)
+KERNEL_RBF, KERNEL_PERIODIC = 0, 1
+GRAD_VARIATIONAL, GRAD_EMBEDDING, GRAD_KERNELS, GRAD_INDPOINTS = 1, 2, 4, 8
+GRAD_ALL = 15
+
+
+class Dims(ctypes.Structure):
+    _fields_ = [("n_trials", ctypes.c_int32), ("n_neurons", ctypes.c_int32),
+                ("n_latents", ctypes.c_int32), ("n_quad", ctypes.c_int32),
+                ("n_ind", ctypes.POINTER(ctypes.c_int32)),
+                ("kernel_type", ctypes.POINTER(ctypes.c_int32)),
+                ("scale", ctypes.POINTER(ctypes.c_double)),
+                ("lengthscale_scale", ctypes.POINTER(ctypes.c_double)),
+                ("period_scale", ctypes.POINTER(ctypes.c_double))]
+
+
+_vp = ctypes.c_void_p
+_vpp = ctypes.POINTER(ctypes.c_void_p)
+_i32, _i64, _u32, _f64 = ctypes.c_int32, ctypes.c_int64, ctypes.c_uint, ctypes.c_double
+
+# name -> (restype, argtypes): every symbol include/svgpfa.h declares
+SIGNATURES = {
+    "svgpfa_create": (ctypes.c_int, [ctypes.POINTER(Dims), ctypes.c_int, ctypes.POINTER(_vp)]),
+    "svgpfa_destroy": (None, [_vp]),
+    "svgpfa_last_error": (ctypes.c_char_p, [_vp]),
+    "svgpfa_set_stream": (ctypes.c_int, [_vp, _vp]),
+    "svgpfa_sync": (ctypes.c_int, [_vp]),
+    "svgpfa_set_reg": (ctypes.c_int, [_vp, _f64]),
+    "svgpfa_set_quad": (ctypes.c_int, [_vp, _vp, _vp]),
+    "svgpfa_set_spikes": (ctypes.c_int, [_vp, ctypes.POINTER(_i64), _vp, _vp]),
+    "svgpfa_build_kernels": (ctypes.c_int, [_vp, _vpp, _vpp]),
+    "svgpfa_shared_len": (_i64, [_vp]),
+    "svgpfa_elbo": (ctypes.c_int, [_vp, _vpp, _vpp, _vp, _vp, _u32, _vp, _vpp, _vpp, _vpp]),
+    "svgpfa_latent_stats": (ctypes.c_int, [_vp, _vpp, _vpp, _vp, _vp, _vp, _vp]),
+    "svgpfa_ell_given_stats": (ctypes.c_int, [_vp, _vp, _vp, ctypes.c_int, _vp]),
+    "svgpfa_predict": (ctypes.c_int, [_vp, _vpp, _vpp, _vp, _i32, _vp, _vp]),
+    "svgpfa_get_kzz": (ctypes.c_int, [_vp, _i32, _vp]),
+    "svgpfa_get_kzz_chol": (ctypes.c_int, [_vp, _i32, _vp]),
+    "svgpfa_get_ktz_quad": (ctypes.c_int, [_vp, _i32, _vp]),
+    "svgpfa_get_ktz_spikes": (ctypes.c_int, [_vp, _i32, _vp]),
+    "svgpfa_enable_timing": (ctypes.c_int, [_vp, ctypes.c_int]),
+    "svgpfa_last_spike_kernel_ms": (_f64, [_vp]),
+}
+
+_lib = None
+
+
+def load():
+    """Load the in-tree HIP library and bind every declared symbol (raises if anything is missing)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} not found: the svGPFA HIP engine is not built. "
+            "Run `python __graft_entry__.py` (hipcc --offload-arch=gfx950). There is no CPU fallback.")
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the symbol is absent
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib

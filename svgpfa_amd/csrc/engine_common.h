@@ -1,0 +1,164 @@
+// Shared host/device definitions of the svGPFA ELBO engine (gfx950 only).
+//
+// HBM layout (all fp64, engine-owned unless noted).  R trials, K latents, M_k inducing
+// points, Q quadrature nodes, S spikes on this GPU.
+//   per-latent blocks   X[k]  : base offM[k]  = R * sum_{k'<k} M_k'      element (r, j)    at offM  + r*M   + j
+//                       XX[k] : base offMM[k] = R * sum_{k'<k} M_k'^2    element (r, i, j) at offMM + r*M*M + i*M + j
+//   Zs (snapshot of Z), a = Kzz^-1 m, ut = L^-1 m, adjoint of ut          : X layout
+//   Kzz, L = chol(Kzz), Linv = L^-1, Vt = L^-1 L_S, adjoint Gt of (Vt Vt^T) : XX layout
+// Everything downstream of the Cholesky works in WHITENED coordinates (kt = L^-1 kappa(t, Z),
+// ut = L^-1 m, Vt = L^-1 L_S): mu = kt.ut, var = s2 - |kt|^2 + |Vt^T kt|^2.  All whitened
+// quantities are O(1), which keeps fp64 error at ~sqrt(cond(Kzz)) u instead of cond(Kzz)^2 u
+// for the explicit-inverse algebra (measured against a 40-digit referee, tests/tools/).
+//   quad stats mu/var/gmu/gvar : [r][q][k]
+//   spikes: times[S], neuron[S] (CSR over trials, neuron-major inside a trial), mu_spk[k][S]
+//   spike chunks: <= SPIKE_CHUNK spikes of one trial; partial sums P0/P1 [chunk][sumM], T [chunk][K][2]
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define SV_RBF 0
+#define SV_PERIODIC 1
+#define SV_MAX_M 64
+#define SV_MAX_K 32
+
+#define SV_SPL 8                      // spikes per lane in the spike pass
+#define SV_SPIKE_CHUNK (64 * SV_SPL)  // spikes per wavefront work item
+
+struct LatentMeta {
+  int M, P, ktype, nth;
+  long long offM, offMM;
+  int colM;    // sum_{k'<k} M_k'
+  int thoff;   // sum_{k'<k} nth_k'
+  double scale2, inv_ls_scale, inv_p_scale;
+};
+
+struct LatentPtrs {
+  const double* mean;
+  const double* cholvec;
+  double* g_mean;
+  double* g_cholvec;
+  double* g_Z;
+};
+
+struct SpikeChunk {
+  int trial;
+  int count;
+  long long start;  // global spike index of the first spike of the chunk
+};
+
+// Everything a kernel needs, passed by value (fits well inside the kernarg segment).
+struct EngineView {
+  int R, N, K, Q, S;
+  int sumM, nchunks, nqt, qtile, nth_total;
+  double reg;
+  const LatentMeta* meta;
+  const double* tq;
+  const double* wq;
+  const double* spk_t;
+  const int* spk_n;
+  const long long* spk_off;   // R+1
+  const long long* seg_off;   // R*N+1 : first spike of (trial, neuron)
+  const double* spk_cnt;      // N     : spikes per neuron over all local trials
+  const SpikeChunk* chunks;
+  const int* chunk_first;     // R+1   : first chunk of each trial
+  double* Zs;
+  double* theta;              // K x 2 snapshot
+  double* Kzz; double* L; double* Linv;
+  double* a; double* ut; double* Vt; double* klpart;   // klpart [R*K]
+  double* muq; double* varq; double* gmuq; double* gvarq;
+  double* gaq; double* GW; double* gZq; double* gthq;   // quad-side adjoints of ut, Vt Vt^T, direct Z / theta; gthq [R*K*2]
+  double* P0; double* P1; double* Tpart;           // spike partials
+  double* muspk;                                   // [K][S]
+  double* varspk;                                  // [K][S] (stats API only)
+  double* gCpart; double* gdpart; double* ellq;    // [R*nqt][N][K], [R*nqt][N], [R*nqt]
+  double* ells; double* gthitem;                   // [R*K], [R*K*2]
+  double* Mseg;                                    // [N][K] sum over spikes of mu_spk per neuron (stats path)
+  int* status;
+};
+
+// ------------------------------------------------------------------ covariance functions
+// kappa(x1, x2) = s2 * ktil(delta), delta = x1 - x2.
+//   RBF      (reference stats/kernels.py:33-46): ktil = exp(-delta^2 * h),        h = 1/(2 l^2)
+//   periodic (reference stats/kernels.py:73-85): ktil = exp(-sin^2(pi delta/p) h), h = 2/l^2
+// Derivatives are expressed through basis values (bz, b0, b1) and constants (cz, c0, c1):
+//   d kappa / d x2      = ktil * bz * cz
+//   d kappa / d theta_0 = ktil * b0 * c0        (lengthscale, unscaled parameter)
+//   d kappa / d theta_1 = ktil * b1 * c1        (period, unscaled parameter; periodic only)
+struct KPar {
+  double s2, h, ip, cz, c0, c1;
+};
+
+__device__ __forceinline__ KPar make_kpar(const LatentMeta& m, const double* th) {
+  KPar p;
+  const double PI = 3.14159265358979323846;
+  double l = th[0] * m.inv_ls_scale;
+  p.s2 = m.scale2;
+  if (m.ktype == SV_RBF) {
+    p.h = 0.5 / (l * l);
+    p.ip = 0.0;
+    p.cz = p.s2 * 2.0 * p.h;
+    p.c0 = p.s2 * 2.0 * p.h / l * m.inv_ls_scale;
+    p.c1 = 0.0;
+  } else {
+    double per = th[1] * m.inv_p_scale;
+    p.ip = 1.0 / per;
+    p.h = 2.0 / (l * l);
+    p.cz = p.s2 * PI * p.h * p.ip;
+    p.c0 = p.s2 * 2.0 * p.h / l * m.inv_ls_scale;
+    p.c1 = p.s2 * PI * p.h * p.ip * p.ip * m.inv_p_scale;
+  }
+  return p;
+}
+
+template <int KT>
+__device__ __forceinline__ double kern_val(double delta, const KPar& p) {
+  if (KT == SV_RBF) {
+    return exp(-(delta * delta) * p.h);
+  } else {
+    double u = delta * p.ip;
+    double r = u - rint(u);
+    double sn = sinpi(r);
+    return exp(-(sn * sn) * p.h);
+  }
+}
+
+template <int KT>
+__device__ __forceinline__ void kern_eval(double delta, const KPar& p, double& kt, double& bz,
+                                          double& b0, double& b1) {
+  if (KT == SV_RBF) {
+    double q = delta * delta;
+    kt = exp(-q * p.h);
+    bz = delta;
+    b0 = q;
+    b1 = 0.0;
+  } else {
+    double u = delta * p.ip;
+    double r = u - rint(u);
+    double sn, cs;
+    sincospi(r, &sn, &cs);
+    double ss = sn * sn;
+    kt = exp(-ss * p.h);
+    bz = 2.0 * sn * cs;
+    b0 = ss;
+    b1 = delta * bz;
+  }
+}
+
+__device__ __forceinline__ double wave_sum(double x) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) x += __shfl_xor(x, o, 64);
+  return x;
+}
+
+// Deterministic block sum (fixed tree); `red` needs blockDim.x/64 doubles.  All threads get the result.
+__device__ __forceinline__ double block_sum(double x, double* red) {
+  x = wave_sum(x);
+  int w = threadIdx.x >> 6, nw = blockDim.x >> 6;
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) red[w] = x;
+  __syncthreads();
+  double s = 0.0;
+  for (int i = 0; i < nw; ++i) s += red[i];
+  return s;
+}

@@ -1,0 +1,236 @@
+// Spike-time pass: the dominant kernel (sum_k R M_k S_r kernel evaluations per ELBO).
+//
+// One wavefront per (spike chunk, latent).  Each lane owns SV_SPL spikes of the chunk (times and
+// embedding weights c_s = C[n_s, k] in registers); the inducing points z_j and a_j = (Kzz^-1 m)_j
+// are wave-uniform.  For the exponential link the spike term of the ELL needs only the posterior
+// MEAN, whose adjoint is known a priori (d ELL / d mu_k(t_s) = C[n_s, k]), so value and all
+// gradients come out of ONE pass over kappa(t_s, z_j):
+//   P0_j = sum_s c_s ktil_sj            -> g_a_j = s2 P0_j, ELL_spk = a . g_a
+//   P1_j = sum_s c_s ktil_sj bz_sj      -> direct dZ_j = a_j cz P1_j
+//   T_t  = sum_s c_s sum_j a_j ktil_sj bt_sj -> direct dtheta_t = c_t T_t
+//   mu_s = s2 sum_j ktil_sj a_j         -> dC[n_s, k] (segment sums per neuron)
+// Replaces the reference's K*R Python loop of kernelsMatricesStore.py:208-221,
+// svPosteriorOnLatents.py:265-300 and svEmbedding.py:137-144; Ktz is never materialised.
+#pragma once
+#include "engine_common.h"
+
+template <int KT, bool FULL>
+__device__ void spike_body(const EngineView& ev, const double* __restrict__ C, int ch, int k,
+                           double* red) {
+  const int lane = threadIdx.x;
+  const SpikeChunk c = ev.chunks[ch];
+  const LatentMeta m = ev.meta[k];
+  const int M = m.M, K = ev.K, r = c.trial;
+  const KPar p = make_kpar(m, ev.theta + 2 * k);
+  const double* __restrict__ z = ev.Zs + m.offM + (long long)r * M;
+  const double* __restrict__ a = ev.a + m.offM + (long long)r * M;
+
+  double t[SV_SPL], cw[SV_SPL], mu[SV_SPL], T0[SV_SPL], T1[SV_SPL];
+#pragma unroll
+  for (int i = 0; i < SV_SPL; ++i) {
+    int idx = i * 64 + lane;
+    bool ok = idx < c.count;
+    long long gs = c.start + (ok ? idx : 0);
+    t[i] = ev.spk_t[gs];
+    cw[i] = ok ? C[(long long)ev.spk_n[gs] * K + k] : 0.0;
+    mu[i] = 0.0;
+    T0[i] = 0.0;
+    T1[i] = 0.0;
+  }
+
+  for (int jb = 0; jb < M; jb += 8) {
+#pragma unroll
+    for (int jj = 0; jj < 8; ++jj) {
+      const int j = jb + jj;
+      double p0 = 0.0, p1 = 0.0;
+      if (j < M) {
+        const double zj = z[j], aj = a[j];
+#pragma unroll
+        for (int i = 0; i < SV_SPL; ++i) {
+          if (FULL) {
+            double kt, bz, b0, b1;
+            kern_eval<KT>(t[i] - zj, p, kt, bz, b0, b1);
+            double ck = cw[i] * kt;
+            p0 += ck;
+            p1 = fma(ck, bz, p1);
+            double w = kt * aj;
+            mu[i] += w;
+            T0[i] = fma(w, b0, T0[i]);
+            if (KT == SV_PERIODIC) T1[i] = fma(w, b1, T1[i]);
+          } else {
+            p0 = fma(cw[i], kern_val<KT>(t[i] - zj, p), p0);
+          }
+        }
+      }
+      red[jj * 65 + lane] = p0;
+      if (FULL) red[(8 + jj) * 65 + lane] = p1;
+    }
+    __syncthreads();
+    // transposed reduction: 16 vectors x 64 lanes -> lane (v, quarter) sums 16 elements
+    {
+      const int v = lane & 15, qd = lane >> 4;
+      double s = 0.0;
+      if (FULL || v < 8) {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) s += red[v * 65 + qd * 16 + e];
+      }
+      s += __shfl_xor(s, 16, 64);
+      s += __shfl_xor(s, 32, 64);
+      const int j = jb + (v & 7);
+      if (lane < 16 && j < M) {
+        long long o = (long long)ch * ev.sumM + m.colM + j;
+        if (v < 8)
+          ev.P0[o] = s;
+        else if (FULL)
+          ev.P1[o] = s;
+      }
+    }
+    __syncthreads();
+  }
+
+  if (FULL) {
+    double t0 = 0.0, t1 = 0.0;
+#pragma unroll
+    for (int i = 0; i < SV_SPL; ++i) {
+      int idx = i * 64 + lane;
+      if (idx < c.count) ev.muspk[(long long)k * ev.S + c.start + idx] = p.s2 * mu[i];
+      t0 = fma(cw[i], T0[i], t0);
+      t1 = fma(cw[i], T1[i], t1);
+    }
+    t0 = wave_sum(t0);
+    t1 = wave_sum(t1);
+    if (lane == 0) {
+      ev.Tpart[((long long)ch * K + k) * 2 + 0] = t0;
+      ev.Tpart[((long long)ch * K + k) * 2 + 1] = t1;
+    }
+  }
+}
+
+template <bool FULL>
+__global__ __launch_bounds__(64) void k_spike(EngineView ev, const double* __restrict__ C) {
+  __shared__ double red[16 * 65];
+  const int item = blockIdx.x;
+  const int ch = item / ev.K, k = item % ev.K;
+  if (ev.meta[k].ktype == SV_RBF)
+    spike_body<SV_RBF, FULL>(ev, C, ch, k, red);
+  else
+    spike_body<SV_PERIODIC, FULL>(ev, C, ch, k, red);
+}
+
+// dC from the spike term: segment sums of mu_spk over the spikes of each (trial, neuron),
+// added to the trial's first quadrature-block partial.  Thread = (k, trial*N + neuron).
+__global__ void k_spike_gc(EngineView ev) {
+  long long id = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  long long RN = (long long)ev.R * ev.N;
+  if (id >= RN * ev.K) return;
+  int k = (int)(id / RN);
+  long long rn = id % RN;
+  int r = (int)(rn / ev.N), n = (int)(rn % ev.N);
+  double s = 0.0;
+  for (long long i = ev.seg_off[rn]; i < ev.seg_off[rn + 1]; ++i) s += ev.muspk[(long long)k * ev.S + i];
+  ev.gCpart[(((long long)r * ev.nqt) * ev.N + n) * ev.K + k] += s;
+}
+
+// Mseg[n][k] = sum over all local spikes of neuron n of mu_k(t_s)   (embedding M-step path)
+__global__ void k_mseg(EngineView ev) {
+  int id = blockIdx.x * blockDim.x + threadIdx.x;
+  if (id >= ev.N * ev.K) return;
+  int n = id / ev.K, k = id % ev.K;
+  double s = 0.0;
+  for (int r = 0; r < ev.R; ++r) {
+    long long rn = (long long)r * ev.N + n;
+    double sr = 0.0;
+    for (long long i = ev.seg_off[rn]; i < ev.seg_off[rn + 1]; ++i) sr += ev.muspk[(long long)k * ev.S + i];
+    s += sr;
+  }
+  ev.Mseg[id] = s;
+}
+
+// ------------------------------------------------------------------------------ k_finalize
+// Fixed-order reductions of the per-trial partials into the `shared` output vector
+// [ELBO, ELL, KL, dC (N*K), dd (N), dtheta].  Last block does the three scalars.
+__global__ __launch_bounds__(256) void k_finalize(EngineView ev, const double* d, unsigned mask,
+                                                  double* shared) {
+  __shared__ double red[4];
+  const int tid = threadIdx.x;
+  const int NK = ev.N * ev.K, nblk = ev.R * ev.nqt;
+  if (blockIdx.x == gridDim.x - 1) {
+    double e = 0.0, kl = 0.0;
+    for (int i = tid; i < nblk; i += 256) e += ev.ellq[i];
+    for (int i = tid; i < ev.R * ev.K; i += 256) {
+      e += ev.ells[i];
+      kl += ev.klpart[i];
+    }
+    for (int n = tid; n < ev.N; n += 256) e += ev.spk_cnt[n] * d[n];
+    e = block_sum(e, red);
+    kl = block_sum(kl, red);
+    if (tid == 0) {
+      shared[0] = e - kl;
+      shared[1] = e;
+      shared[2] = kl;
+    }
+    return;
+  }
+  int id = blockIdx.x * 256 + tid;
+  if (id < NK) {
+    double s = 0.0;
+    if (mask & 2u)
+      for (int b = 0; b < nblk; ++b) s += ev.gCpart[(long long)b * NK + id];
+    shared[3 + id] = s;
+  } else if (id < NK + ev.N) {
+    int n = id - NK;
+    double s = 0.0;
+    if (mask & 2u) {
+      for (int b = 0; b < nblk; ++b) s += ev.gdpart[(long long)b * ev.N + n];
+      s += ev.spk_cnt[n];
+    }
+    shared[3 + id] = s;
+  } else if (id < NK + ev.N + ev.nth_total) {
+    int ti = id - NK - ev.N;
+    int k = 0;
+    while (k + 1 < ev.K && ev.meta[k + 1].thoff <= ti) ++k;
+    int t = ti - ev.meta[k].thoff;
+    double s = 0.0;
+    if (mask & 4u)
+      for (int r = 0; r < ev.R; ++r) s += ev.gthitem[((long long)r * ev.K + k) * 2 + t];
+    shared[3 + id] = s;
+  }
+}
+
+// ELL with frozen latent stats (embedding M-step closure): out = [ELL, dC, dd]
+__global__ __launch_bounds__(256) void k_finalize_stats(EngineView ev, const double* C, const double* d,
+                                                        int want_grad, double* out) {
+  __shared__ double red[4];
+  const int tid = threadIdx.x;
+  const int NK = ev.N * ev.K, nblk = ev.R * ev.nqt;
+  if (blockIdx.x == gridDim.x - 1) {
+    double e = 0.0;
+    for (int i = tid; i < nblk; i += 256) e += ev.ellq[i];
+    for (int i = tid; i < NK; i += 256) e += C[i] * ev.Mseg[i];
+    for (int n = tid; n < ev.N; n += 256) e += ev.spk_cnt[n] * d[n];
+    e = block_sum(e, red);
+    if (tid == 0) out[0] = e;
+    return;
+  }
+  if (!want_grad) return;
+  int id = blockIdx.x * 256 + tid;
+  if (id < NK) {
+    double s = 0.0;
+    for (int b = 0; b < nblk; ++b) s += ev.gCpart[(long long)b * NK + id];
+    out[1 + id] = s + ev.Mseg[id];
+  } else if (id < NK + ev.N) {
+    int n = id - NK;
+    double s = 0.0;
+    for (int b = 0; b < nblk; ++b) s += ev.gdpart[(long long)b * ev.N + n];
+    out[1 + id] = s + ev.spk_cnt[n];
+  }
+}
+
+// [K][S] -> [S][K] copy for the stats API
+__global__ void k_transpose_ks(const double* in, double* out, long long S, int K) {
+  long long id = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (id >= S * K) return;
+  long long s = id / K;
+  int k = (int)(id % K);
+  out[id] = in[(long long)k * S + s];
+}

@@ -1,0 +1,525 @@
+// libsvgpfa_hip.so -- C ABI of the MI355X-native svGPFA ELBO engine (see include/svgpfa.h).
+// Host side: owns HBM buffers, validates shapes, enqueues the kernel pipeline on one HIP stream.
+#include "../../include/svgpfa.h"
+
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "engine_common.h"
+#include "kernels_item.h"
+#include "kernels_spike.h"
+#include "kernels_times.h"
+
+struct PtrTable {
+  LatentPtrs p[SV_MAX_K];
+};
+
+// k_prep / k_bwd read the caller's per-latent tensors: the pointer table travels by value in
+// the kernarg segment, so nothing has to be staged through HBM when the caller's tensors move.
+__global__ __launch_bounds__(64) void k_prep_entry(EngineView ev, PtrTable pt);
+__global__ __launch_bounds__(64) void k_bwd_entry(EngineView ev, PtrTable pt, unsigned mask);
+
+struct svgpfa_engine {
+  EngineView v{};
+  std::vector<LatentMeta> meta;
+  std::vector<void*> allocs;
+  hipStream_t stream = nullptr;
+  int device = 0;
+  int Mmax = 0, KT = 0;
+  long long totM = 0, totMM = 0;  // R*sum M, R*sum M^2
+  bool have_quad = false, have_spikes = false, have_kernels = false, have_stats = false;
+  bool timing = false;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  bool ev_valid = false;
+  std::string err;
+  int* status_host = nullptr;  // pinned
+};
+
+#define HIPCHK(e, call)                                                                  \
+  do {                                                                                   \
+    hipError_t _s = (call);                                                              \
+    if (_s != hipSuccess) {                                                              \
+      (e)->err = std::string(#call) + ": " + hipGetErrorString(_s);                      \
+      return SVGPFA_ERR_HIP;                                                             \
+    }                                                                                    \
+  } while (0)
+
+#define FAIL(e, code, msg) \
+  do {                     \
+    (e)->err = (msg);      \
+    return (code);         \
+  } while (0)
+
+template <typename T>
+static int dalloc(svgpfa_engine* e, T** p, size_t n) {
+  void* q = nullptr;
+  if (n == 0) n = 1;
+  hipError_t s = hipMalloc(&q, n * sizeof(T));
+  if (s != hipSuccess) {
+    e->err = std::string("hipMalloc: ") + hipGetErrorString(s);
+    return SVGPFA_ERR_HIP;
+  }
+  e->allocs.push_back(q);
+  *p = (T*)q;
+  return SVGPFA_OK;
+}
+#define DALLOC(e, p, n)                      \
+  do {                                       \
+    int _r = dalloc((e), &(p), (size_t)(n)); \
+    if (_r) return _r;                       \
+  } while (0)
+
+static size_t lds_build(int M) { return (size_t)2 * M * (M + 1) * 8; }
+static size_t lds_prep(int M) { return ((size_t)M * (M + 1) + 128) * 8; }
+static size_t lds_bwd(int M) { return ((size_t)4 * M * (M + 1) + 256) * 8; }
+static size_t lds_times(int M) { return ((size_t)2 * M * (M + 1) + 128 * (M + 1) + 128 + 768) * 8; }
+static size_t lds_qbwd(int M) {
+  int QB = (M <= 32) ? 64 : 32;
+  return ((size_t)2 * M * (M + 1) + (size_t)3 * QB * (M + 1) + 64 * 5 + 4) * 8;
+}
+static size_t lds_qell(const svgpfa_engine* e) {
+  return ((size_t)2 * e->v.qtile * e->KT + e->v.qtile + (size_t)e->v.N * e->KT + e->v.N + 4) * 8;
+}
+
+__global__ __launch_bounds__(64) void k_prep_entry(EngineView ev, PtrTable pt) {
+  extern __shared__ double sm[];
+  k_prep_body(ev, pt.p[blockIdx.x % ev.K], sm);
+}
+__global__ __launch_bounds__(64) void k_bwd_entry(EngineView ev, PtrTable pt, unsigned mask) {
+  extern __shared__ double sm[];
+  k_bwd_body(ev, pt.p[blockIdx.x % ev.K], mask, sm);
+}
+
+template <typename F>
+static int allow_lds(svgpfa_engine* e, F f, size_t bytes) {
+  if (bytes > 160 * 1024) FAIL(e, SVGPFA_ERR_UNSUPPORTED, "problem needs more than 160 KiB of LDS per workgroup");
+  if (bytes > 48 * 1024)
+    HIPCHK(e, hipFuncSetAttribute((const void*)f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+  return SVGPFA_OK;
+}
+
+extern "C" {
+
+int svgpfa_create(const svgpfa_dims* d, int device, svgpfa_engine** out) {
+  if (!d || !out) return SVGPFA_ERR_INVALID;
+  *out = nullptr;
+  svgpfa_engine* e = new svgpfa_engine();
+  *out = e;  // returned even on failure so that the caller can read last_error, then destroy
+  e->device = device;
+  if (d->n_trials <= 0 || d->n_neurons <= 0 || d->n_latents <= 0 || d->n_quad <= 0 || !d->n_ind ||
+      !d->kernel_type)
+    FAIL(e, SVGPFA_ERR_INVALID, "svgpfa_create: non-positive dimension or NULL descriptor array");
+  if (d->n_latents > SV_MAX_K) FAIL(e, SVGPFA_ERR_UNSUPPORTED, "n_latents > 32");
+  HIPCHK(e, hipSetDevice(device));
+  EngineView& v = e->v;
+  v.R = d->n_trials; v.N = d->n_neurons; v.K = d->n_latents; v.Q = d->n_quad;
+  v.reg = 0.0;
+  e->meta.resize(v.K);
+  long long offM = 0, offMM = 0;
+  int colM = 0, thoff = 0;
+  for (int k = 0; k < v.K; ++k) {
+    LatentMeta& m = e->meta[k];
+    m.M = d->n_ind[k];
+    if (m.M <= 0 || m.M > SV_MAX_M) FAIL(e, SVGPFA_ERR_UNSUPPORTED, "inducing points per latent must be in 1..64");
+    m.P = m.M * (m.M + 1) / 2;
+    m.ktype = d->kernel_type[k];
+    if (m.ktype != SV_RBF && m.ktype != SV_PERIODIC) FAIL(e, SVGPFA_ERR_INVALID, "unknown kernel type");
+    m.nth = (m.ktype == SV_RBF) ? 1 : 2;
+    m.offM = offM; m.offMM = offMM; m.colM = colM; m.thoff = thoff;
+    double s = d->scale ? d->scale[k] : 1.0;
+    m.scale2 = s * s;
+    m.inv_ls_scale = 1.0 / (d->lengthscale_scale ? d->lengthscale_scale[k] : 1.0);
+    m.inv_p_scale = 1.0 / (d->period_scale ? d->period_scale[k] : 1.0);
+    offM += (long long)v.R * m.M;
+    offMM += (long long)v.R * m.M * m.M;
+    colM += m.M;
+    thoff += m.nth;
+    e->Mmax = std::max(e->Mmax, m.M);
+  }
+  e->totM = offM; e->totMM = offMM;
+  v.sumM = colM; v.nth_total = thoff;
+  v.qtile = std::min(v.Q, 256);
+  v.nqt = (v.Q + v.qtile - 1) / v.qtile;
+  e->KT = 4 * ((v.K + 3) / 4);
+
+  LatentMeta* dmeta; DALLOC(e, dmeta, v.K);
+  HIPCHK(e, hipMemcpy(dmeta, e->meta.data(), sizeof(LatentMeta) * v.K, hipMemcpyHostToDevice));
+  v.meta = dmeta;
+  double* tq; double* wq; DALLOC(e, tq, (size_t)v.R * v.Q); DALLOC(e, wq, (size_t)v.R * v.Q);
+  v.tq = tq; v.wq = wq;
+  DALLOC(e, v.Zs, e->totM); DALLOC(e, v.theta, 2 * v.K);
+  DALLOC(e, v.Kzz, e->totMM); DALLOC(e, v.L, e->totMM); DALLOC(e, v.Linv, e->totMM);
+  DALLOC(e, v.a, e->totM); DALLOC(e, v.ut, e->totM); DALLOC(e, v.Vt, e->totMM); DALLOC(e, v.klpart, (size_t)v.R * v.K);
+  size_t rqk = (size_t)v.R * v.Q * v.K;
+  DALLOC(e, v.muq, rqk); DALLOC(e, v.varq, rqk); DALLOC(e, v.gmuq, rqk); DALLOC(e, v.gvarq, rqk);
+  DALLOC(e, v.gaq, e->totM); DALLOC(e, v.GW, e->totMM); DALLOC(e, v.gZq, e->totM);
+  DALLOC(e, v.gthq, (size_t)v.R * v.K * 2);
+  size_t nblk = (size_t)v.R * v.nqt;
+  DALLOC(e, v.gCpart, nblk * v.N * v.K); DALLOC(e, v.gdpart, nblk * v.N); DALLOC(e, v.ellq, nblk);
+  DALLOC(e, v.ells, (size_t)v.R * v.K); DALLOC(e, v.gthitem, (size_t)v.R * v.K * 2);
+  DALLOC(e, v.Mseg, (size_t)v.N * v.K);
+  DALLOC(e, v.status, 1);
+  HIPCHK(e, hipMemset(v.status, 0, sizeof(int)));
+  HIPCHK(e, hipMemset(v.gaq, 0, sizeof(double) * e->totM));
+  HIPCHK(e, hipMemset(v.GW, 0, sizeof(double) * e->totMM));
+  HIPCHK(e, hipMemset(v.gZq, 0, sizeof(double) * e->totM));
+  HIPCHK(e, hipMemset(v.gthq, 0, sizeof(double) * v.R * v.K * 2));
+  HIPCHK(e, hipHostMalloc((void**)&e->status_host, sizeof(int)));
+  HIPCHK(e, hipEventCreate(&e->ev0));
+  HIPCHK(e, hipEventCreate(&e->ev1));
+
+  int rc;
+  if ((rc = allow_lds(e, k_build, lds_build(e->Mmax)))) return rc;
+  if ((rc = allow_lds(e, k_prep_entry, lds_prep(e->Mmax)))) return rc;
+  if ((rc = allow_lds(e, k_bwd_entry, lds_bwd(e->Mmax)))) return rc;
+  if ((rc = allow_lds(e, k_times_fwd, lds_times(e->Mmax)))) return rc;
+  if ((rc = allow_lds(e, k_quad_bwd<true>, lds_qbwd(e->Mmax)))) return rc;
+  if ((rc = allow_lds(e, k_quad_bwd<false>, lds_qbwd(e->Mmax)))) return rc;
+  size_t lq = lds_qell(e);
+  switch (e->KT) {
+#define CASE_KT(X) case X: rc = allow_lds(e, k_quad_ell<X>, lq); break;
+    CASE_KT(4) CASE_KT(8) CASE_KT(12) CASE_KT(16) CASE_KT(20) CASE_KT(24) CASE_KT(28) CASE_KT(32)
+#undef CASE_KT
+    default: FAIL(e, SVGPFA_ERR_UNSUPPORTED, "n_latents > 32");
+  }
+  if (rc) return rc;
+  return SVGPFA_OK;
+}
+
+void svgpfa_destroy(svgpfa_engine* e) {
+  if (!e) return;
+  (void)hipSetDevice(e->device);
+  (void)hipDeviceSynchronize();
+  for (void* p : e->allocs) (void)hipFree(p);
+  if (e->status_host) (void)hipHostFree(e->status_host);
+  if (e->ev0) (void)hipEventDestroy(e->ev0);
+  if (e->ev1) (void)hipEventDestroy(e->ev1);
+  delete e;
+}
+
+const char* svgpfa_last_error(const svgpfa_engine* e) { return e ? e->err.c_str() : "null engine"; }
+
+int svgpfa_set_stream(svgpfa_engine* e, void* s) {
+  if (!e) return SVGPFA_ERR_INVALID;
+  e->stream = (hipStream_t)s;
+  return SVGPFA_OK;
+}
+
+int svgpfa_sync(svgpfa_engine* e) {
+  if (!e) return SVGPFA_ERR_INVALID;
+  HIPCHK(e, hipMemcpyAsync(e->status_host, e->v.status, sizeof(int), hipMemcpyDeviceToHost, e->stream));
+  HIPCHK(e, hipStreamSynchronize(e->stream));
+  int st = *e->status_host;
+  if (st != 0) {
+    HIPCHK(e, hipMemsetAsync(e->v.status, 0, sizeof(int), e->stream));
+    int item = st - 1;
+    char buf[160];
+    snprintf(buf, sizeof buf,
+             "Kzz + eps*I is not positive definite (local trial %d, latent %d): Cholesky failed",
+             item / e->v.K, item % e->v.K);
+    e->have_kernels = false;
+    FAIL(e, SVGPFA_ERR_NOT_PD, buf);
+  }
+  return SVGPFA_OK;
+}
+
+int svgpfa_set_reg(svgpfa_engine* e, double eps) {
+  if (!e) return SVGPFA_ERR_INVALID;
+  e->v.reg = eps;
+  return SVGPFA_OK;
+}
+
+int svgpfa_set_quad(svgpfa_engine* e, const double* t, const double* w) {
+  if (!e || !t || !w) return SVGPFA_ERR_INVALID;
+  size_t n = sizeof(double) * e->v.R * e->v.Q;
+  HIPCHK(e, hipMemcpyAsync((void*)e->v.tq, t, n, hipMemcpyDeviceToDevice, e->stream));
+  HIPCHK(e, hipMemcpyAsync((void*)e->v.wq, w, n, hipMemcpyDeviceToDevice, e->stream));
+  e->have_quad = true;
+  e->have_stats = false;
+  return SVGPFA_OK;
+}
+
+int svgpfa_set_spikes(svgpfa_engine* e, const int64_t* off, const double* times, const int32_t* neuron) {
+  if (!e || !off) return SVGPFA_ERR_INVALID;
+  EngineView& v = e->v;
+  if (e->have_spikes) FAIL(e, SVGPFA_ERR_STATE, "svgpfa_set_spikes may be called once per engine");
+  if (off[0] != 0) FAIL(e, SVGPFA_ERR_INVALID, "spike offsets must start at 0");
+  for (int r = 0; r < v.R; ++r)
+    if (off[r + 1] < off[r]) FAIL(e, SVGPFA_ERR_INVALID, "spike offsets must be non-decreasing");
+  const long long S = off[v.R];
+  if (S > 0 && (!times || !neuron)) return SVGPFA_ERR_INVALID;
+  if (S > 2000000000LL) FAIL(e, SVGPFA_ERR_UNSUPPORTED, "more than 2e9 spikes on one GPU");
+  v.S = (int)S;
+  std::vector<int32_t> nh((size_t)S);
+  if (S) HIPCHK(e, hipMemcpy(nh.data(), neuron, sizeof(int32_t) * S, hipMemcpyDeviceToHost));
+  std::vector<long long> seg((size_t)v.R * v.N + 1);
+  std::vector<double> cnt(v.N, 0.0);
+  std::vector<SpikeChunk> chunks;
+  std::vector<int> cfirst(v.R + 1);
+  for (int r = 0; r < v.R; ++r) {
+    long long s0 = off[r], s1 = off[r + 1];
+    long long i = s0;
+    for (int n = 0; n < v.N; ++n) {
+      seg[(size_t)r * v.N + n] = i;
+      while (i < s1 && nh[i] == n) { ++i; cnt[n] += 1.0; }
+    }
+    if (i != s1)
+      FAIL(e, SVGPFA_ERR_INVALID,
+           "spikes of a trial must be grouped by non-decreasing neuron index in [0, n_neurons)");
+    cfirst[r] = (int)chunks.size();
+    for (long long c = s0; c < s1; c += SV_SPIKE_CHUNK) {
+      SpikeChunk ch;
+      ch.trial = r;
+      ch.start = c;
+      ch.count = (int)std::min<long long>(SV_SPIKE_CHUNK, s1 - c);
+      chunks.push_back(ch);
+    }
+  }
+  seg[(size_t)v.R * v.N] = S;
+  cfirst[v.R] = (int)chunks.size();
+  v.nchunks = (int)chunks.size();
+
+  double* st; int* sn; long long* so; long long* sg; double* sc; SpikeChunk* dc; int* cf;
+  DALLOC(e, st, S); DALLOC(e, sn, S); DALLOC(e, so, v.R + 1); DALLOC(e, sg, seg.size());
+  DALLOC(e, sc, v.N); DALLOC(e, dc, chunks.size()); DALLOC(e, cf, v.R + 1);
+  if (S) {
+    HIPCHK(e, hipMemcpy(st, times, sizeof(double) * S, hipMemcpyDeviceToDevice));
+    HIPCHK(e, hipMemcpy(sn, neuron, sizeof(int32_t) * S, hipMemcpyDeviceToDevice));
+  }
+  std::vector<long long> off64(off, off + v.R + 1);
+  HIPCHK(e, hipMemcpy(so, off64.data(), sizeof(long long) * (v.R + 1), hipMemcpyHostToDevice));
+  HIPCHK(e, hipMemcpy(sg, seg.data(), sizeof(long long) * seg.size(), hipMemcpyHostToDevice));
+  HIPCHK(e, hipMemcpy(sc, cnt.data(), sizeof(double) * v.N, hipMemcpyHostToDevice));
+  if (!chunks.empty())
+    HIPCHK(e, hipMemcpy(dc, chunks.data(), sizeof(SpikeChunk) * chunks.size(), hipMemcpyHostToDevice));
+  HIPCHK(e, hipMemcpy(cf, cfirst.data(), sizeof(int) * (v.R + 1), hipMemcpyHostToDevice));
+  v.spk_t = st; v.spk_n = sn; v.spk_off = so; v.seg_off = sg; v.spk_cnt = sc; v.chunks = dc; v.chunk_first = cf;
+  DALLOC(e, v.P0, (size_t)v.nchunks * v.sumM); DALLOC(e, v.P1, (size_t)v.nchunks * v.sumM);
+  DALLOC(e, v.Tpart, (size_t)v.nchunks * v.K * 2);
+  DALLOC(e, v.muspk, (size_t)v.K * S); DALLOC(e, v.varspk, (size_t)v.K * S);
+  HIPCHK(e, hipMemset(v.P1, 0, sizeof(double) * std::max<size_t>(1, (size_t)v.nchunks * v.sumM)));
+  HIPCHK(e, hipMemset(v.Tpart, 0, sizeof(double) * std::max<size_t>(1, (size_t)v.nchunks * v.K * 2)));
+  e->have_spikes = true;
+  e->have_stats = false;
+  return SVGPFA_OK;
+}
+
+int svgpfa_build_kernels(svgpfa_engine* e, const double* const* Z, const double* const* theta) {
+  if (!e || !Z || !theta) return SVGPFA_ERR_INVALID;
+  EngineView& v = e->v;
+  for (int k = 0; k < v.K; ++k) {
+    if (!Z[k] || !theta[k]) FAIL(e, SVGPFA_ERR_INVALID, "NULL Z / theta pointer");
+    const LatentMeta& m = e->meta[k];
+    HIPCHK(e, hipMemcpyAsync(v.Zs + m.offM, Z[k], sizeof(double) * v.R * m.M, hipMemcpyDeviceToDevice, e->stream));
+    HIPCHK(e, hipMemcpyAsync(v.theta + 2 * k, theta[k], sizeof(double) * m.nth, hipMemcpyDeviceToDevice, e->stream));
+  }
+  hipLaunchKernelGGL(k_build, dim3(v.R * v.K), dim3(64), lds_build(e->Mmax), e->stream, v);
+  HIPCHK(e, hipGetLastError());
+  e->have_kernels = true;
+  e->have_stats = false;
+  return SVGPFA_OK;
+}
+
+int64_t svgpfa_shared_len(const svgpfa_engine* e) {
+  if (!e) return 0;
+  return 3 + (int64_t)e->v.N * e->v.K + e->v.N + e->v.nth_total;
+}
+
+static int fill_ptrs(svgpfa_engine* e, PtrTable& pt, const double* const* mean, const double* const* cholvec,
+                     double* const* g_mean, double* const* g_cholvec, double* const* g_Z, unsigned mask) {
+  if (!mean || !cholvec) FAIL(e, SVGPFA_ERR_INVALID, "NULL mean / cholvec table");
+  if ((mask & 1u) && (!g_mean || !g_cholvec)) FAIL(e, SVGPFA_ERR_INVALID, "variational gradients requested but output tables are NULL");
+  if ((mask & 8u) && !g_Z) FAIL(e, SVGPFA_ERR_INVALID, "inducing-point gradients requested but output table is NULL");
+  memset(&pt, 0, sizeof pt);
+  for (int k = 0; k < e->v.K; ++k) {
+    if (!mean[k] || !cholvec[k]) FAIL(e, SVGPFA_ERR_INVALID, "NULL mean / cholvec pointer");
+    pt.p[k].mean = mean[k];
+    pt.p[k].cholvec = cholvec[k];
+    if (mask & 1u) {
+      if (!g_mean[k] || !g_cholvec[k]) FAIL(e, SVGPFA_ERR_INVALID, "NULL variational gradient pointer");
+      pt.p[k].g_mean = g_mean[k];
+      pt.p[k].g_cholvec = g_cholvec[k];
+    }
+    if (mask & 8u) {
+      if (!g_Z[k]) FAIL(e, SVGPFA_ERR_INVALID, "NULL inducing-point gradient pointer");
+      pt.p[k].g_Z = g_Z[k];
+    }
+  }
+  return SVGPFA_OK;
+}
+
+static int launch_quad_ell(svgpfa_engine* e, const double* C, const double* d, int want_cd, int want_lat) {
+  EngineView& v = e->v;
+  size_t lq = lds_qell(e);
+  dim3 g(v.R * v.nqt), b(256);
+  switch (e->KT) {
+#define CASE_KT(X) case X: hipLaunchKernelGGL(k_quad_ell<X>, g, b, lq, e->stream, v, C, d, want_cd, want_lat); break;
+    CASE_KT(4) CASE_KT(8) CASE_KT(12) CASE_KT(16) CASE_KT(20) CASE_KT(24) CASE_KT(28) CASE_KT(32)
+#undef CASE_KT
+  }
+  HIPCHK(e, hipGetLastError());
+  return SVGPFA_OK;
+}
+
+static int check_ready(svgpfa_engine* e) {
+  if (!e->have_quad) FAIL(e, SVGPFA_ERR_STATE, "svgpfa_set_quad has not been called");
+  if (!e->have_spikes) FAIL(e, SVGPFA_ERR_STATE, "svgpfa_set_spikes has not been called");
+  if (!e->have_kernels) FAIL(e, SVGPFA_ERR_STATE, "svgpfa_build_kernels has not been called (or its Cholesky failed)");
+  return SVGPFA_OK;
+}
+
+int svgpfa_elbo(svgpfa_engine* e, const double* const* mean, const double* const* cholvec, const double* C,
+                const double* d, unsigned mask, double* shared, double* const* g_mean,
+                double* const* g_cholvec, double* const* g_Z) {
+  if (!e || !C || !d || !shared) return SVGPFA_ERR_INVALID;
+  int rc;
+  if ((rc = check_ready(e))) return rc;
+  EngineView& v = e->v;
+  PtrTable pt;
+  if ((rc = fill_ptrs(e, pt, mean, cholvec, g_mean, g_cholvec, g_Z, mask))) return rc;
+  const int RK = v.R * v.K;
+  const bool want_lat = (mask & (1u | 4u | 8u)) != 0;
+  const bool full = (mask & (2u | 4u | 8u)) != 0;
+
+  hipLaunchKernelGGL(k_prep_entry, dim3(RK), dim3(64), lds_prep(e->Mmax), e->stream, v, pt);
+  hipLaunchKernelGGL(k_times_fwd, dim3(RK), dim3(256), lds_times(e->Mmax), e->stream, v, v.tq,
+                     (const long long*)nullptr, v.Q, v.muq, v.varq, (long long)v.K, 1LL, 1);
+  if ((rc = launch_quad_ell(e, C, d, (mask & 2u) ? 1 : 0, want_lat ? 1 : 0))) return rc;
+  if (want_lat) {
+    if (mask & (4u | 8u))
+      hipLaunchKernelGGL(k_quad_bwd<true>, dim3(RK), dim3(256), lds_qbwd(e->Mmax), e->stream, v);
+    else
+      hipLaunchKernelGGL(k_quad_bwd<false>, dim3(RK), dim3(256), lds_qbwd(e->Mmax), e->stream, v);
+  }
+  if (v.nchunks > 0) {
+    if (e->timing) HIPCHK(e, hipEventRecord(e->ev0, e->stream));
+    if (full)
+      hipLaunchKernelGGL(k_spike<true>, dim3(v.nchunks * v.K), dim3(64), 0, e->stream, v, C);
+    else
+      hipLaunchKernelGGL(k_spike<false>, dim3(v.nchunks * v.K), dim3(64), 0, e->stream, v, C);
+    if (e->timing) {
+      HIPCHK(e, hipEventRecord(e->ev1, e->stream));
+      e->ev_valid = true;
+    }
+    if (mask & 2u) {
+      long long tot = (long long)v.R * v.N * v.K;
+      hipLaunchKernelGGL(k_spike_gc, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, e->stream, v);
+    }
+  }
+  hipLaunchKernelGGL(k_bwd_entry, dim3(RK), dim3(64), lds_bwd(e->Mmax), e->stream, v, pt, mask);
+  int nout = v.N * v.K + v.N + v.nth_total;
+  hipLaunchKernelGGL(k_finalize, dim3((nout + 255) / 256 + 1), dim3(256), 0, e->stream, v, d, mask, shared);
+  HIPCHK(e, hipGetLastError());
+  return SVGPFA_OK;
+}
+
+int svgpfa_latent_stats(svgpfa_engine* e, const double* const* mean, const double* const* cholvec,
+                        double* mu_quad, double* var_quad, double* mu_spk, double* var_spk) {
+  if (!e) return SVGPFA_ERR_INVALID;
+  int rc;
+  if ((rc = check_ready(e))) return rc;
+  EngineView& v = e->v;
+  PtrTable pt;
+  if ((rc = fill_ptrs(e, pt, mean, cholvec, nullptr, nullptr, nullptr, 0))) return rc;
+  const int RK = v.R * v.K;
+  hipLaunchKernelGGL(k_prep_entry, dim3(RK), dim3(64), lds_prep(e->Mmax), e->stream, v, pt);
+  hipLaunchKernelGGL(k_times_fwd, dim3(RK), dim3(256), lds_times(e->Mmax), e->stream, v, v.tq,
+                     (const long long*)nullptr, v.Q, v.muq, v.varq, (long long)v.K, 1LL, 1);
+  hipLaunchKernelGGL(k_times_fwd, dim3(RK), dim3(256), lds_times(e->Mmax), e->stream, v, v.spk_t,
+                     v.spk_off, 0, v.muspk, v.varspk, 1LL, (long long)v.S, 1);
+  hipLaunchKernelGGL(k_mseg, dim3((v.N * v.K + 255) / 256), dim3(256), 0, e->stream, v);
+  size_t rqk = sizeof(double) * v.R * v.Q * v.K;
+  if (mu_quad) HIPCHK(e, hipMemcpyAsync(mu_quad, v.muq, rqk, hipMemcpyDeviceToDevice, e->stream));
+  if (var_quad) HIPCHK(e, hipMemcpyAsync(var_quad, v.varq, rqk, hipMemcpyDeviceToDevice, e->stream));
+  long long tot = (long long)v.S * v.K;
+  if (tot > 0) {
+    unsigned g = (unsigned)((tot + 255) / 256);
+    if (mu_spk) hipLaunchKernelGGL(k_transpose_ks, dim3(g), dim3(256), 0, e->stream, v.muspk, mu_spk, (long long)v.S, v.K);
+    if (var_spk) hipLaunchKernelGGL(k_transpose_ks, dim3(g), dim3(256), 0, e->stream, v.varspk, var_spk, (long long)v.S, v.K);
+  }
+  HIPCHK(e, hipGetLastError());
+  e->have_stats = true;
+  return SVGPFA_OK;
+}
+
+int svgpfa_ell_given_stats(svgpfa_engine* e, const double* C, const double* d, int want_grad, double* out) {
+  if (!e || !C || !d || !out) return SVGPFA_ERR_INVALID;
+  if (!e->have_stats) FAIL(e, SVGPFA_ERR_STATE, "svgpfa_latent_stats has not been called since the last data / kernel change");
+  EngineView& v = e->v;
+  int rc;
+  if ((rc = launch_quad_ell(e, C, d, want_grad ? 1 : 0, 0))) return rc;
+  int nout = v.N * v.K + v.N;
+  hipLaunchKernelGGL(k_finalize_stats, dim3((nout + 255) / 256 + 1), dim3(256), 0, e->stream, v, C, d, want_grad, out);
+  HIPCHK(e, hipGetLastError());
+  return SVGPFA_OK;
+}
+
+int svgpfa_predict(svgpfa_engine* e, const double* const* mean, const double* const* cholvec,
+                   const double* times, int32_t T, double* mu, double* var) {
+  if (!e || !times || !mu || T <= 0) return SVGPFA_ERR_INVALID;
+  if (!e->have_kernels) FAIL(e, SVGPFA_ERR_STATE, "svgpfa_build_kernels has not been called");
+  EngineView& v = e->v;
+  PtrTable pt;
+  int rc;
+  if ((rc = fill_ptrs(e, pt, mean, cholvec, nullptr, nullptr, nullptr, 0))) return rc;
+  const int RK = v.R * v.K;
+  hipLaunchKernelGGL(k_prep_entry, dim3(RK), dim3(64), lds_prep(e->Mmax), e->stream, v, pt);
+  hipLaunchKernelGGL(k_times_fwd, dim3(RK), dim3(256), lds_times(e->Mmax), e->stream, v, times,
+                     (const long long*)nullptr, (int)T, mu, var ? var : mu, (long long)v.K, 1LL, var ? 1 : 0);
+  HIPCHK(e, hipGetLastError());
+  e->have_stats = false;  // k_prep overwrote a / W with these parameters; stats must be recomputed
+  return SVGPFA_OK;
+}
+
+static int get_mm(svgpfa_engine* e, int k, const double* src, double* out) {
+  if (!e || !out || k < 0 || k >= e->v.K) return SVGPFA_ERR_INVALID;
+  if (!e->have_kernels) FAIL(e, SVGPFA_ERR_STATE, "svgpfa_build_kernels has not been called");
+  const LatentMeta& m = e->meta[k];
+  HIPCHK(e, hipMemcpyAsync(out, src + m.offMM, sizeof(double) * e->v.R * m.M * m.M, hipMemcpyDeviceToDevice, e->stream));
+  return SVGPFA_OK;
+}
+int svgpfa_get_kzz(svgpfa_engine* e, int32_t k, double* out) { return get_mm(e, k, e ? e->v.Kzz : nullptr, out); }
+int svgpfa_get_kzz_chol(svgpfa_engine* e, int32_t k, double* out) { return get_mm(e, k, e ? e->v.L : nullptr, out); }
+
+int svgpfa_get_ktz_quad(svgpfa_engine* e, int32_t k, double* out) {
+  if (!e || !out || k < 0 || k >= e->v.K) return SVGPFA_ERR_INVALID;
+  if (!e->have_kernels || !e->have_quad) FAIL(e, SVGPFA_ERR_STATE, "need set_quad and build_kernels first");
+  EngineView& v = e->v;
+  long long ntot = (long long)v.R * v.Q, tot = ntot * e->meta[k].M;
+  hipLaunchKernelGGL(k_ktz, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, e->stream, v, (int)k, v.tq,
+                     (const long long*)nullptr, v.Q, ntot, out);
+  HIPCHK(e, hipGetLastError());
+  return SVGPFA_OK;
+}
+
+int svgpfa_get_ktz_spikes(svgpfa_engine* e, int32_t k, double* out) {
+  if (!e || !out || k < 0 || k >= e->v.K) return SVGPFA_ERR_INVALID;
+  if (!e->have_kernels || !e->have_spikes) FAIL(e, SVGPFA_ERR_STATE, "need set_spikes and build_kernels first");
+  EngineView& v = e->v;
+  long long ntot = v.S, tot = ntot * e->meta[k].M;
+  if (tot == 0) return SVGPFA_OK;
+  hipLaunchKernelGGL(k_ktz, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, e->stream, v, (int)k, v.spk_t,
+                     v.spk_off, 0, ntot, out);
+  HIPCHK(e, hipGetLastError());
+  return SVGPFA_OK;
+}
+
+int svgpfa_enable_timing(svgpfa_engine* e, int on) {
+  if (!e) return SVGPFA_ERR_INVALID;
+  e->timing = on != 0;
+  e->ev_valid = false;
+  return SVGPFA_OK;
+}
+
+double svgpfa_last_spike_kernel_ms(svgpfa_engine* e) {
+  if (!e || !e->timing || !e->ev_valid) return -1.0;
+  if (hipEventSynchronize(e->ev1) != hipSuccess) return -1.0;
+  float ms = 0.f;
+  if (hipEventElapsedTime(&ms, e->ev0, e->ev1) != hipSuccess) return -1.0;
+  return (double)ms;
+}
+
+}  // extern "C"
