@@ -1,0 +1,202 @@
+#!/usr/bin/env python3
+"""bench.py -- ELBO+gradient evaluations per second of the HIP engine (BASELINE.json metric).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config cfg3] [--variant all|estep]
+
+One "step" = one complete evaluation of the sparse-variational lower bound and its gradients on
+the named synthetic workload (seeded), inputs already resident in HBM:
+  variant "all"   : rebuild kernels (Kzz, Cholesky) + ELBO + gradients of all four parameter
+                    groups -- the closure of the reference's svLBFGS.py:162-174 (headline)
+  variant "estep" : ELBO + gradients of the variational parameters, kernels not rebuilt --
+                    the closure of the reference's svEM.py:218-223
+With N > 1 (launched by torch.distributed.run, one rank per GPU) the 500 trials are sharded by
+spike count across ranks (total work fixed: "strong" scaling) and every step ends with ONE RCCL
+all-reduce of the shared vector [ELBO, ELL, KL, dC, dd, dtheta].
+
+Rank 0 prints one JSON line.  Extra objects:
+  roofline     : the dominant kernel (k_spike): algorithmic fp64 flop-equivalents per launch
+                 (SURVEY 8(d) convention: 24 per kernel evaluation, x3 for value+gradients) over
+                 its mean device time from hipEvents recorded inside the timed region.
+  cpu_baseline : the CPU oracle (oracle/svgpfa_oracle.py, PyTorch-CPU fp64, the reference's
+                 unfused algorithm) timed on this host on a bounded sample of the same workload.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+if REPO not in sys.path:
+    sys.path.insert(0, REPO)
+
+FP64_PEAK_TFLOPS = 78.6   # MI355X fp64 vector = fp64 matrix peak (AMD public figure)
+HBM_PEAK_GBS = 8000.0
+
+
+def algorithmic_work(prob, variant):
+    """flop-equivalents and bytes per evaluation, and the spike kernel's share."""
+    R, N, K, Q = prob["R"], prob["N"], prob["K"], prob["Q"]
+    S = int(prob["spike_offsets"][-1])
+    Sbar = S / max(R, 1)
+    Ms = prob["Ms"]
+    T_fwd = sum(R * M * (M + Q + Sbar) for M in Ms)
+    F_fwd = (sum(R * (3 * M**3 + Q * (2 * M**2 + 4 * M) + 2 * M * Sbar) for M in Ms)
+             + R * (4 * Q * K * N + 3 * Q * N) + 2 * S * K)
+    flops_eval = 3 * (F_fwd + 24 * T_fwd)
+    T_spk = sum(M * S for M in Ms)
+    F_spk = sum(2 * M * S for M in Ms) + 2 * S * K
+    flops_spike = 3 * (F_spk + 24 * T_spk)
+    ngrad = sum(R * (M + M * (M + 1) // 2) for M in Ms)
+    if variant == "all":
+        ngrad += sum(R * M for M in Ms) + N * K + N + sum(1 if t == "exponentialQuadratic" else 2
+                                                           for t in prob["kernel_types"])
+    bytes_eval = 8 * (S + 2 * R * Q + sum(R * (2 * M + M * (M + 1) // 2) for M in Ms) + N * K + N) \
+        + 4 * S + 8 * ngrad + 8
+    return dict(flops_eval=flops_eval, flops_spike=flops_spike, bytes_eval=bytes_eval, kernel_evals=T_fwd)
+
+
+def cpu_baseline(config, variant, sample_trials):
+    """Time the CPU oracle on the first `sample_trials` trials of the workload (same seed)."""
+    import torch
+    from oracle import svgpfa_oracle as orc
+    from svgpfa_amd.utils import synthetic
+    full = synthetic.make_config(config)
+    R = full["R"]
+    sample = synthetic.shard_trials(full, 0, 1)
+    ns = min(sample_trials, R)
+    sub = dict(sample)
+    off = sample["spike_offsets"]
+    sub["R"] = ns
+    sub["spike_offsets"] = off[:ns + 1].copy()
+    sub["spike_times"] = sample["spike_times"][:off[ns]]
+    sub["spike_neuron"] = sample["spike_neuron"][:off[ns]]
+    for key in ("quad_points", "quad_weights"):
+        sub[key] = sample[key][:ns]
+    for key in ("Z", "mean", "cholVecs"):
+        sub[key] = [a[:ns] for a in sample[key]]
+    mask = 15 if variant == "all" else 1
+    warm = dict(sub)   # tiny warm-up (2 trials) so that one-off torch initialisation is not timed
+    warm["R"] = 2
+    warm["spike_offsets"] = off[:3].copy()
+    warm["spike_times"], warm["spike_neuron"] = sample["spike_times"][:off[2]], sample["spike_neuron"][:off[2]]
+    for key in ("quad_points", "quad_weights"):
+        warm[key] = sample[key][:2]
+    for key in ("Z", "mean", "cholVecs"):
+        warm[key] = [a[:2] for a in sample[key]]
+    orc.elbo_and_grads(synthetic.to_oracle_problem(warm), mask)
+    p = synthetic.to_oracle_problem(sub)
+    t0 = time.perf_counter()
+    orc.elbo_and_grads(p, mask)
+    dt = time.perf_counter() - t0
+    frac = ns / R
+    return dict(value=frac / dt, unit="evals/s", cores=int(torch.get_num_threads()), kind="port",
+                sample=f"oracle ({'ALL' if mask == 15 else 'E-step'} closure) on the first {ns} of {R} trials of "
+                       f"{config} ({int(off[ns])} spikes), {dt:.2f} s; value = ({ns}/{R}) / time "
+                       f"(linear in trials; the reference itself is super-linear, SURVEY 3.4)")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--config", default="cfg3", choices=["cfg2", "cfg3", "cfg5"])
+    ap.add_argument("--variant", default="all", choices=["all", "estep"])
+    ap.add_argument("--cpu-sample-trials", type=int, default=50)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from svgpfa_amd.engine import engine_from_problem
+    from svgpfa_amd.utils import synthetic
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and rank == 0:
+        print(f"[bench] note: --gpus {args.gpus} but WORLD_SIZE={world}; using WORLD_SIZE", file=sys.stderr)
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    full = synthetic.make_config(args.config)
+    prob = synthetic.shard_trials(full, rank, world) if world > 1 else full
+    eng, P = engine_from_problem(prob, device=local_rank)
+    mask = 15 if args.variant == "all" else 1
+    shared = torch.empty(eng.shared_len, dtype=torch.float64, device=dev)
+    grads = eng.alloc_grads(mask)
+
+    def step():
+        if args.variant == "all":
+            eng.build_kernels(P["Z"], P["theta"])
+        eng.elbo(P["mean"], P["cholVecs"], P["C"], P["d"], mask, out=shared, grads=grads)
+        if world > 1:
+            dist.all_reduce(shared)   # RCCL sum of [ELBO, ELL, KL, dC, dd, dtheta]
+
+    for _ in range(args.warmup):
+        step()
+    eng.sync()
+    eng.enable_timing(True)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    spike_ms, launches = eng.spike_kernel_ms()
+    eng.enable_timing(False)
+    eng.sync()
+    elbo = float(shared[0])
+
+    if world > 1:
+        t = torch.tensor([elapsed, spike_ms / max(launches, 1)], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed, spike_avg_ms = float(t[0]), float(t[1])
+    else:
+        spike_avg_ms = spike_ms / max(launches, 1)
+
+    if rank == 0:
+        work = algorithmic_work(prob, args.variant)      # this rank's shard (what one launch processes)
+        work_full = algorithmic_work(full, args.variant)
+        ms_per_step = 1e3 * elapsed / args.steps
+        achieved = work["flops_spike"] / (spike_avg_ms * 1e-3) / 1e12 if spike_avg_ms > 0 else None
+        out = {
+            "metric": "ELBO+grad evals/sec at (trials,neurons,latents,ind)=(%d,%d,%d,%d)" % (
+                full["R"], full["N"], full["K"], full["Ms"][0]),
+            "value": args.steps / elapsed, "unit": "evals/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
+            "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": f"{args.config}: {full['R']} trials x {full['N']} neurons x {full['K']} latents x "
+                                   f"{full['Ms'][0]} inducing, {int(full['spike_offsets'][-1])} spikes, Q={full['Q']}",
+                       "variant": "ALL (rebuild kernels + ELBO + 4 gradient groups)" if args.variant == "all"
+                       else "E-step (ELBO + variational gradients)",
+                       "parallelism": f"trials sharded {world}-way by spike count, 1 RCCL all-reduce/step" if world > 1 else "single GPU"},
+            "elbo": elbo,
+            "roofline": {"bound": "mfma", "achieved": achieved, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
+                         "frac": (achieved / FP64_PEAK_TFLOPS) if achieved else None, "traffic": None,
+                         "kernel": "k_spike<%s>" % ("true" if mask & 14 else "false"),
+                         "kernel_avg_ms": spike_avg_ms, "kernel_launches": launches,
+                         "algorithmic_flops_per_launch": work["flops_spike"],
+                         "note": "fp64 compute-bound on the VALU (software exp/sincospi); fp64 vector and matrix "
+                                 "peaks are both 78.6 TFLOP/s on MI355X, so the MFMA-peak field is that figure",
+                         "eval_frac_fp64": work_full["flops_eval"] / world / (ms_per_step * 1e-3) / 1e12 / FP64_PEAK_TFLOPS,
+                         "eval_frac_hbm": work_full["bytes_eval"] / world / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args.config, args.variant, args.cpu_sample_trials)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -145,11 +145,12 @@ int svgpfa_get_kzz_chol(svgpfa_engine* e, int32_t k, double* out);
 int svgpfa_get_ktz_quad(svgpfa_engine* e, int32_t k, double* out);
 int svgpfa_get_ktz_spikes(svgpfa_engine* e, int32_t k, double* out);
 
-/* Timing hook for bench.py: device time (ms) of the most recent svgpfa_elbo call's dominant
- * kernel (the spike-time pass), measured with hipEvents on the engine's stream; negative if
- * event timing is disabled.  svgpfa_enable_timing(e, 1) turns it on. */
+/* Timing hook for bench.py.  While enabled, every svgpfa_elbo call brackets its dominant kernel
+ * (the spike-time pass) with a hipEvent pair on the engine's stream; nothing is waited for at
+ * record time.  svgpfa_spike_kernel_ms synchronises the stream, adds up the elapsed device time
+ * of all pairs recorded since the previous query and returns it with the launch count. */
 int svgpfa_enable_timing(svgpfa_engine* e, int on);
-double svgpfa_last_spike_kernel_ms(svgpfa_engine* e);
+int svgpfa_spike_kernel_ms(svgpfa_engine* e, double* total_ms, int32_t* launches);
 
 #ifdef __cplusplus
 }

@@ -32,8 +32,8 @@ struct svgpfa_engine {
   long long totM = 0, totMM = 0;  // R*sum M, R*sum M^2
   bool have_quad = false, have_spikes = false, have_kernels = false, have_stats = false;
   bool timing = false;
-  hipEvent_t ev0 = nullptr, ev1 = nullptr;
-  bool ev_valid = false;
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool;  // event pairs, reused
+  size_t ev_used = 0;
   std::string err;
   int* status_host = nullptr;  // pinned
 };
@@ -168,8 +168,6 @@ int svgpfa_create(const svgpfa_dims* d, int device, svgpfa_engine** out) {
   HIPCHK(e, hipMemset(v.gZq, 0, sizeof(double) * e->totM));
   HIPCHK(e, hipMemset(v.gthq, 0, sizeof(double) * v.R * v.K * 2));
   HIPCHK(e, hipHostMalloc((void**)&e->status_host, sizeof(int)));
-  HIPCHK(e, hipEventCreate(&e->ev0));
-  HIPCHK(e, hipEventCreate(&e->ev1));
 
   int rc;
   if ((rc = allow_lds(e, k_build, lds_build(e->Mmax)))) return rc;
@@ -195,8 +193,10 @@ void svgpfa_destroy(svgpfa_engine* e) {
   (void)hipDeviceSynchronize();
   for (void* p : e->allocs) (void)hipFree(p);
   if (e->status_host) (void)hipHostFree(e->status_host);
-  if (e->ev0) (void)hipEventDestroy(e->ev0);
-  if (e->ev1) (void)hipEventDestroy(e->ev1);
+  for (auto& pr : e->ev_pool) {
+    (void)hipEventDestroy(pr.first);
+    (void)hipEventDestroy(pr.second);
+  }
   delete e;
 }
 
@@ -395,15 +395,22 @@ int svgpfa_elbo(svgpfa_engine* e, const double* const* mean, const double* const
       hipLaunchKernelGGL(k_quad_bwd<false>, dim3(RK), dim3(256), lds_qbwd(e->Mmax), e->stream, v);
   }
   if (v.nchunks > 0) {
-    if (e->timing) HIPCHK(e, hipEventRecord(e->ev0, e->stream));
+    std::pair<hipEvent_t, hipEvent_t>* evp = nullptr;
+    if (e->timing) {
+      if (e->ev_used == e->ev_pool.size()) {
+        std::pair<hipEvent_t, hipEvent_t> pr;
+        HIPCHK(e, hipEventCreate(&pr.first));
+        HIPCHK(e, hipEventCreate(&pr.second));
+        e->ev_pool.push_back(pr);
+      }
+      evp = &e->ev_pool[e->ev_used++];
+      HIPCHK(e, hipEventRecord(evp->first, e->stream));
+    }
     if (full)
       hipLaunchKernelGGL(k_spike<true>, dim3(v.nchunks * v.K), dim3(64), 0, e->stream, v, C);
     else
       hipLaunchKernelGGL(k_spike<false>, dim3(v.nchunks * v.K), dim3(64), 0, e->stream, v, C);
-    if (e->timing) {
-      HIPCHK(e, hipEventRecord(e->ev1, e->stream));
-      e->ev_valid = true;
-    }
+    if (evp) HIPCHK(e, hipEventRecord(evp->second, e->stream));
     if (mask & 2u) {
       long long tot = (long long)v.R * v.N * v.K;
       hipLaunchKernelGGL(k_spike_gc, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, e->stream, v);
@@ -510,16 +517,23 @@ int svgpfa_get_ktz_spikes(svgpfa_engine* e, int32_t k, double* out) {
 int svgpfa_enable_timing(svgpfa_engine* e, int on) {
   if (!e) return SVGPFA_ERR_INVALID;
   e->timing = on != 0;
-  e->ev_valid = false;
+  e->ev_used = 0;
   return SVGPFA_OK;
 }
 
-double svgpfa_last_spike_kernel_ms(svgpfa_engine* e) {
-  if (!e || !e->timing || !e->ev_valid) return -1.0;
-  if (hipEventSynchronize(e->ev1) != hipSuccess) return -1.0;
-  float ms = 0.f;
-  if (hipEventElapsedTime(&ms, e->ev0, e->ev1) != hipSuccess) return -1.0;
-  return (double)ms;
+int svgpfa_spike_kernel_ms(svgpfa_engine* e, double* total_ms, int32_t* launches) {
+  if (!e || !total_ms || !launches) return SVGPFA_ERR_INVALID;
+  HIPCHK(e, hipStreamSynchronize(e->stream));
+  double tot = 0.0;
+  for (size_t i = 0; i < e->ev_used; ++i) {
+    float ms = 0.f;
+    HIPCHK(e, hipEventElapsedTime(&ms, e->ev_pool[i].first, e->ev_pool[i].second));
+    tot += ms;
+  }
+  *total_ms = tot;
+  *launches = (int32_t)e->ev_used;
+  e->ev_used = 0;
+  return SVGPFA_OK;
 }
 
 }  // extern "C"

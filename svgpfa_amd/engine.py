@@ -126,7 +126,18 @@ class Engine:
         tt = self._table(theta, self.nth)
         self._check(self.lib.svgpfa_build_kernels(self._h, zt, tt))
 
-    def elbo(self, mean, cholvec, C, d, grad_mask=0, out=None):
+    def alloc_grads(self, grad_mask):
+        """Per-trial gradient buffers (g_mean, g_cholvec, g_Z) for `grad_mask` (None where not requested)."""
+        mk = lambda r, c: torch.empty(r, c, dtype=torch.float64, device=self.device)
+        g_mean = g_chol = g_Z = None
+        if grad_mask & _lib.GRAD_VARIATIONAL:
+            g_mean = [mk(self.R, m) for m in self.Ms]
+            g_chol = [mk(self.R, p) for p in self.Ps]
+        if grad_mask & _lib.GRAD_INDPOINTS:
+            g_Z = [mk(self.R, m) for m in self.Ms]
+        return g_mean, g_chol, g_Z
+
+    def elbo(self, mean, cholvec, C, d, grad_mask=0, out=None, grads=None):
         """Enqueue one ELBO(+grad) evaluation.  Returns (shared, g_mean, g_cholvec, g_Z); the
         lists are None for groups not in grad_mask.  Call sync() before trusting the numbers."""
         self._use_current_stream()
@@ -136,14 +147,11 @@ class Engine:
         if C.numel() != self.N * self.K or d.numel() != self.N:
             raise ValueError("C must be N x K and d must have N entries")
         shared = out if out is not None else torch.empty(self.shared_len, dtype=torch.float64, device=self.device)
-        g_mean = g_chol = g_Z = None
-        if grad_mask & _lib.GRAD_VARIATIONAL:
-            g_mean = [torch.empty(self.R, m, dtype=torch.float64, device=self.device) for m in self.Ms]
-            g_chol = [torch.empty(self.R, p, dtype=torch.float64, device=self.device) for p in self.Ps]
-        if grad_mask & _lib.GRAD_INDPOINTS:
-            g_Z = [torch.empty(self.R, m, dtype=torch.float64, device=self.device) for m in self.Ms]
+        g_mean, g_chol, g_Z = grads if grads is not None else self.alloc_grads(grad_mask)
         self._check(self.lib.svgpfa_elbo(self._h, mt, ct, _ptr(C), _ptr(d), int(grad_mask), _ptr(shared),
-                                         self._table(g_mean), self._table(g_chol), self._table(g_Z)))
+                                         self._table(g_mean, [self.R * m for m in self.Ms]),
+                                         self._table(g_chol, [self.R * p for p in self.Ps]),
+                                         self._table(g_Z, [self.R * m for m in self.Ms])))
         return shared, g_mean, g_chol, g_Z
 
     def split_shared(self, shared):
@@ -219,8 +227,11 @@ class Engine:
     def enable_timing(self, on=True):
         self._check(self.lib.svgpfa_enable_timing(self._h, int(on)))
 
-    def last_spike_kernel_ms(self):
-        return float(self.lib.svgpfa_last_spike_kernel_ms(self._h))
+    def spike_kernel_ms(self):
+        """(total device ms, launches) of the spike-pass kernel since the last query (syncs the stream)."""
+        tot, n = ctypes.c_double(0.0), ctypes.c_int32(0)
+        self._check(self.lib.svgpfa_spike_kernel_ms(self._h, ctypes.byref(tot), ctypes.byref(n)))
+        return tot.value, n.value
 
 
 def engine_from_problem(prob, device=None):
