@@ -41,10 +41,16 @@ struct LatentPtrs {
   double* g_Z;
 };
 
+// A chunk holds <= SV_SPIKE_CHUNK consecutive spikes of one trial.  Normal chunks contain WHOLE
+// (trial, neuron) segments, so the wavefront that owns the chunk is the only writer of those
+// neurons' spike sums.  A neuron with more than SV_SPIKE_CHUNK spikes in a trial gets dedicated
+// chunks (split = 1, all spikes of that one neuron); their sums are added in chunk order later.
 struct SpikeChunk {
   int trial;
   int count;
   long long start;  // global spike index of the first spike of the chunk
+  int split;        // 1: piece of an oversize (trial, neuron) segment
+  int neuron;       // that neuron (split chunks only)
 };
 
 // Everything a kernel needs, passed by value (fits well inside the kernarg segment).
@@ -62,6 +68,8 @@ struct EngineView {
   const double* spk_cnt;      // N     : spikes per neuron over all local trials
   const SpikeChunk* chunks;
   const int* chunk_first;     // R+1   : first chunk of each trial
+  const int* split_chunks;    // indices of the split chunks (usually none)
+  int nsplit;
   double* Zs;
   double* theta;              // K x 2 snapshot
   double* Kzz; double* L; double* Linv;
@@ -69,7 +77,9 @@ struct EngineView {
   double* muq; double* varq; double* gmuq; double* gvarq;
   double* gaq; double* GW; double* gZq; double* gthq;   // quad-side adjoints of ut, Vt Vt^T, direct Z / theta; gthq [R*K*2]
   double* P0; double* P1; double* Tpart;           // spike partials
-  double* muspk;                                   // [K][S]
+  double* gCspk;                                   // [R][N][K] spike part of dC per trial (whole segments)
+  double* splitPart;                               // [nchunks][K] spike part of dC of split chunks
+  double* muspk;                                   // [K][S] (stats API only)
   double* varspk;                                  // [K][S] (stats API only)
   double* gCpart; double* gdpart; double* ellq;    // [R*nqt][N][K], [R*nqt][N], [R*nqt]
   double* ells; double* gthitem;                   // [R*K], [R*K*2]

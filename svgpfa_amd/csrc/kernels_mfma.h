@@ -1,0 +1,562 @@
+// f64 MFMA (v_mfma_f64_16x16x4_f64) versions of the time-point kernels.
+//
+// Everything is kept TRANSPOSED: a tile holds 16 time points on the lane index (col = lane & 15)
+// and 16 inducing-point rows in the 4 accumulator registers (row = (lane >> 4) + 4 r).  In that
+// layout an accumulator tile is exactly the B operand of the next MFMA that contracts over its
+// row index (probe: tests/tools/mfma_f64_probe.hip), so the whole whitening chain
+//     Kt^T -> Kw^T = Linv Kt^T -> T^T = Vt^T Kw^T -> Y^T = Vt T^T -> adj -> gk^T = Linv^T adj
+// runs register-to-register; only the A operands (fragments of the M x M factors) come from LDS.
+// kappa(t, z) itself is evaluated straight into B-operand layout (lane = time point, registers =
+// inducing points), so Ktz never touches LDS or HBM.
+//
+// MP = 16 NT >= max_k M_k; matrices are zero padded to MP, LDS rows padded to LD = MP + 2 doubles
+// (A-fragment reads are then bank-conflict free: lane -> (l & 15) * LD + (l >> 4)).
+#pragma once
+#include "engine_common.h"
+
+typedef double d4 __attribute__((ext_vector_type(4)));
+
+// D[a] = sum_b sum_r mfma(Afrag(a, b, r), B[b][r]);  Mat is lower triangular (zero padded).
+// MODE 0: A = Mat   -> tiles b <= a, Afrag = Mat[16a + (l&15)][16b + 4r + (l>>4)]
+// MODE 1: A = Mat^T -> tiles b >= a, Afrag = Mat[16b + 4r + (l>>4)][16a + (l&15)]
+template <int NT, int MODE>
+__device__ __forceinline__ void tri_chain(d4 (&D)[NT], const double* Mat, int LD, const d4 (&B)[NT],
+                                          int li, int lg) {
+#pragma unroll
+  for (int a = 0; a < NT; ++a) {
+    d4 acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int b = 0; b < NT; ++b) {
+      if (MODE == 0 ? (b <= a) : (b >= a)) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          double av = (MODE == 0) ? Mat[(16 * a + li) * LD + 16 * b + 4 * r + lg]
+                                  : Mat[(16 * b + 4 * r + lg) * LD + 16 * a + li];
+          acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, B[b][r], acc, 0, 0, 0);
+        }
+      }
+    }
+    D[a] = acc;
+  }
+}
+
+__device__ __forceinline__ double row16_sum(double x) {   // sum over the 16 lanes sharing lane >> 4
+#pragma unroll
+  for (int o = 8; o > 0; o >>= 1) x += __shfl_xor(x, o, 64);
+  return x;
+}
+__device__ __forceinline__ double grp4_sum(double x) {    // sum over the 4 lanes sharing lane & 15
+  x += __shfl_xor(x, 16, 64);
+  x += __shfl_xor(x, 32, 64);
+  return x;
+}
+__device__ __forceinline__ void lds_wave_fence() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
+
+template <int NT>
+__device__ __forceinline__ void load_factors(const EngineView& ev, const LatentMeta& m, int r, double* Li,
+                                             double* Vl, double* ul, double* zl, bool want_v) {
+  constexpr int MP = 16 * NT, LD = MP + 2;
+  const int M = m.M, tid = threadIdx.x;
+  const long long base = m.offMM + (long long)r * M * M;
+  const long long vbase = m.offM + (long long)r * M;
+  for (int e = tid; e < MP * MP; e += 256) {
+    int i = e / MP, j = e % MP;
+    bool in = (i < M) && (j < M);
+    Li[i * LD + j] = in ? ev.Linv[base + i * M + j] : 0.0;
+    if (want_v) Vl[i * LD + j] = in ? ev.Vt[base + i * M + j] : 0.0;
+  }
+  if (tid < MP) {
+    ul[tid] = (tid < M) ? ev.ut[vbase + tid] : 0.0;
+    zl[tid] = (tid < M) ? ev.Zs[vbase + tid] : 0.0;
+  }
+}
+
+// ------------------------------------------------------------------------ k_times_fwd_mfma
+// Posterior mean / variance of latent k at a CSR list of times (reference
+// svPosteriorOnLatents.py:185-216, :265-300).  grid = R*K blocks of 256 threads; each wavefront
+// walks tiles of 16 time points.  Output element (time gi, latent k) at gi*os_t + k*os_k.
+template <int NT, int KT>
+__device__ void times_fwd_body(const EngineView& ev, const double* times, const long long* toff, int nper,
+                               double* mu_out, double* var_out, long long os_t, long long os_k,
+                               int want_var, double* sm) {
+  constexpr int MP = 16 * NT, LD = MP + 2;
+  const int item = blockIdx.x, tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6, li = lane & 15, lg = lane >> 4;
+  const int r = item / ev.K, k = item % ev.K;
+  const LatentMeta m = ev.meta[k];
+  double* Li = sm;
+  double* Vl = Li + MP * LD;
+  double* ul = Vl + MP * LD;
+  double* zl = ul + MP;
+  const KPar p = make_kpar(m, ev.theta + 2 * k);
+  const long long t0 = toff ? toff[r] : (long long)r * nper;
+  const int nt = toff ? (int)(toff[r + 1] - toff[r]) : nper;
+  load_factors<NT>(ev, m, r, Li, Vl, ul, zl, want_var != 0);
+  __syncthreads();
+
+  double uj[NT][4], zj[NT][4];
+#pragma unroll
+  for (int a = 0; a < NT; ++a)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      uj[a][q] = ul[16 * a + 4 * q + lg];
+      zj[a][q] = zl[16 * a + 4 * q + lg];
+    }
+
+  const int ntiles = (nt + 15) >> 4;
+  for (int tile = wave; tile < ntiles; tile += 4) {
+    const int node = 16 * tile + li;
+    const bool ok = node < nt;
+    const double tq = times[t0 + (ok ? node : 0)];
+    d4 X0[NT];
+#pragma unroll
+    for (int a = 0; a < NT; ++a)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) X0[a][q] = p.s2 * kern_val<KT>(tq - zj[a][q], p);
+    d4 Kw[NT];
+    tri_chain<NT, 0>(Kw, Li, LD, X0, li, lg);
+    double pm = 0.0, n2 = 0.0, tt = 0.0;
+#pragma unroll
+    for (int a = 0; a < NT; ++a)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        pm = fma(uj[a][q], Kw[a][q], pm);
+        n2 = fma(Kw[a][q], Kw[a][q], n2);
+      }
+    if (want_var) {
+      d4 T[NT];
+      tri_chain<NT, 1>(T, Vl, LD, Kw, li, lg);
+#pragma unroll
+      for (int a = 0; a < NT; ++a)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) tt = fma(T[a][q], T[a][q], tt);
+    }
+    pm = grp4_sum(pm);
+    n2 = grp4_sum(n2);
+    tt = grp4_sum(tt);
+    if (lg == 0 && ok) {
+      long long gi = t0 + node;
+      mu_out[gi * os_t + k * os_k] = pm;
+      if (want_var) var_out[gi * os_t + k * os_k] = (p.s2 - n2) + tt;
+    }
+  }
+}
+
+template <int NT>
+__global__ __launch_bounds__(256) void k_times_fwd_mfma(EngineView ev, const double* times,
+                                                        const long long* toff, int nper, double* mu_out,
+                                                        double* var_out, long long os_t, long long os_k,
+                                                        int want_var) {
+  extern __shared__ double sm[];
+  if (ev.meta[blockIdx.x % ev.K].ktype == SV_RBF)
+    times_fwd_body<NT, SV_RBF>(ev, times, toff, nper, mu_out, var_out, os_t, os_k, want_var, sm);
+  else
+    times_fwd_body<NT, SV_PERIODIC>(ev, times, toff, nper, mu_out, var_out, os_t, os_k, want_var, sm);
+}
+
+// ------------------------------------------------------------------------- k_quad_bwd_mfma
+// Adjoints of the quadrature term wrt ut (gt), Vt Vt^T (Gt) and -- FULL -- the direct dependence
+// on Z / theta through kappa(t_q, Z).  grid = R*K blocks of 256 threads.
+template <int NT, int KT, bool FULL>
+__device__ void quad_bwd_mfma_body(const EngineView& ev, double* sm) {
+  constexpr int MP = 16 * NT, LD = MP + 2, NTRI = NT * (NT + 1) / 2;
+  const int item = blockIdx.x, tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6, li = lane & 15, lg = lane >> 4;
+  const int r = item / ev.K, k = item % ev.K;
+  const LatentMeta m = ev.meta[k];
+  const int M = m.M, Q = ev.Q, K = ev.K;
+  double* Li = sm;                    // MP*LD
+  double* Vl = Li + MP * LD;          // MP*LD
+  double* ul = Vl + MP * LD;          // MP
+  double* zl = ul + MP;               // MP
+  double* S = zl + MP;                // 4 * 16*LD  (per-wave transpose scratch; later the Gt sum buffer)
+  double* gvs = S + 4 * 16 * LD;      // 4 * 16
+  double* vred = gvs + 64;            // 4 * 2 * MP  (gu / dz partials per wave)
+  double* tred = vred + 8 * MP;       // 8
+  const KPar p = make_kpar(m, ev.theta + 2 * k);
+  const long long base = m.offMM + (long long)r * M * M;
+  const long long vbase = m.offM + (long long)r * M;
+  load_factors<NT>(ev, m, r, Li, Vl, ul, zl, FULL);
+  __syncthreads();
+
+  double uj[NT][4], zj[NT][4];
+#pragma unroll
+  for (int a = 0; a < NT; ++a)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      uj[a][q] = ul[16 * a + 4 * q + lg];
+      zj[a][q] = zl[16 * a + 4 * q + lg];
+    }
+  d4 gu[NT], dz[NT], GW[NTRI];
+#pragma unroll
+  for (int a = 0; a < NT; ++a) {
+    gu[a] = (d4){0.0, 0.0, 0.0, 0.0};
+    dz[a] = (d4){0.0, 0.0, 0.0, 0.0};
+  }
+#pragma unroll
+  for (int t = 0; t < NTRI; ++t) GW[t] = (d4){0.0, 0.0, 0.0, 0.0};
+  double th0 = 0.0, th1 = 0.0;
+  double* Sw = S + wave * 16 * LD;
+  double* gvw = gvs + wave * 16;
+
+  const int ntiles = (Q + 15) >> 4;
+  for (int tile = wave; tile < ntiles; tile += 4) {
+    const int node = 16 * tile + li;
+    const bool ok = node < Q;
+    const long long gi = (long long)r * Q + (ok ? node : 0);
+    const double tq = ev.tq[gi];
+    const double gm = ok ? ev.gmuq[gi * K + k] : 0.0;
+    const double gvv = ok ? ev.gvarq[gi * K + k] : 0.0;
+    d4 X0[NT], kbz[NT], kb0[NT], kb1[NT];
+#pragma unroll
+    for (int a = 0; a < NT; ++a)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        if (FULL) {
+          double kt, bz, b0v, b1v;
+          kern_eval<KT>(tq - zj[a][q], p, kt, bz, b0v, b1v);
+          X0[a][q] = p.s2 * kt;
+          kbz[a][q] = kt * bz;
+          kb0[a][q] = kt * b0v;
+          kb1[a][q] = kt * b1v;
+        } else {
+          X0[a][q] = p.s2 * kern_val<KT>(tq - zj[a][q], p);
+        }
+      }
+    d4 Kw[NT];
+    tri_chain<NT, 0>(Kw, Li, LD, X0, li, lg);
+#pragma unroll
+    for (int a = 0; a < NT; ++a)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) gu[a][q] = fma(gm, Kw[a][q], gu[a][q]);
+    if (FULL) {
+      d4 T[NT], Y[NT], Gk[NT];
+      tri_chain<NT, 1>(T, Vl, LD, Kw, li, lg);
+      tri_chain<NT, 0>(Y, Vl, LD, T, li, lg);
+#pragma unroll
+      for (int a = 0; a < NT; ++a)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) Y[a][q] = gm * uj[a][q] + 2.0 * gvv * (Y[a][q] - Kw[a][q]);
+      tri_chain<NT, 1>(Gk, Li, LD, Y, li, lg);
+#pragma unroll
+      for (int a = 0; a < NT; ++a)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          th0 = fma(Gk[a][q], kb0[a][q], th0);
+          if (KT == SV_PERIODIC) th1 = fma(Gk[a][q], kb1[a][q], th1);
+          dz[a][q] = fma(Gk[a][q], kbz[a][q], dz[a][q]);
+        }
+    }
+    // Gt += Kw^T diag(gvar) Kw : contraction over the time index -> transpose through LDS
+#pragma unroll
+    for (int a = 0; a < NT; ++a)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) Sw[li * LD + 16 * a + 4 * q + lg] = Kw[a][q];
+    if (lg == 0) gvw[li] = gvv;
+    lds_wave_fence();
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const int nc = 4 * c + lg;
+      const double g = gvw[nc];
+      double aop[NT];
+#pragma unroll
+      for (int a = 0; a < NT; ++a) aop[a] = Sw[nc * LD + 16 * a + li];
+      int t = 0;
+#pragma unroll
+      for (int a = 0; a < NT; ++a)
+#pragma unroll
+        for (int b = 0; b <= a; ++b) {
+          GW[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(aop[a], g * aop[b], GW[t], 0, 0, 0);
+          ++t;
+        }
+    }
+    lds_wave_fence();
+  }
+
+  // ---- reductions: over the 16 time lanes, then over the 4 wavefronts (fixed order)
+#pragma unroll
+  for (int a = 0; a < NT; ++a)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      double g = row16_sum(gu[a][q]);
+      double z = FULL ? row16_sum(dz[a][q]) : 0.0;
+      if (li == 0) {
+        vred[(wave * 2 + 0) * MP + 16 * a + 4 * q + lg] = g;
+        vred[(wave * 2 + 1) * MP + 16 * a + 4 * q + lg] = z;
+      }
+    }
+  th0 = wave_sum(th0);
+  th1 = wave_sum(th1);
+  if (lane == 0) {
+    tred[wave * 2 + 0] = th0;
+    tred[wave * 2 + 1] = th1;
+  }
+  __syncthreads();   // all waves done with their scratch: S becomes the MP x MP sum buffer
+  for (int w = 0; w < 4; ++w) {
+    if (wave == w) {
+      int t = 0;
+#pragma unroll
+      for (int a = 0; a < NT; ++a)
+#pragma unroll
+        for (int b = 0; b <= a; ++b) {
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            int row = 16 * a + lg + 4 * q, col = 16 * b + li;
+            if (w == 0)
+              S[row * MP + col] = GW[t][q];
+            else
+              S[row * MP + col] += GW[t][q];
+          }
+          ++t;
+        }
+    }
+    __syncthreads();
+  }
+  if (tid < M) {
+    double g = ((vred[0 * MP + tid] + vred[2 * MP + tid]) + vred[4 * MP + tid]) + vred[6 * MP + tid];
+    ev.gaq[vbase + tid] = g;
+    if (FULL) {
+      double z = ((vred[1 * MP + tid] + vred[3 * MP + tid]) + vred[5 * MP + tid]) + vred[7 * MP + tid];
+      ev.gZq[vbase + tid] = p.cz * z;
+    }
+  }
+  for (int e = tid; e < M * M; e += 256) {
+    int i = e / M, j = e % M;
+    ev.GW[base + e] = ((i >> 4) >= (j >> 4)) ? S[i * MP + j] : S[j * MP + i];
+  }
+  if (FULL && tid == 0) {
+    ev.gthq[item * 2 + 0] = p.c0 * (((tred[0] + tred[2]) + tred[4]) + tred[6]);
+    ev.gthq[item * 2 + 1] = p.c1 * (((tred[1] + tred[3]) + tred[5]) + tred[7]);
+  }
+}
+
+template <int NT, bool FULL>
+__global__ __launch_bounds__(256) void k_quad_bwd_mfma(EngineView ev) {
+  extern __shared__ double sm[];
+  if (ev.meta[blockIdx.x % ev.K].ktype == SV_RBF)
+    quad_bwd_mfma_body<NT, SV_RBF, FULL>(ev, sm);
+  else
+    quad_bwd_mfma_body<NT, SV_PERIODIC, FULL>(ev, sm);
+}
+
+// ------------------------------------------------------------------------------ k_bwd_mfma
+// Per-(trial, latent) backward through the whitened algebra (derivation: kernels_item.h header).
+// One wavefront per item; every M x M product runs on the f64 MFMA with the left operand read
+// from LDS as A fragments and the right operand held as register tiles, one 16-column panel at a time.
+template <int NT, int KT>
+__device__ void bwd_mfma_body(const EngineView& ev, const LatentPtrs pt, unsigned mask, double* sm) {
+  constexpr int MP = 16 * NT, LD = MP + 2;
+  const int item = blockIdx.x, lane = threadIdx.x, li = lane & 15, lg = lane >> 4;
+  const int r = item / ev.K, k = item % ev.K;
+  const LatentMeta m = ev.meta[k];
+  const int M = m.M;
+  double* Li = sm;               // MP*LD
+  double* Vl = Li + MP * LD;     // MP*LD
+  double* Gl = Vl + MP * LD;     // MP*LD  Gt, later At
+  double* Cs = Gl + MP * LD;     // MP*LD  C = Vt Vt^T Gt
+  double* gt = Cs + MP * LD;     // MP
+  double* ul = gt + MP;          // MP
+  double* gs = ul + MP;          // MP
+  double* zl = gs + MP;          // MP
+  const long long base = m.offMM + (long long)r * M * M;
+  const long long vbase = m.offM + (long long)r * M;
+  const KPar p = make_kpar(m, ev.theta + 2 * k);
+  const bool want_zt = (mask & (4u | 8u)) != 0;
+
+  // ---- gather the spike partial sums of this trial (fixed chunk order)
+  double p1sum = 0.0, espk = 0.0, a_l = 0.0;
+  for (int i = lane; i < MP; i += 64) {
+    gs[i] = 0.0; ul[i] = 0.0; zl[i] = 0.0; gt[i] = 0.0;
+  }
+  if (lane < M) {
+    double p0 = 0.0;
+    for (int c = ev.chunk_first[r]; c < ev.chunk_first[r + 1]; ++c) {
+      p0 += ev.P0[(long long)c * ev.sumM + m.colM + lane];
+      if (want_zt) p1sum += ev.P1[(long long)c * ev.sumM + m.colM + lane];
+    }
+    a_l = ev.a[vbase + lane];
+    double gsp = p.s2 * p0;
+    espk = a_l * gsp;
+    gs[lane] = gsp;
+    ul[lane] = ev.ut[vbase + lane];
+    zl[lane] = ev.Zs[vbase + lane];
+  }
+  espk = wave_sum(espk);
+  if (lane == 0) ev.ells[item] = espk;
+  if ((mask & (1u | 4u | 8u)) == 0) return;
+
+  for (int e = lane; e < MP * MP; e += 64) {
+    int i = e / MP, j = e % MP;
+    bool in = (i < M) && (j < M);
+    Li[i * LD + j] = in ? ev.Linv[base + i * M + j] : 0.0;
+    Vl[i * LD + j] = in ? ev.Vt[base + i * M + j] : 0.0;
+    Gl[i * LD + j] = in ? ev.GW[base + i * M + j] : 0.0;
+  }
+  __syncthreads();
+  if (lane < M) {
+    double s = ev.gaq[vbase + lane];
+    for (int q = 0; q <= lane; ++q) s += Li[lane * LD + q] * gs[q];
+    gt[lane] = s;
+  }
+  __syncthreads();
+
+  if (mask & 1u) {
+    if (lane < M) {
+      double s = 0.0;
+      for (int q = lane; q < M; ++q) s += Li[q * LD + lane] * (gt[q] - ul[q]);
+      pt.g_mean[(long long)r * M + lane] = s;
+    }
+    // dL_S = tril(Linv^T (2 Gt - I) Vt) + diag(1 / L_S,ii), one 16-column panel at a time
+    const double* cv = pt.cholvec + (long long)r * m.P;
+    double* gcv = pt.g_cholvec + (long long)r * m.P;
+#pragma unroll
+    for (int c = 0; c < NT; ++c) {
+      d4 P[NT], X[NT];
+#pragma unroll
+      for (int b = 0; b < NT; ++b)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) P[b][q] = Vl[(16 * b + 4 * q + lg) * LD + 16 * c + li];
+#pragma unroll
+      for (int a = 0; a < NT; ++a) {
+        d4 acc = {0.0, 0.0, 0.0, 0.0};
+        if (a >= c) {
+#pragma unroll
+          for (int b = 0; b < NT; ++b) {
+            if (b >= c) {   // Vt lower triangular: panel c has zero tiles above the diagonal
+#pragma unroll
+              for (int q = 0; q < 4; ++q) {
+                int row = 16 * a + li, col = 16 * b + 4 * q + lg;
+                double av = 2.0 * Gl[row * LD + col] - (row == col ? 1.0 : 0.0);
+                acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, P[b][q], acc, 0, 0, 0);
+              }
+            }
+          }
+        }
+        X[a] = acc;
+      }
+#pragma unroll
+      for (int a = 0; a < NT; ++a) {
+        if (a >= c) {
+          d4 acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+          for (int b = a; b < NT; ++b)
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+              acc = __builtin_amdgcn_mfma_f64_16x16x4f64(Li[(16 * b + 4 * q + lg) * LD + 16 * a + li], X[b][q], acc, 0, 0, 0);
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            int i = 16 * a + 4 * q + lg, j = 16 * c + li;
+            if (i < M && j <= i) {
+              double g = acc[q];
+              if (i == j) g += 1.0 / cv[i * (i + 1) / 2 + i];
+              gcv[i * (i + 1) / 2 + j] = g;
+            }
+          }
+        }
+      }
+    }
+  }
+  if (!want_zt) return;
+
+  // ---- C = Vt Vt^T Gt (-> LDS) and VV = Vt Vt^T (registers), panel by panel
+  d4 VV[NT][NT];
+#pragma unroll
+  for (int c = 0; c < NT; ++c) {
+    d4 P[NT], Bm[NT], Cm[NT];
+#pragma unroll
+    for (int b = 0; b < NT; ++b)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) P[b][q] = Gl[(16 * b + 4 * q + lg) * LD + 16 * c + li];
+    tri_chain<NT, 1>(Bm, Vl, LD, P, li, lg);
+    tri_chain<NT, 0>(Cm, Vl, LD, Bm, li, lg);
+#pragma unroll
+    for (int a = 0; a < NT; ++a)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) Cs[(16 * a + 4 * q + lg) * LD + 16 * c + li] = Cm[a][q];
+#pragma unroll
+    for (int b = 0; b < NT; ++b)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) P[b][q] = Vl[(16 * c + li) * LD + 16 * b + 4 * q + lg];   // Vt^T panel
+    tri_chain<NT, 0>(VV[c], Vl, LD, P, li, lg);
+  }
+  __syncthreads();
+  // ---- At (in place over Gt): each element is read and written by exactly one lane
+#pragma unroll
+  for (int c = 0; c < NT; ++c)
+#pragma unroll
+    for (int a = 0; a < NT; ++a)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        int i = 16 * a + 4 * q + lg, j = 16 * c + li;
+        double v = -0.5 * (gt[i] * ul[j] + ul[i] * gt[j]) + 0.5 * ul[i] * ul[j] + Gl[i * LD + j] +
+                   0.5 * (VV[c][a][q] - (i == j ? 1.0 : 0.0)) - Cs[i * LD + j] - Cs[j * LD + i];
+        Gl[i * LD + j] = v;
+      }
+  __syncthreads();
+  // ---- A = Linv^T At Linv, contracted on the fly with dKzz/dZ and dKzz/dtheta
+  d4 gzrow[NT];
+#pragma unroll
+  for (int a = 0; a < NT; ++a) gzrow[a] = (d4){0.0, 0.0, 0.0, 0.0};
+  double t0 = 0.0, t1 = 0.0;
+#pragma unroll
+  for (int c = 0; c < NT; ++c) {
+    d4 P[NT], Dm[NT], Am[NT];
+#pragma unroll
+    for (int b = 0; b < NT; ++b)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) P[b][q] = Li[(16 * b + 4 * q + lg) * LD + 16 * c + li];
+#pragma unroll
+    for (int a = 0; a < NT; ++a) {
+      d4 acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+      for (int b = c; b < NT; ++b)   // Linv lower triangular
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+          acc = __builtin_amdgcn_mfma_f64_16x16x4f64(Gl[(16 * a + li) * LD + 16 * b + 4 * q + lg], P[b][q], acc, 0, 0, 0);
+      Dm[a] = acc;
+    }
+    tri_chain<NT, 1>(Am, Li, LD, Dm, li, lg);
+    const double zc = zl[16 * c + li];
+#pragma unroll
+    for (int a = 0; a < NT; ++a)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        int i = 16 * a + 4 * q + lg, j = 16 * c + li;
+        if (i < M && j < M) {
+          double kt, bz, b0, b1;
+          kern_eval<KT>(zl[i] - zc, p, kt, bz, b0, b1);
+          double ak = Am[a][q] * kt;
+          gzrow[a][q] -= ak * bz;
+          t0 = fma(ak, b0, t0);
+          t1 = fma(ak, b1, t1);
+        }
+      }
+  }
+  t0 = wave_sum(t0) * p.c0;
+  t1 = wave_sum(t1) * p.c1;
+  __syncthreads();
+  // direct spike part a_j cz P1_j lives on lanes j < M; park it in gs for the row owners
+  if (lane < M) gs[lane] = a_l * p.cz * p1sum;
+  __syncthreads();
+#pragma unroll
+  for (int a = 0; a < NT; ++a)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      double g = row16_sum(gzrow[a][q]) * 2.0 * p.cz;
+      int i = 16 * a + 4 * q + lg;
+      if ((mask & 8u) && li == 0 && i < M) pt.g_Z[(long long)r * M + i] = g + ev.gZq[vbase + i] + gs[i];
+    }
+  if (lane == 0) {
+    double s0 = 0.0, s1 = 0.0;
+    for (int c = ev.chunk_first[r]; c < ev.chunk_first[r + 1]; ++c) {
+      s0 += ev.Tpart[((long long)c * ev.K + k) * 2 + 0];
+      s1 += ev.Tpart[((long long)c * ev.K + k) * 2 + 1];
+    }
+    ev.gthitem[item * 2 + 0] = t0 + ev.gthq[item * 2 + 0] + p.c0 * s0;
+    ev.gthitem[item * 2 + 1] = t1 + ev.gthq[item * 2 + 1] + p.c1 * s1;
+  }
+}

@@ -8,11 +8,32 @@
 //   P0_j = sum_s c_s ktil_sj            -> g_a_j = s2 P0_j, ELL_spk = a . g_a
 //   P1_j = sum_s c_s ktil_sj bz_sj      -> direct dZ_j = a_j cz P1_j
 //   T_t  = sum_s c_s sum_j a_j ktil_sj bt_sj -> direct dtheta_t = c_t T_t
-//   mu_s = s2 sum_j ktil_sj a_j         -> dC[n_s, k] (segment sums per neuron)
+//   mu_s = s2 sum_j ktil_sj a_j         -> dC[n, k] += sum_{s in n} mu_s, emitted per neuron by an
+//                                          in-wave segmented scan (spikes are neuron-sorted)
 // Replaces the reference's K*R Python loop of kernelsMatricesStore.py:208-221,
 // svPosteriorOnLatents.py:265-300 and svEmbedding.py:137-144; Ktz is never materialised.
 #pragma once
 #include "engine_common.h"
+
+// One group of 64 consecutive, neuron-sorted spikes: inclusive segmented scan of v over equal
+// keys, continuing the carry (ck, cv) of the previous group; completed segments are stored
+// (each (neuron) has exactly one writer).  key < 0 marks padding lanes (always at the end).
+__device__ __forceinline__ void seg_emit(int key, double v, int& ck, double& cv, double* out, int K,
+                                         int lane) {
+#pragma unroll
+  for (int dd = 1; dd < 64; dd <<= 1) {
+    double vu = __shfl_up(v, dd, 64);
+    int ku = __shfl_up(key, dd, 64);
+    if (lane >= dd && ku == key) v += vu;
+  }
+  if (key == ck) v += cv;
+  const int k0 = __shfl(key, 0, 64);
+  if (ck >= 0 && k0 != ck && lane == 0) out[(long long)ck * K] = cv;
+  const int kn = __shfl_down(key, 1, 64);
+  if (lane < 63 && key >= 0 && key != kn) out[(long long)key * K] = v;
+  ck = __shfl(key, 63, 64);
+  cv = __shfl(v, 63, 64);
+}
 
 template <int KT, bool FULL>
 __device__ void spike_body(const EngineView& ev, const double* __restrict__ C, int ch, int k,
@@ -26,13 +47,15 @@ __device__ void spike_body(const EngineView& ev, const double* __restrict__ C, i
   const double* __restrict__ a = ev.a + m.offM + (long long)r * M;
 
   double t[SV_SPL], cw[SV_SPL], mu[SV_SPL], T0[SV_SPL], T1[SV_SPL];
+  int nid[SV_SPL];
 #pragma unroll
   for (int i = 0; i < SV_SPL; ++i) {
     int idx = i * 64 + lane;
     bool ok = idx < c.count;
     long long gs = c.start + (ok ? idx : 0);
     t[i] = ev.spk_t[gs];
-    cw[i] = ok ? C[(long long)ev.spk_n[gs] * K + k] : 0.0;
+    nid[i] = ok ? ev.spk_n[gs] : -1;
+    cw[i] = ok ? C[(long long)nid[i] * K + k] : 0.0;
     mu[i] = 0.0;
     T0[i] = 0.0;
     T1[i] = 0.0;
@@ -92,10 +115,23 @@ __device__ void spike_body(const EngineView& ev, const double* __restrict__ C, i
     double t0 = 0.0, t1 = 0.0;
 #pragma unroll
     for (int i = 0; i < SV_SPL; ++i) {
-      int idx = i * 64 + lane;
-      if (idx < c.count) ev.muspk[(long long)k * ev.S + c.start + idx] = p.s2 * mu[i];
       t0 = fma(cw[i], T0[i], t0);
       t1 = fma(cw[i], T1[i], t1);
+    }
+    // spike part of dC[n, k]: per-neuron sums of mu_s
+    if (c.split) {
+      double tot = 0.0;
+#pragma unroll
+      for (int i = 0; i < SV_SPL; ++i) tot += (nid[i] >= 0) ? mu[i] : 0.0;
+      tot = wave_sum(tot);
+      if (lane == 0) ev.splitPart[(long long)ch * K + k] = p.s2 * tot;
+    } else {
+      double* out = ev.gCspk + (long long)r * ev.N * K + k;
+      int ck = -1;
+      double cv = 0.0;
+#pragma unroll
+      for (int i = 0; i < SV_SPL; ++i) seg_emit(nid[i], p.s2 * mu[i], ck, cv, out, K, lane);
+      if (ck >= 0 && lane == 0) out[(long long)ck * K] = cv;
     }
     t0 = wave_sum(t0);
     t1 = wave_sum(t1);
@@ -117,20 +153,6 @@ __global__ __launch_bounds__(64) void k_spike(EngineView ev, const double* __res
     spike_body<SV_PERIODIC, FULL>(ev, C, ch, k, red);
 }
 
-// dC from the spike term: segment sums of mu_spk over the spikes of each (trial, neuron),
-// added to the trial's first quadrature-block partial.  Thread = (k, trial*N + neuron).
-__global__ void k_spike_gc(EngineView ev) {
-  long long id = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  long long RN = (long long)ev.R * ev.N;
-  if (id >= RN * ev.K) return;
-  int k = (int)(id / RN);
-  long long rn = id % RN;
-  int r = (int)(rn / ev.N), n = (int)(rn % ev.N);
-  double s = 0.0;
-  for (long long i = ev.seg_off[rn]; i < ev.seg_off[rn + 1]; ++i) s += ev.muspk[(long long)k * ev.S + i];
-  ev.gCpart[(((long long)r * ev.nqt) * ev.N + n) * ev.K + k] += s;
-}
-
 // Mseg[n][k] = sum over all local spikes of neuron n of mu_k(t_s)   (embedding M-step path)
 __global__ void k_mseg(EngineView ev) {
   int id = blockIdx.x * blockDim.x + threadIdx.x;
@@ -148,20 +170,27 @@ __global__ void k_mseg(EngineView ev) {
 
 // ------------------------------------------------------------------------------ k_finalize
 // Fixed-order reductions of the per-trial partials into the `shared` output vector
-// [ELBO, ELL, KL, dC (N*K), dd (N), dtheta].  Last block does the three scalars.
+// [ELBO, ELL, KL, dC (N*K), dd (N), dtheta].  Block roles by blockIdx:
+//   [0, nbC)            dC : 32 outputs x 8 trial groups per block; each thread sums its trials'
+//                            quadrature and spike partials, then the 8 groups are added in order
+//                            through LDS
+//   [nbC, nbC+nbD)      dd, [.., +nbT) dtheta : same scheme
+//   last block          the three scalars
 __global__ __launch_bounds__(256) void k_finalize(EngineView ev, const double* d, unsigned mask,
                                                   double* shared) {
-  __shared__ double red[4];
-  const int tid = threadIdx.x;
-  const int NK = ev.N * ev.K, nblk = ev.R * ev.nqt;
-  if (blockIdx.x == gridDim.x - 1) {
+  __shared__ double red[8 * 32];
+  const int tid = threadIdx.x, o = tid & 31, pg = tid >> 5;
+  const int NK = ev.N * ev.K, N = ev.N, K = ev.K, R = ev.R, nqt = ev.nqt;
+  const int nbC = (NK + 31) / 32, nbD = (N + 31) / 32, nbT = (ev.nth_total + 31) / 32;
+  int blk = blockIdx.x;
+  if (blk == nbC + nbD + nbT) {
     double e = 0.0, kl = 0.0;
-    for (int i = tid; i < nblk; i += 256) e += ev.ellq[i];
-    for (int i = tid; i < ev.R * ev.K; i += 256) {
+    for (int i = tid; i < R * nqt; i += 256) e += ev.ellq[i];
+    for (int i = tid; i < R * K; i += 256) {
       e += ev.ells[i];
       kl += ev.klpart[i];
     }
-    for (int n = tid; n < ev.N; n += 256) e += ev.spk_cnt[n] * d[n];
+    for (int n = tid; n < N; n += 256) e += ev.spk_cnt[n] * d[n];
     e = block_sum(e, red);
     kl = block_sum(kl, red);
     if (tid == 0) {
@@ -171,29 +200,54 @@ __global__ __launch_bounds__(256) void k_finalize(EngineView ev, const double* d
     }
     return;
   }
-  int id = blockIdx.x * 256 + tid;
-  if (id < NK) {
-    double s = 0.0;
-    if (mask & 2u)
-      for (int b = 0; b < nblk; ++b) s += ev.gCpart[(long long)b * NK + id];
-    shared[3 + id] = s;
-  } else if (id < NK + ev.N) {
-    int n = id - NK;
-    double s = 0.0;
-    if (mask & 2u) {
-      for (int b = 0; b < nblk; ++b) s += ev.gdpart[(long long)b * ev.N + n];
-      s += ev.spk_cnt[n];
+  double s = 0.0;
+  int out = -1;
+  if (blk < nbC) {
+    const int id = blk * 32 + o;
+    if (id < NK) {
+      out = 3 + id;
+      if (mask & 2u) {
+        const int n = id / K, k = id % K;
+        for (int r = pg; r < R; r += 8) {
+          double v = ev.gCspk[(long long)r * NK + id];
+          for (int qt = 0; qt < nqt; ++qt) v += ev.gCpart[((long long)r * nqt + qt) * NK + id];
+          s += v;
+        }
+        if (pg == 0)
+          for (int l = 0; l < ev.nsplit; ++l) {
+            const int ch = ev.split_chunks[l];
+            if (ev.chunks[ch].neuron == n) s += ev.splitPart[(long long)ch * K + k];
+          }
+      }
     }
-    shared[3 + id] = s;
-  } else if (id < NK + ev.N + ev.nth_total) {
-    int ti = id - NK - ev.N;
-    int k = 0;
-    while (k + 1 < ev.K && ev.meta[k + 1].thoff <= ti) ++k;
-    int t = ti - ev.meta[k].thoff;
-    double s = 0.0;
-    if (mask & 4u)
-      for (int r = 0; r < ev.R; ++r) s += ev.gthitem[((long long)r * ev.K + k) * 2 + t];
-    shared[3 + id] = s;
+  } else if (blk < nbC + nbD) {
+    const int n = (blk - nbC) * 32 + o;
+    if (n < N) {
+      out = 3 + NK + n;
+      if (mask & 2u) {
+        for (int b = pg; b < R * nqt; b += 8) s += ev.gdpart[(long long)b * N + n];
+        if (pg == 0) s += ev.spk_cnt[n];
+      }
+    }
+  } else {
+    const int ti = (blk - nbC - nbD) * 32 + o;
+    if (ti < ev.nth_total) {
+      out = 3 + NK + N + ti;
+      if (mask & 4u) {
+        int k = 0;
+        while (k + 1 < K && ev.meta[k + 1].thoff <= ti) ++k;
+        const int t = ti - ev.meta[k].thoff;
+        for (int r = pg; r < R; r += 8) s += ev.gthitem[((long long)r * K + k) * 2 + t];
+      }
+    }
+  }
+  red[pg * 32 + o] = s;
+  __syncthreads();
+  if (pg == 0 && out >= 0) {
+    double t = red[o];
+#pragma unroll
+    for (int g = 1; g < 8; ++g) t += red[g * 32 + o];
+    shared[out] = t;
   }
 }
 

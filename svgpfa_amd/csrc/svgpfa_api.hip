@@ -10,6 +10,7 @@
 
 #include "engine_common.h"
 #include "kernels_item.h"
+#include "kernels_mfma.h"
 #include "kernels_spike.h"
 #include "kernels_times.h"
 
@@ -28,7 +29,7 @@ struct svgpfa_engine {
   std::vector<void*> allocs;
   hipStream_t stream = nullptr;
   int device = 0;
-  int Mmax = 0, KT = 0;
+  int Mmax = 0, KT = 0, NT = 1;
   long long totM = 0, totMM = 0;  // R*sum M, R*sum M^2
   bool have_quad = false, have_spikes = false, have_kernels = false, have_stats = false;
   bool timing = false;
@@ -80,6 +81,21 @@ static size_t lds_qbwd(int M) {
   int QB = (M <= 32) ? 64 : 32;
   return ((size_t)2 * M * (M + 1) + (size_t)3 * QB * (M + 1) + 64 * 5 + 4) * 8;
 }
+static size_t lds_times_mfma(int NT) {
+  size_t MP = 16 * NT, LD = MP + 2;
+  return (2 * MP * LD + 2 * MP) * 8;
+}
+static size_t lds_qbwd_mfma(int NT) {
+  size_t MP = 16 * NT, LD = MP + 2;
+  return (2 * MP * LD + 2 * MP + 4 * 16 * LD + 64 + 8 * MP + 8) * 8;
+}
+#define DISPATCH_NT(nt, ...)                                 \
+  switch (nt) {                                              \
+    case 1: { constexpr int NT_ = 1; __VA_ARGS__; } break;   \
+    case 2: { constexpr int NT_ = 2; __VA_ARGS__; } break;   \
+    case 3: { constexpr int NT_ = 3; __VA_ARGS__; } break;   \
+    default: { constexpr int NT_ = 4; __VA_ARGS__; } break;  \
+  }
 static size_t lds_qell(const svgpfa_engine* e) {
   return ((size_t)2 * e->v.qtile * e->KT + e->v.qtile + (size_t)e->v.N * e->KT + e->v.N + 4) * 8;
 }
@@ -91,6 +107,19 @@ __global__ __launch_bounds__(64) void k_prep_entry(EngineView ev, PtrTable pt) {
 __global__ __launch_bounds__(64) void k_bwd_entry(EngineView ev, PtrTable pt, unsigned mask) {
   extern __shared__ double sm[];
   k_bwd_body(ev, pt.p[blockIdx.x % ev.K], mask, sm);
+}
+template <int NT>
+__global__ __launch_bounds__(64) void k_bwd_mfma(EngineView ev, PtrTable pt, unsigned mask) {
+  extern __shared__ double sm[];
+  const int k = blockIdx.x % ev.K;
+  if (ev.meta[k].ktype == SV_RBF)
+    bwd_mfma_body<NT, SV_RBF>(ev, pt.p[k], mask, sm);
+  else
+    bwd_mfma_body<NT, SV_PERIODIC>(ev, pt.p[k], mask, sm);
+}
+static size_t lds_bwd_mfma(int NT) {
+  size_t MP = 16 * NT, LD = MP + 2;
+  return (4 * MP * LD + 4 * MP) * 8;
 }
 
 template <typename F>
@@ -144,6 +173,7 @@ int svgpfa_create(const svgpfa_dims* d, int device, svgpfa_engine** out) {
   v.qtile = std::min(v.Q, 256);
   v.nqt = (v.Q + v.qtile - 1) / v.qtile;
   e->KT = 4 * ((v.K + 3) / 4);
+  e->NT = (e->Mmax + 15) / 16;
 
   LatentMeta* dmeta; DALLOC(e, dmeta, v.K);
   HIPCHK(e, hipMemcpy(dmeta, e->meta.data(), sizeof(LatentMeta) * v.K, hipMemcpyHostToDevice));
@@ -173,9 +203,14 @@ int svgpfa_create(const svgpfa_dims* d, int device, svgpfa_engine** out) {
   if ((rc = allow_lds(e, k_build, lds_build(e->Mmax)))) return rc;
   if ((rc = allow_lds(e, k_prep_entry, lds_prep(e->Mmax)))) return rc;
   if ((rc = allow_lds(e, k_bwd_entry, lds_bwd(e->Mmax)))) return rc;
-  if ((rc = allow_lds(e, k_times_fwd, lds_times(e->Mmax)))) return rc;
-  if ((rc = allow_lds(e, k_quad_bwd<true>, lds_qbwd(e->Mmax)))) return rc;
-  if ((rc = allow_lds(e, k_quad_bwd<false>, lds_qbwd(e->Mmax)))) return rc;
+  DISPATCH_NT(e->NT, rc = allow_lds(e, k_bwd_mfma<NT_>, lds_bwd_mfma(NT_)));
+  if (rc) return rc;
+  DISPATCH_NT(e->NT, rc = allow_lds(e, k_times_fwd_mfma<NT_>, lds_times_mfma(NT_)));
+  if (rc) return rc;
+  DISPATCH_NT(e->NT, rc = allow_lds(e, (k_quad_bwd_mfma<NT_, true>), lds_qbwd_mfma(NT_)));
+  if (rc) return rc;
+  DISPATCH_NT(e->NT, rc = allow_lds(e, (k_quad_bwd_mfma<NT_, false>), lds_qbwd_mfma(NT_)));
+  if (rc) return rc;
   size_t lq = lds_qell(e);
   switch (e->KT) {
 #define CASE_KT(X) case X: rc = allow_lds(e, k_quad_ell<X>, lq); break;
@@ -258,33 +293,52 @@ int svgpfa_set_spikes(svgpfa_engine* e, const int64_t* off, const double* times,
   std::vector<long long> seg((size_t)v.R * v.N + 1);
   std::vector<double> cnt(v.N, 0.0);
   std::vector<SpikeChunk> chunks;
-  std::vector<int> cfirst(v.R + 1);
+  std::vector<int> cfirst(v.R + 1), splits;
   for (int r = 0; r < v.R; ++r) {
     long long s0 = off[r], s1 = off[r + 1];
     long long i = s0;
+    cfirst[r] = (int)chunks.size();
+    SpikeChunk cur{r, 0, s0, 0, -1};
+    auto flush = [&]() {
+      if (cur.count > 0) chunks.push_back(cur);
+      cur.count = 0;
+    };
     for (int n = 0; n < v.N; ++n) {
       seg[(size_t)r * v.N + n] = i;
+      long long b = i;
       while (i < s1 && nh[i] == n) { ++i; cnt[n] += 1.0; }
+      long long len = i - b;
+      if (len == 0) continue;
+      if (len > SV_SPIKE_CHUNK) {             // oversize segment: dedicated split chunks
+        flush();
+        for (long long c = b; c < i; c += SV_SPIKE_CHUNK) {
+          SpikeChunk sc{r, (int)std::min<long long>(SV_SPIKE_CHUNK, i - c), c, 1, n};
+          splits.push_back((int)chunks.size());
+          chunks.push_back(sc);
+        }
+        cur.start = i;
+      } else {
+        if (cur.count + len > SV_SPIKE_CHUNK) flush();
+        if (cur.count == 0) cur.start = b;
+        cur.count += (int)len;
+      }
     }
+    flush();
     if (i != s1)
       FAIL(e, SVGPFA_ERR_INVALID,
            "spikes of a trial must be grouped by non-decreasing neuron index in [0, n_neurons)");
-    cfirst[r] = (int)chunks.size();
-    for (long long c = s0; c < s1; c += SV_SPIKE_CHUNK) {
-      SpikeChunk ch;
-      ch.trial = r;
-      ch.start = c;
-      ch.count = (int)std::min<long long>(SV_SPIKE_CHUNK, s1 - c);
-      chunks.push_back(ch);
-    }
   }
   seg[(size_t)v.R * v.N] = S;
   cfirst[v.R] = (int)chunks.size();
   v.nchunks = (int)chunks.size();
 
-  double* st; int* sn; long long* so; long long* sg; double* sc; SpikeChunk* dc; int* cf;
+  double* st; int* sn; long long* so; long long* sg; double* sc; SpikeChunk* dc; int* cf; int* sp;
   DALLOC(e, st, S); DALLOC(e, sn, S); DALLOC(e, so, v.R + 1); DALLOC(e, sg, seg.size());
-  DALLOC(e, sc, v.N); DALLOC(e, dc, chunks.size()); DALLOC(e, cf, v.R + 1);
+  DALLOC(e, sc, v.N); DALLOC(e, dc, chunks.size()); DALLOC(e, cf, v.R + 1); DALLOC(e, sp, splits.size());
+  if (!splits.empty())
+    HIPCHK(e, hipMemcpy(sp, splits.data(), sizeof(int) * splits.size(), hipMemcpyHostToDevice));
+  v.split_chunks = sp;
+  v.nsplit = (int)splits.size();
   if (S) {
     HIPCHK(e, hipMemcpy(st, times, sizeof(double) * S, hipMemcpyDeviceToDevice));
     HIPCHK(e, hipMemcpy(sn, neuron, sizeof(int32_t) * S, hipMemcpyDeviceToDevice));
@@ -300,6 +354,9 @@ int svgpfa_set_spikes(svgpfa_engine* e, const int64_t* off, const double* times,
   DALLOC(e, v.P0, (size_t)v.nchunks * v.sumM); DALLOC(e, v.P1, (size_t)v.nchunks * v.sumM);
   DALLOC(e, v.Tpart, (size_t)v.nchunks * v.K * 2);
   DALLOC(e, v.muspk, (size_t)v.K * S); DALLOC(e, v.varspk, (size_t)v.K * S);
+  DALLOC(e, v.gCspk, (size_t)v.R * v.N * v.K); DALLOC(e, v.splitPart, (size_t)v.nchunks * v.K);
+  HIPCHK(e, hipMemset(v.gCspk, 0, sizeof(double) * (size_t)v.R * v.N * v.K));
+  HIPCHK(e, hipMemset(v.splitPart, 0, sizeof(double) * std::max<size_t>(1, (size_t)v.nchunks * v.K)));
   HIPCHK(e, hipMemset(v.P1, 0, sizeof(double) * std::max<size_t>(1, (size_t)v.nchunks * v.sumM)));
   HIPCHK(e, hipMemset(v.Tpart, 0, sizeof(double) * std::max<size_t>(1, (size_t)v.nchunks * v.K * 2)));
   e->have_spikes = true;
@@ -364,6 +421,15 @@ static int launch_quad_ell(svgpfa_engine* e, const double* C, const double* d, i
   return SVGPFA_OK;
 }
 
+static int launch_times(svgpfa_engine* e, const double* times, const long long* toff, int nper, double* mu,
+                        double* var, long long os_t, long long os_k, int want_var) {
+  EngineView& v = e->v;
+  DISPATCH_NT(e->NT, hipLaunchKernelGGL(k_times_fwd_mfma<NT_>, dim3(v.R * v.K), dim3(256), lds_times_mfma(NT_),
+                                        e->stream, v, times, toff, nper, mu, var, os_t, os_k, want_var));
+  HIPCHK(e, hipGetLastError());
+  return SVGPFA_OK;
+}
+
 static int check_ready(svgpfa_engine* e) {
   if (!e->have_quad) FAIL(e, SVGPFA_ERR_STATE, "svgpfa_set_quad has not been called");
   if (!e->have_spikes) FAIL(e, SVGPFA_ERR_STATE, "svgpfa_set_spikes has not been called");
@@ -385,14 +451,14 @@ int svgpfa_elbo(svgpfa_engine* e, const double* const* mean, const double* const
   const bool full = (mask & (2u | 4u | 8u)) != 0;
 
   hipLaunchKernelGGL(k_prep_entry, dim3(RK), dim3(64), lds_prep(e->Mmax), e->stream, v, pt);
-  hipLaunchKernelGGL(k_times_fwd, dim3(RK), dim3(256), lds_times(e->Mmax), e->stream, v, v.tq,
-                     (const long long*)nullptr, v.Q, v.muq, v.varq, (long long)v.K, 1LL, 1);
+  if ((rc = launch_times(e, v.tq, nullptr, v.Q, v.muq, v.varq, (long long)v.K, 1LL, 1))) return rc;
   if ((rc = launch_quad_ell(e, C, d, (mask & 2u) ? 1 : 0, want_lat ? 1 : 0))) return rc;
   if (want_lat) {
-    if (mask & (4u | 8u))
-      hipLaunchKernelGGL(k_quad_bwd<true>, dim3(RK), dim3(256), lds_qbwd(e->Mmax), e->stream, v);
-    else
-      hipLaunchKernelGGL(k_quad_bwd<false>, dim3(RK), dim3(256), lds_qbwd(e->Mmax), e->stream, v);
+    if (mask & (4u | 8u)) {
+      DISPATCH_NT(e->NT, hipLaunchKernelGGL((k_quad_bwd_mfma<NT_, true>), dim3(RK), dim3(256), lds_qbwd_mfma(NT_), e->stream, v));
+    } else {
+      DISPATCH_NT(e->NT, hipLaunchKernelGGL((k_quad_bwd_mfma<NT_, false>), dim3(RK), dim3(256), lds_qbwd_mfma(NT_), e->stream, v));
+    }
   }
   if (v.nchunks > 0) {
     std::pair<hipEvent_t, hipEvent_t>* evp = nullptr;
@@ -411,14 +477,10 @@ int svgpfa_elbo(svgpfa_engine* e, const double* const* mean, const double* const
     else
       hipLaunchKernelGGL(k_spike<false>, dim3(v.nchunks * v.K), dim3(64), 0, e->stream, v, C);
     if (evp) HIPCHK(e, hipEventRecord(evp->second, e->stream));
-    if (mask & 2u) {
-      long long tot = (long long)v.R * v.N * v.K;
-      hipLaunchKernelGGL(k_spike_gc, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, e->stream, v);
-    }
   }
-  hipLaunchKernelGGL(k_bwd_entry, dim3(RK), dim3(64), lds_bwd(e->Mmax), e->stream, v, pt, mask);
-  int nout = v.N * v.K + v.N + v.nth_total;
-  hipLaunchKernelGGL(k_finalize, dim3((nout + 255) / 256 + 1), dim3(256), 0, e->stream, v, d, mask, shared);
+  DISPATCH_NT(e->NT, hipLaunchKernelGGL(k_bwd_mfma<NT_>, dim3(RK), dim3(64), lds_bwd_mfma(NT_), e->stream, v, pt, mask));
+  int nfin = (v.N * v.K + 31) / 32 + (v.N + 31) / 32 + (v.nth_total + 31) / 32 + 1;
+  hipLaunchKernelGGL(k_finalize, dim3(nfin), dim3(256), 0, e->stream, v, d, mask, shared);
   HIPCHK(e, hipGetLastError());
   return SVGPFA_OK;
 }
@@ -433,10 +495,8 @@ int svgpfa_latent_stats(svgpfa_engine* e, const double* const* mean, const doubl
   if ((rc = fill_ptrs(e, pt, mean, cholvec, nullptr, nullptr, nullptr, 0))) return rc;
   const int RK = v.R * v.K;
   hipLaunchKernelGGL(k_prep_entry, dim3(RK), dim3(64), lds_prep(e->Mmax), e->stream, v, pt);
-  hipLaunchKernelGGL(k_times_fwd, dim3(RK), dim3(256), lds_times(e->Mmax), e->stream, v, v.tq,
-                     (const long long*)nullptr, v.Q, v.muq, v.varq, (long long)v.K, 1LL, 1);
-  hipLaunchKernelGGL(k_times_fwd, dim3(RK), dim3(256), lds_times(e->Mmax), e->stream, v, v.spk_t,
-                     v.spk_off, 0, v.muspk, v.varspk, 1LL, (long long)v.S, 1);
+  if ((rc = launch_times(e, v.tq, nullptr, v.Q, v.muq, v.varq, (long long)v.K, 1LL, 1))) return rc;
+  if ((rc = launch_times(e, v.spk_t, v.spk_off, 0, v.muspk, v.varspk, 1LL, (long long)v.S, 1))) return rc;
   hipLaunchKernelGGL(k_mseg, dim3((v.N * v.K + 255) / 256), dim3(256), 0, e->stream, v);
   size_t rqk = sizeof(double) * v.R * v.Q * v.K;
   if (mu_quad) HIPCHK(e, hipMemcpyAsync(mu_quad, v.muq, rqk, hipMemcpyDeviceToDevice, e->stream));
@@ -474,8 +534,7 @@ int svgpfa_predict(svgpfa_engine* e, const double* const* mean, const double* co
   if ((rc = fill_ptrs(e, pt, mean, cholvec, nullptr, nullptr, nullptr, 0))) return rc;
   const int RK = v.R * v.K;
   hipLaunchKernelGGL(k_prep_entry, dim3(RK), dim3(64), lds_prep(e->Mmax), e->stream, v, pt);
-  hipLaunchKernelGGL(k_times_fwd, dim3(RK), dim3(256), lds_times(e->Mmax), e->stream, v, times,
-                     (const long long*)nullptr, (int)T, mu, var ? var : mu, (long long)v.K, 1LL, var ? 1 : 0);
+  if ((rc = launch_times(e, times, nullptr, (int)T, mu, var ? var : mu, (long long)v.K, 1LL, var ? 1 : 0))) return rc;
   HIPCHK(e, hipGetLastError());
   e->have_stats = false;  // k_prep overwrote a / W with these parameters; stats must be recomputed
   return SVGPFA_OK;
