@@ -17,6 +17,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "sv_math.h"
+
 #define SV_RBF 0
 #define SV_PERIODIC 1
 #define SV_MAX_M 64
@@ -57,6 +59,8 @@ struct SpikeChunk {
 struct EngineView {
   int R, N, K, Q, S;
   int sumM, nchunks, nqt, qtile, nth_total;
+  int ntype[2];               // number of RBF / periodic latents
+  int klist[2][SV_MAX_K];     // their indices: kernels are launched once per covariance type
   double reg;
   const LatentMeta* meta;
   const double* tq;
@@ -97,15 +101,20 @@ struct EngineView {
 //   d kappa / d theta_1 = ktil * b1 * c1        (period, unscaled parameter; periodic only)
 struct KPar {
   double s2, h, ip, cz, c0, c1;
+  double h2;   // base-2 exponent scale: RBF h log2(e); periodic h log2(e) / 2
+  double q4;   // periodic: 4 / p  (angle 2 pi delta / p = (pi/2) (q4 delta))
 };
 
 __device__ __forceinline__ KPar make_kpar(const LatentMeta& m, const double* th) {
   KPar p;
   const double PI = 3.14159265358979323846;
+  const double L2E = 1.4426950408889634074;
   double l = th[0] * m.inv_ls_scale;
   p.s2 = m.scale2;
   if (m.ktype == SV_RBF) {
     p.h = 0.5 / (l * l);
+    p.h2 = p.h * L2E;
+    p.q4 = 0.0;
     p.ip = 0.0;
     p.cz = p.s2 * 2.0 * p.h;
     p.c0 = p.s2 * 2.0 * p.h / l * m.inv_ls_scale;
@@ -114,6 +123,8 @@ __device__ __forceinline__ KPar make_kpar(const LatentMeta& m, const double* th)
     double per = th[1] * m.inv_p_scale;
     p.ip = 1.0 / per;
     p.h = 2.0 / (l * l);
+    p.h2 = 0.5 * p.h * L2E;
+    p.q4 = 4.0 * p.ip;
     p.cz = p.s2 * PI * p.h * p.ip;
     p.c0 = p.s2 * 2.0 * p.h / l * m.inv_ls_scale;
     p.c1 = p.s2 * PI * p.h * p.ip * p.ip * m.inv_p_scale;
@@ -121,15 +132,17 @@ __device__ __forceinline__ KPar make_kpar(const LatentMeta& m, const double* th)
   return p;
 }
 
+// ktil via the lean base-2 kernels of sv_math.h (no special cases, <= 1 ulp polynomials):
+//   RBF       ktil = 2^(-delta^2 h2)
+//   periodic  sin^2(pi delta / p) = (1 - cos(2 pi delta / p)) / 2  ->  ktil = 2^(h2 (cs - 1))
 template <int KT>
 __device__ __forceinline__ double kern_val(double delta, const KPar& p) {
   if (KT == SV_RBF) {
-    return exp(-(delta * delta) * p.h);
+    return sv_exp2_neg(-(delta * delta) * p.h2);
   } else {
-    double u = delta * p.ip;
-    double r = u - rint(u);
-    double sn = sinpi(r);
-    return exp(-(sn * sn) * p.h);
+    double sn, cs;
+    sv_sincos_quarter(delta * p.q4, sn, cs);
+    return sv_exp2_neg(fma(cs, p.h2, -p.h2));
   }
 }
 
@@ -138,20 +151,17 @@ __device__ __forceinline__ void kern_eval(double delta, const KPar& p, double& k
                                           double& b0, double& b1) {
   if (KT == SV_RBF) {
     double q = delta * delta;
-    kt = exp(-q * p.h);
+    kt = sv_exp2_neg(-q * p.h2);
     bz = delta;
     b0 = q;
     b1 = 0.0;
   } else {
-    double u = delta * p.ip;
-    double r = u - rint(u);
     double sn, cs;
-    sincospi(r, &sn, &cs);
-    double ss = sn * sn;
-    kt = exp(-ss * p.h);
-    bz = 2.0 * sn * cs;
-    b0 = ss;
-    b1 = delta * bz;
+    sv_sincos_quarter(delta * p.q4, sn, cs);
+    kt = sv_exp2_neg(fma(cs, p.h2, -p.h2));
+    bz = sn;
+    b0 = 0.5 - 0.5 * cs;
+    b1 = delta * sn;
   }
 }
 

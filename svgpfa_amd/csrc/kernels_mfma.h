@@ -86,7 +86,8 @@ __device__ void times_fwd_body(const EngineView& ev, const double* times, const 
   constexpr int MP = 16 * NT, LD = MP + 2;
   const int item = blockIdx.x, tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6, li = lane & 15, lg = lane >> 4;
-  const int r = item / ev.K, k = item % ev.K;
+  const int nk = ev.ntype[KT];
+  const int r = item / nk, k = ev.klist[KT][item % nk];
   const LatentMeta m = ev.meta[k];
   double* Li = sm;
   double* Vl = Li + MP * LD;
@@ -146,16 +147,13 @@ __device__ void times_fwd_body(const EngineView& ev, const double* times, const 
   }
 }
 
-template <int NT>
+template <int NT, int KT>
 __global__ __launch_bounds__(256) void k_times_fwd_mfma(EngineView ev, const double* times,
                                                         const long long* toff, int nper, double* mu_out,
                                                         double* var_out, long long os_t, long long os_k,
                                                         int want_var) {
   extern __shared__ double sm[];
-  if (ev.meta[blockIdx.x % ev.K].ktype == SV_RBF)
-    times_fwd_body<NT, SV_RBF>(ev, times, toff, nper, mu_out, var_out, os_t, os_k, want_var, sm);
-  else
-    times_fwd_body<NT, SV_PERIODIC>(ev, times, toff, nper, mu_out, var_out, os_t, os_k, want_var, sm);
+  times_fwd_body<NT, KT>(ev, times, toff, nper, mu_out, var_out, os_t, os_k, want_var, sm);
 }
 
 // ------------------------------------------------------------------------- k_quad_bwd_mfma
@@ -164,9 +162,11 @@ __global__ __launch_bounds__(256) void k_times_fwd_mfma(EngineView ev, const dou
 template <int NT, int KT, bool FULL>
 __device__ void quad_bwd_mfma_body(const EngineView& ev, double* sm) {
   constexpr int MP = 16 * NT, LD = MP + 2, NTRI = NT * (NT + 1) / 2;
-  const int item = blockIdx.x, tid = threadIdx.x;
+  const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6, li = lane & 15, lg = lane >> 4;
-  const int r = item / ev.K, k = item % ev.K;
+  const int nk = ev.ntype[KT];
+  const int r = blockIdx.x / nk, k = ev.klist[KT][blockIdx.x % nk];
+  const int item = r * ev.K + k;
   const LatentMeta m = ev.meta[k];
   const int M = m.M, Q = ev.Q, K = ev.K;
   double* Li = sm;                    // MP*LD
@@ -334,13 +334,10 @@ __device__ void quad_bwd_mfma_body(const EngineView& ev, double* sm) {
   }
 }
 
-template <int NT, bool FULL>
+template <int NT, int KT, bool FULL>
 __global__ __launch_bounds__(256) void k_quad_bwd_mfma(EngineView ev) {
   extern __shared__ double sm[];
-  if (ev.meta[blockIdx.x % ev.K].ktype == SV_RBF)
-    quad_bwd_mfma_body<NT, SV_RBF, FULL>(ev, sm);
-  else
-    quad_bwd_mfma_body<NT, SV_PERIODIC, FULL>(ev, sm);
+  quad_bwd_mfma_body<NT, KT, FULL>(ev, sm);
 }
 
 // ------------------------------------------------------------------------------ k_bwd_mfma
@@ -350,8 +347,10 @@ __global__ __launch_bounds__(256) void k_quad_bwd_mfma(EngineView ev) {
 template <int NT, int KT>
 __device__ void bwd_mfma_body(const EngineView& ev, const LatentPtrs pt, unsigned mask, double* sm) {
   constexpr int MP = 16 * NT, LD = MP + 2;
-  const int item = blockIdx.x, lane = threadIdx.x, li = lane & 15, lg = lane >> 4;
-  const int r = item / ev.K, k = item % ev.K;
+  const int lane = threadIdx.x, li = lane & 15, lg = lane >> 4;
+  const int nk = ev.ntype[KT];
+  const int r = blockIdx.x / nk, k = ev.klist[KT][blockIdx.x % nk];
+  const int item = r * ev.K + k;
   const LatentMeta m = ev.meta[k];
   const int M = m.M;
   double* Li = sm;               // MP*LD

@@ -14,6 +14,7 @@
 // svPosteriorOnLatents.py:265-300 and svEmbedding.py:137-144; Ktz is never materialised.
 #pragma once
 #include "engine_common.h"
+#include "sv_math.h"
 
 // One group of 64 consecutive, neuron-sorted spikes: inclusive segmented scan of v over equal
 // keys, continuing the carry (ck, cv) of the previous group; completed segments are stored
@@ -38,6 +39,8 @@ __device__ __forceinline__ void seg_emit(int key, double v, int& ck, double& cv,
 template <int KT, bool FULL>
 __device__ void spike_body(const EngineView& ev, const double* __restrict__ C, int ch, int k,
                            double* red) {
+  // NV partial-sum vectors per inducing point: P0 | P0 P1 P2 (RBF) | P0 P1 P2 P3 (periodic)
+  constexpr int NV = FULL ? (KT == SV_RBF ? 3 : 4) : 1;
   const int lane = threadIdx.x;
   const SpikeChunk c = ev.chunks[ch];
   const LatentMeta m = ev.meta[k];
@@ -45,78 +48,111 @@ __device__ void spike_body(const EngineView& ev, const double* __restrict__ C, i
   const KPar p = make_kpar(m, ev.theta + 2 * k);
   const double* __restrict__ z = ev.Zs + m.offM + (long long)r * M;
   const double* __restrict__ a = ev.a + m.offM + (long long)r * M;
+  // Scaled coordinates so that ktil = 2^y with no further multiplies:
+  //   RBF      u = (t - z) sc, sc = sqrt(h log2 e):  y = -u^2          bz = u / sc,  b0 = -y / sc^2
+  //   periodic w = (t - z) 4/p:  (sn, cs) = sincos(pi/2 w), y = hh (cs - 1), hh = h log2(e) / 2
+  //            bz = sn,  b0 = sin^2 = -y / (2 hh),  b1 = delta sn = (p/4) w sn
+  const double L2E = 1.4426950408889634074;
+  double sc, hh = 0.0, w1, w2, w3 = 0.0;
+  if (KT == SV_RBF) {
+    sc = sqrt(p.h * L2E);
+    w1 = 1.0 / sc;
+    w2 = -1.0 / (sc * sc);
+  } else {
+    sc = 4.0 * p.ip;
+    hh = 0.5 * p.h * L2E;
+    w1 = 1.0;
+    w2 = -1.0 / (2.0 * hh);
+    w3 = 1.0 / sc;
+  }
 
-  double t[SV_SPL], cw[SV_SPL], mu[SV_SPL], T0[SV_SPL], T1[SV_SPL];
+  double ts[SV_SPL], cw[SV_SPL], mu[SV_SPL];
   int nid[SV_SPL];
 #pragma unroll
   for (int i = 0; i < SV_SPL; ++i) {
     int idx = i * 64 + lane;
     bool ok = idx < c.count;
     long long gs = c.start + (ok ? idx : 0);
-    t[i] = ev.spk_t[gs];
+    ts[i] = ev.spk_t[gs] * sc;
     nid[i] = ok ? ev.spk_n[gs] : -1;
     cw[i] = ok ? C[(long long)nid[i] * K + k] : 0.0;
     mu[i] = 0.0;
-    T0[i] = 0.0;
-    T1[i] = 0.0;
   }
+  double t0acc = 0.0, t1acc = 0.0;
 
   for (int jb = 0; jb < M; jb += 8) {
 #pragma unroll
     for (int jj = 0; jj < 8; ++jj) {
       const int j = jb + jj;
-      double p0 = 0.0, p1 = 0.0;
+      double p0 = 0.0, p1 = 0.0, p2 = 0.0, p3 = 0.0;
       if (j < M) {
-        const double zj = z[j], aj = a[j];
+        const double zs = z[j] * sc, aj = a[j];
 #pragma unroll
         for (int i = 0; i < SV_SPL; ++i) {
-          if (FULL) {
-            double kt, bz, b0, b1;
-            kern_eval<KT>(t[i] - zj, p, kt, bz, b0, b1);
-            double ck = cw[i] * kt;
-            p0 += ck;
-            p1 = fma(ck, bz, p1);
-            double w = kt * aj;
-            mu[i] += w;
-            T0[i] = fma(w, b0, T0[i]);
-            if (KT == SV_PERIODIC) T1[i] = fma(w, b1, T1[i]);
+          const double u = ts[i] - zs;
+          double y, sn = 0.0;
+          if (KT == SV_RBF) {
+            y = -(u * u);
           } else {
-            p0 = fma(cw[i], kern_val<KT>(t[i] - zj, p), p0);
+            double cs;
+            sv_sincos_quarter(u, sn, cs);
+            y = fma(cs, hh, -hh);
+          }
+          const double kt = sv_exp2_neg(y);
+          if (FULL) {
+            const double ck = cw[i] * kt;
+            p0 += ck;
+            p1 = fma(ck, (KT == SV_RBF) ? u : sn, p1);
+            p2 = fma(ck, y, p2);
+            if (KT == SV_PERIODIC) p3 = fma(ck, u * sn, p3);
+            mu[i] = fma(kt, aj, mu[i]);
+          } else {
+            p0 = fma(cw[i], kt, p0);
           }
         }
       }
       red[jj * 65 + lane] = p0;
-      if (FULL) red[(8 + jj) * 65 + lane] = p1;
+      if (FULL) {
+        red[(8 + jj) * 65 + lane] = p1;
+        red[(16 + jj) * 65 + lane] = p2;
+        if (KT == SV_PERIODIC) red[(24 + jj) * 65 + lane] = p3;
+      }
     }
     __syncthreads();
-    // transposed reduction: 16 vectors x 64 lanes -> lane (v, quarter) sums 16 elements
-    {
-      const int v = lane & 15, qd = lane >> 4;
+    // transposed reduction: lane (v, quarter) sums 16 of the 64 lane-partials of vector v
+#pragma unroll
+    for (int v0 = 0; v0 < NV * 8; v0 += 16) {
+      const int v = v0 + (lane & 15), qd = lane >> 4;
       double s = 0.0;
-      if (FULL || v < 8) {
+      if (v < NV * 8) {
 #pragma unroll
         for (int e = 0; e < 16; ++e) s += red[v * 65 + qd * 16 + e];
       }
       s += __shfl_xor(s, 16, 64);
       s += __shfl_xor(s, 32, 64);
       const int j = jb + (v & 7);
-      if (lane < 16 && j < M) {
-        long long o = (long long)ch * ev.sumM + m.colM + j;
-        if (v < 8)
+      if (lane < 16 && v < NV * 8 && j < M) {
+        const long long o = (long long)ch * ev.sumM + m.colM + j;
+        const int type = v >> 3;
+        if (type == 0)
           ev.P0[o] = s;
-        else if (FULL)
-          ev.P1[o] = s;
+        else if (type == 1)
+          ev.P1[o] = s * w1;
+        else if (type == 2)
+          t0acc = fma(a[j], s, t0acc);
+        else
+          t1acc = fma(a[j], s, t1acc);
       }
     }
     __syncthreads();
   }
 
   if (FULL) {
-    double t0 = 0.0, t1 = 0.0;
-#pragma unroll
-    for (int i = 0; i < SV_SPL; ++i) {
-      t0 = fma(cw[i], T0[i], t0);
-      t1 = fma(cw[i], T1[i], t1);
+    const double t0 = wave_sum(t0acc) * w2;
+    const double t1 = wave_sum(t1acc) * w3;
+    if (lane == 0) {
+      ev.Tpart[((long long)ch * K + k) * 2 + 0] = t0;
+      ev.Tpart[((long long)ch * K + k) * 2 + 1] = t1;
     }
     // spike part of dC[n, k]: per-neuron sums of mu_s
     if (c.split) {
@@ -133,24 +169,17 @@ __device__ void spike_body(const EngineView& ev, const double* __restrict__ C, i
       for (int i = 0; i < SV_SPL; ++i) seg_emit(nid[i], p.s2 * mu[i], ck, cv, out, K, lane);
       if (ck >= 0 && lane == 0) out[(long long)ck * K] = cv;
     }
-    t0 = wave_sum(t0);
-    t1 = wave_sum(t1);
-    if (lane == 0) {
-      ev.Tpart[((long long)ch * K + k) * 2 + 0] = t0;
-      ev.Tpart[((long long)ch * K + k) * 2 + 1] = t1;
-    }
   }
 }
 
-template <bool FULL>
+template <int KT, bool FULL>
 __global__ __launch_bounds__(64) void k_spike(EngineView ev, const double* __restrict__ C) {
-  __shared__ double red[16 * 65];
+  constexpr int NV = FULL ? (KT == SV_RBF ? 3 : 4) : 1;
+  __shared__ double red[NV * 8 * 65];
   const int item = blockIdx.x;
-  const int ch = item / ev.K, k = item % ev.K;
-  if (ev.meta[k].ktype == SV_RBF)
-    spike_body<SV_RBF, FULL>(ev, C, ch, k, red);
-  else
-    spike_body<SV_PERIODIC, FULL>(ev, C, ch, k, red);
+  const int nk = ev.ntype[KT];
+  const int ch = item / nk, k = ev.klist[KT][item % nk];
+  spike_body<KT, FULL>(ev, C, ch, k, red);
 }
 
 // Mseg[n][k] = sum over all local spikes of neuron n of mu_k(t_s)   (embedding M-step path)

@@ -4,6 +4,7 @@
 
 #include <algorithm>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -37,6 +38,10 @@ struct svgpfa_engine {
   size_t ev_used = 0;
   std::string err;
   int* status_host = nullptr;  // pinned
+  hipStream_t side = nullptr;  // the spike pass runs here, concurrently with the quadrature chain
+  bool overlap = false;        // SVGPFA_OVERLAP=1: spike pass on a side stream (measured slower: both
+                               // kernels fill the chip, so they time-slice instead of co-issuing)
+  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
 };
 
 #define HIPCHK(e, call)                                                                  \
@@ -108,18 +113,36 @@ __global__ __launch_bounds__(64) void k_bwd_entry(EngineView ev, PtrTable pt, un
   extern __shared__ double sm[];
   k_bwd_body(ev, pt.p[blockIdx.x % ev.K], mask, sm);
 }
-template <int NT>
+template <int NT, int KT>
 __global__ __launch_bounds__(64) void k_bwd_mfma(EngineView ev, PtrTable pt, unsigned mask) {
   extern __shared__ double sm[];
-  const int k = blockIdx.x % ev.K;
-  if (ev.meta[k].ktype == SV_RBF)
-    bwd_mfma_body<NT, SV_RBF>(ev, pt.p[k], mask, sm);
-  else
-    bwd_mfma_body<NT, SV_PERIODIC>(ev, pt.p[k], mask, sm);
+  const int k = ev.klist[KT][blockIdx.x % ev.ntype[KT]];
+  bwd_mfma_body<NT, KT>(ev, pt.p[k], mask, sm);
 }
+// launch STMT once per covariance type that has latents; KT_ is the compile-time type
+#define FOR_KT(e, ...)                                                        \
+  do {                                                                        \
+    if ((e)->v.ntype[0] > 0) { constexpr int KT_ = SV_RBF; __VA_ARGS__; }      \
+    if ((e)->v.ntype[1] > 0) { constexpr int KT_ = SV_PERIODIC; __VA_ARGS__; } \
+  } while (0)
 static size_t lds_bwd_mfma(int NT) {
   size_t MP = 16 * NT, LD = MP + 2;
   return (4 * MP * LD + 4 * MP) * 8;
+}
+
+// Snapshot Z_k / theta_k of all latents into engine-owned HBM in ONE launch (reference semantics:
+// later evaluations keep using the matrices of the last buildKernelsMatrices() call).
+struct SnapTable {
+  const double* Z[SV_MAX_K];
+  const double* theta[SV_MAX_K];
+};
+__global__ void k_snapshot(EngineView ev, SnapTable st) {
+  const int k = blockIdx.y;
+  const LatentMeta m = ev.meta[k];
+  const long long n = (long long)ev.R * m.M;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
+    ev.Zs[m.offM + i] = st.Z[k][i];
+  if (blockIdx.x == 0 && threadIdx.x < m.nth) ev.theta[2 * k + threadIdx.x] = st.theta[k][threadIdx.x];
 }
 
 template <typename F>
@@ -168,6 +191,11 @@ int svgpfa_create(const svgpfa_dims* d, int device, svgpfa_engine** out) {
     thoff += m.nth;
     e->Mmax = std::max(e->Mmax, m.M);
   }
+  v.ntype[0] = v.ntype[1] = 0;
+  for (int k = 0; k < v.K; ++k) {
+    int t = e->meta[k].ktype;
+    v.klist[t][v.ntype[t]++] = k;
+  }
   e->totM = offM; e->totMM = offMM;
   v.sumM = colM; v.nth_total = thoff;
   v.qtile = std::min(v.Q, 256);
@@ -198,18 +226,26 @@ int svgpfa_create(const svgpfa_dims* d, int device, svgpfa_engine** out) {
   HIPCHK(e, hipMemset(v.gZq, 0, sizeof(double) * e->totM));
   HIPCHK(e, hipMemset(v.gthq, 0, sizeof(double) * v.R * v.K * 2));
   HIPCHK(e, hipHostMalloc((void**)&e->status_host, sizeof(int)));
+  HIPCHK(e, hipStreamCreateWithFlags(&e->side, hipStreamNonBlocking));
+  {
+    const char* ov = getenv("SVGPFA_OVERLAP");
+    e->overlap = (ov && ov[0] == '1');
+  }
+  HIPCHK(e, hipEventCreateWithFlags(&e->ev_fork, hipEventDisableTiming));
+  HIPCHK(e, hipEventCreateWithFlags(&e->ev_join, hipEventDisableTiming));
 
   int rc;
   if ((rc = allow_lds(e, k_build, lds_build(e->Mmax)))) return rc;
   if ((rc = allow_lds(e, k_prep_entry, lds_prep(e->Mmax)))) return rc;
   if ((rc = allow_lds(e, k_bwd_entry, lds_bwd(e->Mmax)))) return rc;
-  DISPATCH_NT(e->NT, rc = allow_lds(e, k_bwd_mfma<NT_>, lds_bwd_mfma(NT_)));
+  rc = 0;
+  DISPATCH_NT(e->NT, FOR_KT(e, if (!rc) rc = allow_lds(e, (k_bwd_mfma<NT_, KT_>), lds_bwd_mfma(NT_))));
   if (rc) return rc;
-  DISPATCH_NT(e->NT, rc = allow_lds(e, k_times_fwd_mfma<NT_>, lds_times_mfma(NT_)));
+  DISPATCH_NT(e->NT, FOR_KT(e, if (!rc) rc = allow_lds(e, (k_times_fwd_mfma<NT_, KT_>), lds_times_mfma(NT_))));
   if (rc) return rc;
-  DISPATCH_NT(e->NT, rc = allow_lds(e, (k_quad_bwd_mfma<NT_, true>), lds_qbwd_mfma(NT_)));
+  DISPATCH_NT(e->NT, FOR_KT(e, if (!rc) rc = allow_lds(e, (k_quad_bwd_mfma<NT_, KT_, true>), lds_qbwd_mfma(NT_))));
   if (rc) return rc;
-  DISPATCH_NT(e->NT, rc = allow_lds(e, (k_quad_bwd_mfma<NT_, false>), lds_qbwd_mfma(NT_)));
+  DISPATCH_NT(e->NT, FOR_KT(e, if (!rc) rc = allow_lds(e, (k_quad_bwd_mfma<NT_, KT_, false>), lds_qbwd_mfma(NT_))));
   if (rc) return rc;
   size_t lq = lds_qell(e);
   switch (e->KT) {
@@ -228,6 +264,9 @@ void svgpfa_destroy(svgpfa_engine* e) {
   (void)hipDeviceSynchronize();
   for (void* p : e->allocs) (void)hipFree(p);
   if (e->status_host) (void)hipHostFree(e->status_host);
+  if (e->side) (void)hipStreamDestroy(e->side);
+  if (e->ev_fork) (void)hipEventDestroy(e->ev_fork);
+  if (e->ev_join) (void)hipEventDestroy(e->ev_join);
   for (auto& pr : e->ev_pool) {
     (void)hipEventDestroy(pr.first);
     (void)hipEventDestroy(pr.second);
@@ -367,11 +406,16 @@ int svgpfa_set_spikes(svgpfa_engine* e, const int64_t* off, const double* times,
 int svgpfa_build_kernels(svgpfa_engine* e, const double* const* Z, const double* const* theta) {
   if (!e || !Z || !theta) return SVGPFA_ERR_INVALID;
   EngineView& v = e->v;
+  SnapTable st;
+  memset(&st, 0, sizeof st);
   for (int k = 0; k < v.K; ++k) {
     if (!Z[k] || !theta[k]) FAIL(e, SVGPFA_ERR_INVALID, "NULL Z / theta pointer");
-    const LatentMeta& m = e->meta[k];
-    HIPCHK(e, hipMemcpyAsync(v.Zs + m.offM, Z[k], sizeof(double) * v.R * m.M, hipMemcpyDeviceToDevice, e->stream));
-    HIPCHK(e, hipMemcpyAsync(v.theta + 2 * k, theta[k], sizeof(double) * m.nth, hipMemcpyDeviceToDevice, e->stream));
+    st.Z[k] = Z[k];
+    st.theta[k] = theta[k];
+  }
+  {
+    int gx = std::max(1, std::min(64, (v.R * e->Mmax + 255) / 256));
+    hipLaunchKernelGGL(k_snapshot, dim3(gx, v.K), dim3(256), 0, e->stream, v, st);
   }
   hipLaunchKernelGGL(k_build, dim3(v.R * v.K), dim3(64), lds_build(e->Mmax), e->stream, v);
   HIPCHK(e, hipGetLastError());
@@ -424,8 +468,9 @@ static int launch_quad_ell(svgpfa_engine* e, const double* C, const double* d, i
 static int launch_times(svgpfa_engine* e, const double* times, const long long* toff, int nper, double* mu,
                         double* var, long long os_t, long long os_k, int want_var) {
   EngineView& v = e->v;
-  DISPATCH_NT(e->NT, hipLaunchKernelGGL(k_times_fwd_mfma<NT_>, dim3(v.R * v.K), dim3(256), lds_times_mfma(NT_),
-                                        e->stream, v, times, toff, nper, mu, var, os_t, os_k, want_var));
+  DISPATCH_NT(e->NT, FOR_KT(e, hipLaunchKernelGGL((k_times_fwd_mfma<NT_, KT_>), dim3(v.R * v.ntype[KT_]), dim3(256),
+                                                  lds_times_mfma(NT_), e->stream, v, times, toff, nper, mu, var,
+                                                  os_t, os_k, want_var)));
   HIPCHK(e, hipGetLastError());
   return SVGPFA_OK;
 }
@@ -451,16 +496,14 @@ int svgpfa_elbo(svgpfa_engine* e, const double* const* mean, const double* const
   const bool full = (mask & (2u | 4u | 8u)) != 0;
 
   hipLaunchKernelGGL(k_prep_entry, dim3(RK), dim3(64), lds_prep(e->Mmax), e->stream, v, pt);
-  if ((rc = launch_times(e, v.tq, nullptr, v.Q, v.muq, v.varq, (long long)v.K, 1LL, 1))) return rc;
-  if ((rc = launch_quad_ell(e, C, d, (mask & 2u) ? 1 : 0, want_lat ? 1 : 0))) return rc;
-  if (want_lat) {
-    if (mask & (4u | 8u)) {
-      DISPATCH_NT(e->NT, hipLaunchKernelGGL((k_quad_bwd_mfma<NT_, true>), dim3(RK), dim3(256), lds_qbwd_mfma(NT_), e->stream, v));
-    } else {
-      DISPATCH_NT(e->NT, hipLaunchKernelGGL((k_quad_bwd_mfma<NT_, false>), dim3(RK), dim3(256), lds_qbwd_mfma(NT_), e->stream, v));
-    }
-  }
+  // fork: the spike pass (fp64 VALU bound) needs only a = Kzz^-1 m from k_prep; it runs on the side
+  // stream while the quadrature chain (f64 MFMA) runs on the main stream; k_bwd joins both.
+  hipStream_t sps = e->overlap ? e->side : e->stream;
   if (v.nchunks > 0) {
+    if (e->overlap) {
+      HIPCHK(e, hipEventRecord(e->ev_fork, e->stream));
+      HIPCHK(e, hipStreamWaitEvent(e->side, e->ev_fork, 0));
+    }
     std::pair<hipEvent_t, hipEvent_t>* evp = nullptr;
     if (e->timing) {
       if (e->ev_used == e->ev_pool.size()) {
@@ -470,15 +513,30 @@ int svgpfa_elbo(svgpfa_engine* e, const double* const* mean, const double* const
         e->ev_pool.push_back(pr);
       }
       evp = &e->ev_pool[e->ev_used++];
-      HIPCHK(e, hipEventRecord(evp->first, e->stream));
+      HIPCHK(e, hipEventRecord(evp->first, sps));
     }
-    if (full)
-      hipLaunchKernelGGL(k_spike<true>, dim3(v.nchunks * v.K), dim3(64), 0, e->stream, v, C);
-    else
-      hipLaunchKernelGGL(k_spike<false>, dim3(v.nchunks * v.K), dim3(64), 0, e->stream, v, C);
-    if (evp) HIPCHK(e, hipEventRecord(evp->second, e->stream));
+    if (full) {
+      FOR_KT(e, hipLaunchKernelGGL((k_spike<KT_, true>), dim3(v.nchunks * v.ntype[KT_]), dim3(64), 0, sps, v, C));
+    } else {
+      FOR_KT(e, hipLaunchKernelGGL((k_spike<KT_, false>), dim3(v.nchunks * v.ntype[KT_]), dim3(64), 0, sps, v, C));
+    }
+    if (evp) HIPCHK(e, hipEventRecord(evp->second, sps));
+    if (e->overlap) HIPCHK(e, hipEventRecord(e->ev_join, e->side));
   }
-  DISPATCH_NT(e->NT, hipLaunchKernelGGL(k_bwd_mfma<NT_>, dim3(RK), dim3(64), lds_bwd_mfma(NT_), e->stream, v, pt, mask));
+  if ((rc = launch_times(e, v.tq, nullptr, v.Q, v.muq, v.varq, (long long)v.K, 1LL, 1))) return rc;
+  if ((rc = launch_quad_ell(e, C, d, (mask & 2u) ? 1 : 0, want_lat ? 1 : 0))) return rc;
+  if (want_lat) {
+    if (mask & (4u | 8u)) {
+      DISPATCH_NT(e->NT, FOR_KT(e, hipLaunchKernelGGL((k_quad_bwd_mfma<NT_, KT_, true>), dim3(v.R * v.ntype[KT_]),
+                                                      dim3(256), lds_qbwd_mfma(NT_), e->stream, v)));
+    } else {
+      DISPATCH_NT(e->NT, FOR_KT(e, hipLaunchKernelGGL((k_quad_bwd_mfma<NT_, KT_, false>), dim3(v.R * v.ntype[KT_]),
+                                                      dim3(256), lds_qbwd_mfma(NT_), e->stream, v)));
+    }
+  }
+  if (v.nchunks > 0 && e->overlap) HIPCHK(e, hipStreamWaitEvent(e->stream, e->ev_join, 0));
+  DISPATCH_NT(e->NT, FOR_KT(e, hipLaunchKernelGGL((k_bwd_mfma<NT_, KT_>), dim3(v.R * v.ntype[KT_]), dim3(64),
+                                                  lds_bwd_mfma(NT_), e->stream, v, pt, mask)));
   int nfin = (v.N * v.K + 31) / 32 + (v.N + 31) / 32 + (v.nth_total + 31) / 32 + 1;
   hipLaunchKernelGGL(k_finalize, dim3(nfin), dim3(256), 0, e->stream, v, d, mask, shared);
   HIPCHK(e, hipGetLastError());
