@@ -1,0 +1,159 @@
+"""Expectation-conditional-maximisation driver with the reference's interface and step semantics
+(/root/reference/src/svGPFA/stats/svEM.py:76-294): per step ONE torch.optim.LBFGS.step over one parameter
+group, closures that negate model.eval() (kernels / inducing-point steps rebuild the kernel matrices
+first; the embedding step freezes the latent statistics and optimises the ELL only), histories and
+TerminationInfo returned in the same tuple.  The reference's own SVEM_PyTorch also drives the engine-backed
+model unchanged; this mirror exists because the reference's source cannot travel to the GPU box.
+
+Left out on purpose: the lock-file streaming for the legacy GUI."""
+import copy
+import io
+import math
+import pickle
+import sys
+import time
+import traceback
+
+import torch
+
+
+class TerminationInfo:
+    def __init__(self, message):
+        self._message = message
+
+    @property
+    def message(self):
+        return self._message
+
+
+class ErrorTerminationInfo(TerminationInfo):
+    def __init__(self, message, error, stack_trace):
+        super().__init__(message=message)
+        self._error = error
+        self._stack_trace = stack_trace
+
+    @property
+    def error(self):
+        return self._error
+
+    @property
+    def stack_trace(self):
+        return self._stack_trace
+
+
+_STEPS = {"ecm": ["estep", "mstep_embedding", "mstep_kernels", "mstep_indpointslocs"],
+          "mecm": ["estep", "mstep_embedding", "estep", "mstep_kernels", "estep", "mstep_indpointslocs"]}
+
+
+class SVEM_PyTorch:
+
+    def maximize(self, model, optim_params, method="ECM", getIterationModelParamsFn=None,
+                 printIterationModelParams=True, verbose=True, out=sys.stdout, savePartial=False,
+                 savePartialFilenamePattern="results/00000000_{:s}_estimatedModel.pickle", **_ignored):
+        if method.lower() not in _STEPS:
+            raise ValueError("Invalid method={:s}. Supported values are ECM and mECM".format(method))
+        steps = _STEPS[method.lower()]
+        run = {"estep": self._eStep, "mstep_embedding": self._mStepEmbedding,
+               "mstep_kernels": self._mStepKernels, "mstep_indpointslocs": self._mStepIndPointsLocs}
+
+        def save(tag):
+            if savePartial:
+                with open(savePartialFilenamePattern.format(tag), "wb") as f:
+                    pickle.dump({"model": model}, f)
+
+        save("initial")
+        lowerBoundHist = [model.eval().item()]
+        elapsedTimeHist = [0.0]
+        start = time.time()
+        log = io.StringIO()
+        iterationsModelParams = None
+        if getIterationModelParamsFn is not None:
+            iterationsModelParams = [None] * (optim_params["em_max_iter"] + 1)
+            iterationsModelParams[0] = getIterationModelParamsFn(model=model)
+            if printIterationModelParams:
+                print(iterationsModelParams[0])
+        maxRes = {"lowerBound": -math.inf}
+        for it in range(1, optim_params["em_max_iter"] + 1):
+            for step in steps:
+                if not optim_params["{:s}_estimate".format(step)]:
+                    continue
+                msg = "Iteration {:02d}, {:s} start: {:f}\n".format(it, step, float(maxRes["lowerBound"]))
+                log.write(msg)
+                if verbose:
+                    out.write(msg)
+                try:
+                    maxRes = run[step](model=model, optim_params=optim_params["{:s}_optim_params".format(step)])
+                except Exception as e:                      # svEM.py:150-163: report and hand back partial histories
+                    trace = traceback.format_exc()
+                    print(e)
+                    print(trace)
+                    info = ErrorTerminationInfo(
+                        message=f"Error occured while processing {step} in iteration {it}", error=e, stack_trace=trace)
+                    return lowerBoundHist, elapsedTimeHist, info, iterationsModelParams
+                msg = "Iteration {:02d}, {:s} end: {:f}, niter: {:d}, nfeval: {:d}\n".format(
+                    it, step, float(maxRes["lowerBound"]), maxRes["niter"], maxRes["nfeval"])
+                log.write(msg)
+                if verbose:
+                    out.write(msg)
+                save("{:s}{:03d}".format(step, it))
+                if getIterationModelParamsFn is not None:
+                    iterationsModelParams[it] = getIterationModelParamsFn(model=model)
+                    if printIterationModelParams:
+                        print(iterationsModelParams[it])
+            elapsedTimeHist.append(time.time() - start)
+            lowerBoundHist.append(maxRes["lowerBound"].item())
+        info = TerminationInfo("Maximum number of iterations ({:d}) reached".format(optim_params["em_max_iter"]))
+        return lowerBoundHist, elapsedTimeHist, info, iterationsModelParams
+
+    # ---- the four conditional maximisations (svEM.py:218-264)
+    def _eStep(self, model, optim_params):
+        x = model.getSVPosteriorOnIndPointsParams()
+        return self._lbfgs_step(x, model.eval, optim_params)
+
+    def _mStepEmbedding(self, model, optim_params):
+        x = model.getSVEmbeddingParams()
+        stats = model.computeSVPosteriorOnLatentsStats()
+        return self._lbfgs_step(
+            x, lambda: model.evalELLSumAcrossTrialsAndNeurons(svPosteriorOnLatentsStats=stats), optim_params)
+
+    def _mStepKernels(self, model, optim_params):
+        x = model.getKernelsParams()
+        previous = [copy.deepcopy(t) for t in x]
+
+        def evalFunc():
+            model.buildKernelsMatrices()
+            return model.eval()
+        try:
+            return self._lbfgs_step(x, evalFunc, optim_params)
+        except Exception:                                  # svEM.py:246-253: roll the kernel params back
+            for t, p in zip(x, previous):
+                t.requires_grad_(False)
+                t.copy_(p)
+            raise
+
+    def _mStepIndPointsLocs(self, model, optim_params):
+        x = model.getIndPointsLocs()
+
+        def evalFunc():
+            model.buildKernelsMatrices()
+            return model.eval()
+        return self._lbfgs_step(x, evalFunc, optim_params)
+
+    @staticmethod
+    def _lbfgs_step(x, evalFunc, optim_params):
+        optimizer = torch.optim.LBFGS(x, **optim_params)
+        for t in x:
+            t.requires_grad_(True)
+        try:
+            def closure():
+                optimizer.zero_grad()
+                loss = -evalFunc()
+                loss.backward()
+                return loss
+            optimizer.step(closure)
+        finally:
+            for t in x:
+                t.requires_grad_(False)
+        lowerBound = evalFunc()
+        state = optimizer.state[optimizer._params[0]]
+        return {"lowerBound": lowerBound, "nfeval": state["func_evals"], "niter": state["n_iter"]}

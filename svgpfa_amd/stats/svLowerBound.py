@@ -1,0 +1,347 @@
+"""SVLowerBound: the reference's model facade (/root/reference/src/svGPFA/stats/svLowerBound.py:5-120)
+over the HIP engine.
+
+What the reference spreads over an object graph (expectedLogLikelihood / klDivergence / svEmbedding /
+svPosteriorOnLatents / svPosteriorOnIndPoints / kernelsMatricesStore) is ONE engine handle here; this
+class keeps the protocol the EM loop relies on (svEM.py:93,106,202,219-263,290):
+
+  * the lists returned by get*Params() hold the very tensor objects the model reads on the next
+    eval(); the optimiser flips their requires_grad and mutates them in place;
+  * eval() returns a 0-dim fp64 tensor whose backward() fills .grad of whichever parameter tensors
+    have requires_grad=True (the engine computes those gradient groups natively, no autograd graph);
+  * buildKernelsMatrices() snapshots Z / kernel params and rebuilds Kzz and its Cholesky factor;
+    a non positive-definite Kzz raises torch.linalg.LinAlgError like utils/miscUtils.py:215 does.
+
+Parameter tensors live on the GPU (fp64, contiguous); setInitialParams moves what it is given.
+"""
+import warnings
+
+import numpy as np
+import torch
+
+from .. import _lib
+from ..engine import Engine, SVGPFAEngineError
+
+
+def _to_dev(t, device, dtype=torch.float64):
+    t = torch.as_tensor(t)
+    return t.detach().to(device=device, dtype=dtype).contiguous()
+
+
+class _ELBOFunction(torch.autograd.Function):
+    """eval() + hand-derived backward of the engine as one autograd node.
+    inputs: K means, K cholVecs, C, d, K kernel-param tensors, K inducing-point tensors."""
+
+    @staticmethod
+    def forward(ctx, model, *params):
+        K = model._K
+        need = ctx.needs_input_grad[1:]
+        mask = 0
+        if any(need[0:2 * K]):
+            mask |= _lib.GRAD_VARIATIONAL
+        if any(need[2 * K:2 * K + 2]):
+            mask |= _lib.GRAD_EMBEDDING
+        if any(need[2 * K + 2:3 * K + 2]):
+            mask |= _lib.GRAD_KERNELS
+        if any(need[3 * K + 2:4 * K + 2]):
+            mask |= _lib.GRAD_INDPOINTS
+        eng = model._engine
+        shared, gm, gc, gz = eng.elbo(model._mean, model._cholVecs, model._C, model._d, mask)
+        model._sync()
+        if model._reduce is not None:      # trials sharded over ranks: ONE all-reduce of the shared vector
+            model._reduce(shared)
+        ctx.mask, ctx.K = mask, K
+        ctx.shapes = [p.shape for p in params]
+        _, _, _, gC, gd, gth = eng.split_shared(shared)
+        ctx.grads = (gm, gc, gC, gd, gth, gz)
+        model._last_terms = (shared[0].clone(), shared[1].clone(), shared[2].clone())
+        return shared[0].clone()
+
+    @staticmethod
+    def backward(ctx, gout):
+        K, mask = ctx.K, ctx.mask
+        gm, gc, gC, gd, gth, gz = ctx.grads
+        need = ctx.needs_input_grad[1:]
+        sh = ctx.shapes
+        out = [None]
+        for i in range(4 * K + 2):
+            g = None
+            if need[i]:
+                if i < K:
+                    g = gm[i]
+                elif i < 2 * K:
+                    g = gc[i - K]
+                elif i == 2 * K:
+                    g = gC
+                elif i == 2 * K + 1:
+                    g = gd
+                elif i < 3 * K + 2:
+                    g = gth[i - 2 * K - 2]
+                else:
+                    g = gz[i - 3 * K - 2]
+                g = (gout * g).reshape(sh[i])
+            out.append(g)
+        return tuple(out)
+
+
+class _ELLGivenStatsFunction(torch.autograd.Function):
+    """ELL with frozen latent stats (the embedding M-step closure, svEM.py:225-232)."""
+
+    @staticmethod
+    def forward(ctx, model, C, d):
+        want = any(ctx.needs_input_grad[1:])
+        out = model._engine.ell_given_stats(C, d, want)
+        model._sync()
+        if model._reduce is not None:
+            model._reduce(out)
+        N, K = model._N, model._K
+        ctx.gC = out[1:1 + N * K].view(N, K)
+        ctx.gd = out[1 + N * K:]
+        ctx.dshape = d.shape
+        return out[0].clone()
+
+    @staticmethod
+    def backward(ctx, gout):
+        gC = gout * ctx.gC if ctx.needs_input_grad[1] else None
+        gd = (gout * ctx.gd).reshape(ctx.dshape) if ctx.needs_input_grad[2] else None
+        return None, gC, gd
+
+
+class SVLowerBound:
+
+    def __init__(self, device=None):
+        if not torch.cuda.is_available():
+            raise RuntimeError("svgpfa_amd.stats.SVLowerBound needs a ROCm GPU; there is no CPU fallback")
+        self._device = torch.device("cuda", torch.cuda.current_device() if device is None else device)
+        self._engine = None
+        self._engine_key = None
+        self._kernels = None
+        self._reg = None
+        self._quad = None
+        self._spikes = None
+        self._stats_token = None
+        self._reduce = None          # optional callable(tensor): in-place sum over ranks (trial sharding)
+        self._last_terms = None
+        self._data_version = 0
+        self._engine_data_version = -1
+
+    # ----------------------------------------------------------------- setters (svLowerBound.py:13-45,83-99)
+    def setParamsAndData(self, measurements, initial_params, eLLCalculationParams, priorCovRegParam):
+        self.setMeasurements(measurements=measurements)
+        self.setInitialParams(initial_params=initial_params)
+        self.setELLCalculationParams(eLLCalculationParams=eLLCalculationParams)
+        self.setPriorCovRegParam(priorCovRegParam=priorCovRegParam)
+        self.buildKernelsMatrices()
+
+    def setKernels(self, kernels):
+        self._kernels = kernels
+        self._K = len(kernels)
+
+    def setMeasurements(self, measurements):
+        """measurements[r][n]: 1-D array-like of spike times.  Vectorised CSR packing in the reference's
+        stacking order (expectedLogLikelihood.py:157-173): neuron-major inside each trial."""
+        R = len(measurements)
+        N = len(measurements[0])
+        times, neuron, offsets = [], [], np.zeros(R + 1, dtype=np.int64)
+        for r in range(R):
+            if len(measurements[r]) != N:
+                raise ValueError("every trial must list the same number of neurons")
+            arrs = [np.asarray(x.detach().cpu() if isinstance(x, torch.Tensor) else x, dtype=np.float64).reshape(-1)
+                    for x in measurements[r]]
+            lens = np.fromiter((a.size for a in arrs), dtype=np.int64, count=N)
+            times.append(np.concatenate(arrs) if N else np.zeros(0))
+            neuron.append(np.repeat(np.arange(N, dtype=np.int32), lens))
+            offsets[r + 1] = offsets[r] + int(lens.sum())
+        self._R_data, self._N = R, N
+        self._spikes = (offsets, np.concatenate(times) if R else np.zeros(0),
+                        np.concatenate(neuron) if R else np.zeros(0, dtype=np.int32))
+        self._data_version += 1
+
+    def setInitialParams(self, initial_params):
+        qU = initial_params["posterior_on_latents"]["posterior_on_ind_points"]
+        kms = initial_params["posterior_on_latents"]["kernels_matrices_store"]
+        emb = initial_params["embedding"]
+        dev = self._device
+        self._mean = [_to_dev(t, dev) for t in qU["mean"]]
+        self._cholVecs = [_to_dev(t, dev) for t in qU["cholVecs"]]
+        self._Z = [_to_dev(t, dev) for t in kms["inducing_points_locs0"]]
+        theta = [_to_dev(t, dev) for t in kms["kernels_params0"]]
+        for k, kern in enumerate(self._kernels):
+            kern.setParams(theta[k])
+        self._C = _to_dev(emb["C0"], dev)
+        self._d = _to_dev(emb["d0"], dev)
+
+    def setELLCalculationParams(self, eLLCalculationParams):
+        self._quad = (_to_dev(eLLCalculationParams["leg_quad_points"], self._device),
+                      _to_dev(eLLCalculationParams["leg_quad_weights"], self._device))
+        self._data_version += 1
+
+    def setPriorCovRegParam(self, priorCovRegParam):
+        self._reg = float(priorCovRegParam)
+        if self._engine is not None:
+            self._engine.set_reg(self._reg)
+
+    def setIndPointsLocs(self, locs):
+        self._Z = [_to_dev(t, self._device) for t in locs]
+
+    # ----------------------------------------------------------------- getters (svLowerBound.py:101-120)
+    def getSVPosteriorOnIndPointsParams(self):
+        return list(self._mean) + list(self._cholVecs)          # svPosteriorOnIndPoints.py:37-42
+
+    def getSVEmbeddingParams(self):
+        return [self._C, self._d]
+
+    def getKernels(self):
+        return self._kernels
+
+    def getKernelsParams(self):
+        return [k.getParams() for k in self._kernels]
+
+    def getIndPointsLocs(self):
+        return self._Z
+
+    # ------------------------------------------------------------------------------ engine
+    def _theta(self):
+        return [k.getParams() for k in self._kernels]
+
+    def _ensure_engine(self):
+        if self._kernels is None or self._quad is None or self._spikes is None or self._reg is None:
+            raise RuntimeError("kernels, measurements, initial params, quadrature and the regularisation "
+                               "parameter must be set before building kernel matrices")
+        R = self._Z[0].shape[0]
+        Ms = tuple(int(z.shape[1]) for z in self._Z)
+        Q = int(self._quad[0].shape[1])
+        key = (R, self._N, Q, Ms, tuple(k._engine_type for k in self._kernels),
+               tuple(float(k._scale) for k in self._kernels),
+               tuple(float(k._lengthscaleScale) for k in self._kernels),
+               tuple(float(getattr(k, "_periodScale", 1.0)) for k in self._kernels), self._data_version)
+        if self._engine is not None and key == self._engine_key:
+            return
+        if self._R_data != R or self._quad[0].shape[0] != R:
+            raise ValueError("number of trials differs between measurements, quadrature and parameters")
+        if self._engine is not None:
+            self._engine.close()
+        eng = Engine(R, self._N, Q, Ms, key[4], key[5], key[6], key[7], device=self._device.index)
+        eng.set_reg(self._reg)
+        eng.set_quad(self._quad[0], self._quad[1])
+        off, t, n = self._spikes
+        dev = self._device
+        eng.set_spikes(off, torch.from_numpy(t).to(dev), torch.from_numpy(n).to(dev))
+        self._engine, self._engine_key = eng, key
+        self._stats_token = None
+
+    def _sync(self):
+        try:
+            self._engine.sync()
+        except SVGPFAEngineError as e:
+            if e.code == _lib.ERR_NOT_PD:
+                # the reference raises from torch.linalg.cholesky (utils/miscUtils.py:215)
+                raise torch.linalg.LinAlgError("linalg.cholesky: " + str(e)) from None
+            raise
+
+    def _check_live(self, tensors, what):
+        for t in tensors:
+            if not (t.is_cuda and t.dtype == torch.float64 and t.is_contiguous()):
+                raise ValueError(f"{what} tensors must stay contiguous fp64 tensors on {self._device}")
+
+    # ------------------------------------------------------------------------------ compute
+    def buildKernelsMatrices(self):
+        """svLowerBound.py:77-78: Kzz + eps I, its Cholesky (raises LinAlgError if not PD).  Ktz blocks are
+        recomputed on the fly by the engine from this snapshot of Z and the kernel parameters."""
+        self._ensure_engine()
+        theta = self._theta()
+        self._check_live(self._Z + theta, "inducing point / kernel parameter")
+        self._engine.build_kernels(self._Z, theta)
+        self._sync()
+        self._stats_token = None
+
+    def eval(self):
+        """svLowerBound.py:47-54."""
+        if self._engine is None:
+            self.buildKernelsMatrices()
+        self._check_live(self._mean + self._cholVecs + [self._C, self._d], "variational / embedding")
+        theEval = _ELBOFunction.apply(self, *self._mean, *self._cholVecs, self._C, self._d,
+                                      *self._theta(), *self._Z)
+        if torch.isinf(theEval):
+            warnings.warn("infinity lower bound detected")
+        return theEval
+
+    def computeSVPosteriorOnLatentsStats(self):
+        """svLowerBound.py:80-81.  Returns the reference's dict layout; the engine keeps the same numbers
+        resident for evalELLSumAcrossTrialsAndNeurons."""
+        if self._engine is None:
+            self.buildKernelsMatrices()
+        muq, varq, mus, vars_ = self._engine.latent_stats(self._mean, self._cholVecs)
+        self._sync()
+        off = self._spikes[0]
+        R = len(off) - 1
+        stats = {"allTimes": (muq, varq),
+                 "assocTimes": ([mus[off[r]:off[r + 1]] for r in range(R)],
+                                [vars_[off[r]:off[r + 1]] for r in range(R)])}
+        self._stats_token = stats
+        return stats
+
+    def evalELLSumAcrossTrialsAndNeurons(self, svPosteriorOnLatentsStats=None):
+        """svLowerBound.py:72-75 -> expectedLogLikelihood.py:107-135."""
+        if svPosteriorOnLatentsStats is None:
+            self.computeSVPosteriorOnLatentsStats()
+        elif svPosteriorOnLatentsStats is not self._stats_token:
+            raise NotImplementedError("svPosteriorOnLatentsStats must be the object returned by the latest "
+                                      "computeSVPosteriorOnLatentsStats() call (the stats stay resident in HBM)")
+        return _ELLGivenStatsFunction.apply(self, self._C, self._d)
+
+    def predictLatents(self, times):
+        """svPosteriorOnLatents.py:57-77: times n_trials x n_times x 1 -> (means, vars) n_trials x n_times x K."""
+        if self._engine is None:
+            self.buildKernelsMatrices()
+        t = _to_dev(times, self._device)
+        mu, var = self._engine.predict(self._mean, self._cholVecs, t.reshape(t.shape[0], -1).contiguous())
+        self._sync()
+        self._stats_token = None
+        return mu, var
+
+    def predictEmbedding(self, times):
+        """svEmbedding.py:80-92."""
+        mu, var = self.predictLatents(times)
+        Ct = self._C.detach().T
+        return torch.matmul(mu, Ct) + self._d.detach().reshape(1, 1, -1), torch.matmul(var, Ct ** 2)
+
+    def computeEmbeddingMeansAndVarsAtTimes(self, times):
+        return self.predictEmbedding(times)
+
+    def computeExpectedPosteriorCIFs(self, times):
+        """expectedLogLikelihood.py:62-73: list[R][N] of exp(mean + var / 2) on the grid."""
+        eMean, eVar = self.predictEmbedding(times)
+        cif = torch.exp(eMean + 0.5 * eVar)
+        return [[cif[r, :, n] for n in range(cif.shape[2])] for r in range(cif.shape[0])]
+
+    def sampleCIFs(self, times, nudget=1e-3):
+        raise NotImplementedError("sampleCIFs (GP sampling for plots, svPosteriorOnLatents.py:123-183) is outside "
+                                  "the accelerated ELBO path (SURVEY.md section 2, row 4)")
+
+    # engine-backed KernelsMatricesStore getters (kernelsMatricesStore.py:119-120,176-181)
+    def getKzz(self):
+        return [self._engine.get_kzz(k) for k in range(self._K)]
+
+    def getKzzChol(self):
+        return [self._engine.get_kzz_chol(k) for k in range(self._K)]
+
+    def getKtzAllTimes(self):
+        return [self._engine.get_ktz_quad(k) for k in range(self._K)]
+
+    def lastTerms(self):
+        """(ELBO, ELL, KL) of the most recent eval() as 0-dim tensors."""
+        return self._last_terms
+
+    # ------------------------------------------------------------------------------ pickling
+    def __getstate__(self):
+        """svEM.py:89-92,175-181 pickles {"model": model}: drop the native handle, keep tensors and data."""
+        st = dict(self.__dict__)
+        st["_engine"] = None
+        st["_engine_key"] = None
+        st["_stats_token"] = None
+        st["_reduce"] = None
+        return st
+
+    def __setstate__(self, st):
+        self.__dict__.update(st)

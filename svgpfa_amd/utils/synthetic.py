@@ -39,7 +39,7 @@ def tril_vec(L):
     """Row-major lower-triangle vectorisation (torch.tril_indices order)."""
     M = L.shape[-1]
     i, j = np.tril_indices(M)
-    return L[..., i, j]
+    return np.ascontiguousarray(L[..., i, j])
 
 
 def make_problem(R, N, K, M, kernels="rbf", seed=0, n_quad=200, rate=20.0, reg=1e-3,

@@ -23,6 +23,12 @@ What is written (all float64 numpy arrays, inputs AND reference outputs):
                       scalars + full gradients.
   estep_embedding.npz - embedding M-step closure (ELL with frozen latent stats) on the
                       ragged case.
+  em_small.npz      - the reference's own SVEM_PyTorch.maximize (ECM, 2 iterations) on a small
+                      seeded problem: lowerBoundHist and final shared parameters.
+  cfg1_bundled.npz  - BASELINE config 1: the bundled simulated data
+                      (examples/data/32451751_simRes.pickle: spike times only, as CSR) with the
+                      parameters of examples/params/00000545_estimation_metaData.ini, and the
+                      lowerBoundHist of the reference's EM loop for em_max_iter = 2.
 """
 import os
 import sys
@@ -83,7 +89,7 @@ def ref_model_from_problem(prob):
         else:
             kernels.append(svGPFA.stats.kernels.PeriodicKernel(
                 scale=scales[k], lengthscaleScale=lss[k], periodScale=pss[k]))
-    t = lambda a: torch.from_numpy(np.array(a, dtype=np.float64, copy=True))
+    t = lambda a: torch.from_numpy(np.array(a, dtype=np.float64, copy=True, order="C"))
     params = dict(
         mean=[t(a).unsqueeze(-1) for a in prob["mean"]],
         cholVecs=[t(a).unsqueeze(-1) for a in prob["cholVecs"]],
@@ -293,5 +299,77 @@ def main():
                         C_sum=prob["C"].sum(), **out)
 
 
+LBFGS = dict(max_iter=20, lr=1.0, tolerance_grad=1e-7, tolerance_change=1e-9, line_search_fn="strong_wolfe")
+
+
+def optim_params(em_max_iter):
+    op = {"em_max_iter": em_max_iter}
+    for step in ("estep", "mstep_embedding", "mstep_kernels", "mstep_indpointslocs"):
+        op[f"{step}_estimate"] = True
+        op[f"{step}_optim_params"] = dict(LBFGS)
+    return op
+
+
+def run_reference_em(prob, em_max_iter):
+    import io
+    import svGPFA.stats.svEM
+    model, params = ref_model_from_problem(prob)
+    hist, _, info, _ = svGPFA.stats.svEM.SVEM_PyTorch().maximize(
+        model=model, optim_params=optim_params(em_max_iter), method="ECM", out=io.StringIO())
+    assert not hasattr(info, "_error"), info.message
+    return hist, params
+
+
+def em_small():
+    prob = synthetic.make_problem(R=3, N=8, K=2, M=[5, 6], kernels="mix", seed=123, n_quad=40, rate=12.0,
+                                  reg=1e-3, jitter=1.0)
+    hist, params = run_reference_em(prob, 2)
+    print("em_small lowerBoundHist", hist)
+    np.savez_compressed(os.path.join(HERE, "em_small.npz"), **problem_inputs(prob), lowerBoundHist=np.array(hist),
+                        final_C=params["C"].detach().numpy(), final_d=params["d"].detach().numpy(),
+                        final_theta0=params["theta"][0].detach().numpy(),
+                        final_theta1=params["theta"][1].detach().numpy())
+
+
+def cfg1_bundled():
+    import pickle
+    with open("/root/reference/examples/data/32451751_simRes.pickle", "rb") as f:
+        sim = pickle.load(f)
+    spikes = sim["spikes"]
+    R, N = len(spikes), len(spikes[0])
+    times, neuron, off = [], [], [0]
+    for r in range(R):
+        for n in range(N):
+            sp = np.asarray(spikes[r][n], dtype=np.float64).reshape(-1)   # float32 values, exact in float64
+            times.append(sp)
+            neuron.append(np.full(sp.shape, n, dtype=np.int32))
+        off.append(sum(len(x) for x in times))
+    pdir = "/root/reference/examples/params/"
+    m0 = np.loadtxt(pdir + "uniform_0.00_1.00_len09.csv", delimiter=",").reshape(-1)
+    S0 = np.loadtxt(pdir + "identity_scaled1e-2_09x09.csv", delimiter=",")
+    C0 = np.loadtxt(pdir + "C_constant_1.00constant_100neurons_02latents.csv", delimiter=",").reshape(N, 2)
+    d0 = np.loadtxt(pdir + "d_constant_0.00constant_100neurons.csv", delimiter=",").reshape(-1)
+    K, M, Q = 2, 9, 200
+    L0 = np.linalg.cholesky(S0)
+    pts, wts = synthetic.leg_quad(Q, np.zeros(R), np.ones(R))
+    prob = dict(R=R, N=N, K=K, Ms=[M, M], Q=Q, kernel_types=[synthetic.RBF, synthetic.RBF], reg=1e-3,
+                spike_offsets=np.array(off, dtype=np.int64), spike_times=np.concatenate(times),
+                spike_neuron=np.concatenate(neuron), quad_points=pts, quad_weights=wts,
+                Z=[np.tile(np.linspace(0.0, 1.0, M)[None, :], (R, 1)) for _ in range(K)],
+                mean=[np.tile(m0[None, :], (R, 1)) for _ in range(K)],
+                cholVecs=[np.tile(synthetic.tril_vec(L0)[None, :], (R, 1)) for _ in range(K)],
+                theta=[np.array([2.0]), np.array([1.0])], C=C0.copy(), d=d0.copy())
+    hist, params = run_reference_em(prob, 2)
+    print("cfg1 lowerBoundHist", hist)
+    np.savez_compressed(os.path.join(HERE, "cfg1_bundled.npz"), **problem_inputs(prob),
+                        lowerBoundHist=np.array(hist))
+
+
 if __name__ == "__main__":
-    main()
+    if len(sys.argv) > 1 and sys.argv[1] == "em":
+        em_small()
+        cfg1_bundled()
+    else:
+        main()
+        em_small()
+        cfg1_bundled()

@@ -1,0 +1,219 @@
+"""GPU tests of the reference-API mirror (svgpfa_amd.stats): same call sequences as the reference's own
+tests (stats/tests/test_svLowerBound.py, test_kernelsMatricesStore.py, test_svEM.py), expected values from
+the golden vectors produced by running the reference (tests/golden/make_golden.py)."""
+import io
+import pickle
+
+import numpy as np
+import pytest
+import torch
+
+from helpers import load_golden, rel_err
+from svgpfa_amd.utils import synthetic
+
+pytestmark = pytest.mark.gpu
+
+
+def _kernels(prob):
+    from svgpfa_amd.stats import kernels
+    out = []
+    for k in range(prob["K"]):
+        sc = prob.get("scales", [1.0] * prob["K"])[k]
+        ls = prob.get("lengthscale_scales", [1.0] * prob["K"])[k]
+        ps = prob.get("period_scales", [1.0] * prob["K"])[k]
+        if prob["kernel_types"][k] == synthetic.RBF:
+            out.append(kernels.ExponentialQuadraticKernel(scale=sc, lengthscaleScale=ls))
+        else:
+            out.append(kernels.PeriodicKernel(scale=sc, lengthscaleScale=ls, periodScale=ps))
+    return out
+
+
+def _model(prob):
+    """Build the model exactly as a reference caller would (CPU tensors in, nested spike lists)."""
+    from svgpfa_amd.stats.svGPFAModelFactory import SVGPFAModelFactory
+    t = lambda a: torch.from_numpy(np.array(a, dtype=np.float64, copy=True, order="C"))
+    off, times, neuron = prob["spike_offsets"], prob["spike_times"], prob["spike_neuron"]
+    measurements = []
+    for r in range(prob["R"]):
+        tt, nn = times[off[r]:off[r + 1]], neuron[off[r]:off[r + 1]]
+        measurements.append([t(tt[nn == n]) for n in range(prob["N"])])
+    initial_params = {
+        "posterior_on_latents": {
+            "posterior_on_ind_points": {"mean": [t(a).unsqueeze(-1) for a in prob["mean"]],
+                                        "cholVecs": [t(a).unsqueeze(-1) for a in prob["cholVecs"]]},
+            "kernels_matrices_store": {"kernels_params0": [t(a) for a in prob["theta"]],
+                                       "inducing_points_locs0": [t(a).unsqueeze(-1) for a in prob["Z"]]}},
+        "embedding": {"C0": t(prob["C"]), "d0": t(prob["d"])}}
+    ell = {"leg_quad_points": t(prob["quad_points"]).unsqueeze(-1),
+           "leg_quad_weights": t(prob["quad_weights"]).unsqueeze(-1)}
+    model = SVGPFAModelFactory.buildModelPyTorch(kernels=_kernels(prob))
+    model.setParamsAndData(measurements=measurements, initial_params=initial_params,
+                           eLLCalculationParams=ell, priorCovRegParam=prob["reg"])
+    return model
+
+
+def test_eval_pointProcess():
+    """stats/tests/test_svLowerBound.py:18-106: |lbEval + obj| < 3e-4 on the MATLAB fixture."""
+    prob, ref = load_golden("matlab_estep")
+    model = _model(prob)
+    lbEval = model.eval()
+    assert abs(float(lbEval) + float(ref["matlab_obj"])) < 3e-4
+    assert abs(float(lbEval) - float(ref["ref_elbo"])) < 1e-9 * abs(float(ref["ref_elbo"]))
+    elbo, ell, kl = model.lastTerms()
+    assert abs(float(ell) - (-5499.83650875)) < 3e-4      # test_expectedLogLikelihood.py:104
+    assert abs(float(kl) - 537.65708147) < 1e-5           # test_klDivergence.py:62
+
+
+@pytest.mark.parametrize("group", ["estep", "embedding", "kernels", "indpoints"])
+def test_backward_fills_grad_of_live_tensors(group):
+    """svEM.py:266-288: requires_grad on one group, closure, backward -> .grad of the very tensors returned
+    by the getters; compared with the reference's autograd gradients."""
+    prob, ref = load_golden("ragged_small")
+    model = _model(prob)
+    K = prob["K"]
+    x = {"estep": model.getSVPosteriorOnIndPointsParams, "embedding": model.getSVEmbeddingParams,
+         "kernels": model.getKernelsParams, "indpoints": model.getIndPointsLocs}[group]()
+    for t in x:
+        t.requires_grad_(True)
+    if group in ("kernels", "indpoints"):
+        model.buildKernelsMatrices()
+    loss = -model.eval()
+    loss.backward()
+    names = {"estep": [f"g_mean_{k}" for k in range(K)] + [f"g_cholVecs_{k}" for k in range(K)],
+             "embedding": ["g_C", "g_d"], "kernels": [f"g_theta_{k}" for k in range(K)],
+             "indpoints": [f"g_Z_{k}" for k in range(K)]}[group]
+    for t, nme in zip(x, names):
+        assert t.grad is not None and t.grad.shape == t.shape
+        got = -t.grad.cpu().numpy().reshape(ref[nme].shape)
+        assert rel_err(got, ref[nme]) < 1e-9, (nme, rel_err(got, ref[nme]))
+    others = [p for p in (model.getSVPosteriorOnIndPointsParams() + model.getSVEmbeddingParams()
+                          + model.getKernelsParams() + model.getIndPointsLocs()) if all(p is not q for q in x)]
+    assert all(p.grad is None for p in others)
+
+
+def test_embedding_mstep_closure():
+    """svEM.py:225-232: frozen latent stats, ELL only."""
+    prob, _ = load_golden("ragged_small")
+    ref = np.load(__import__("os").path.join(__import__("helpers").GOLDEN, "estep_embedding.npz"))
+    model = _model(prob)
+    stats = model.computeSVPosteriorOnLatentsStats()
+    C, d = model.getSVEmbeddingParams()
+    C.requires_grad_(True), d.requires_grad_(True)
+    ell = model.evalELLSumAcrossTrialsAndNeurons(svPosteriorOnLatentsStats=stats)
+    ell.backward()
+    assert abs(float(ell) - float(ref["ref_ell"])) < 1e-10 * max(1.0, abs(float(ref["ref_ell"])))
+    assert rel_err(C.grad.cpu().numpy(), ref["g_C"]) < 1e-9
+    assert rel_err(d.grad.cpu().numpy(), ref["g_d"]) < 1e-9
+    with pytest.raises(NotImplementedError):
+        model.evalELLSumAcrossTrialsAndNeurons(svPosteriorOnLatentsStats={"allTimes": None, "assocTimes": None})
+
+
+def test_kernels_matrices_store_standalone():
+    """stats/tests/test_kernelsMatricesStore.py:12-183: Kzz (+eps), Ktz / KttDiag at quad and spike times."""
+    from svgpfa_amd.stats import kernelsMatricesStore as kms
+    prob, ref = load_golden("matlab_estep")
+    t = lambda a: torch.from_numpy(np.array(a, dtype=np.float64, copy=True, order="C"))
+    Z = [t(a).unsqueeze(-1) for a in prob["Z"]]
+    kernels = _kernels(prob)
+    params0 = {"kernels_params0": [t(a) for a in prob["theta"]], "inducing_points_locs0": Z}
+    s1 = kms.IndPointsLocsKMS_Chol()
+    s1.setKernels(kernels=kernels)
+    s1.setInitialParams(initial_params=params0)
+    s1.setRegParam(reg_param=prob["reg"])
+    s1.buildKernelsMatrices()
+    for k in range(prob["K"]):
+        assert rel_err(s1.getKzz()[k].cpu().numpy(), ref[f"Kzz_{k}"]) < 1e-12
+    # solveForLatent == cholesky_solve with the stored factor (kernelsMatricesStore.py:132-134)
+    m0 = t(prob["mean"][0]).unsqueeze(-1).to(s1.getKzz()[0].device)
+    sol = s1.solveForLatent(input=m0, latentIndex=0)
+    assert rel_err(torch.matmul(s1.getKzz()[0], sol).cpu().numpy(), m0.cpu().numpy()) < 1e-8
+    s2 = kms.IndPointsLocsAndAllTimesKMS()
+    s2.setKernels(kernels=kernels)
+    s2.setInitialParams(initial_params=params0)
+    s2.setTimes(times=t(prob["quad_points"]).unsqueeze(-1))
+    s2.buildKernelsMatrices()
+    for k in range(prob["K"]):
+        assert rel_err(s2.getKtz()[k].cpu().numpy(), ref[f"KtzQuad_{k}"]) < 1e-12
+    assert rel_err(s2.getKttDiag().cpu().numpy(), ref["KttDiagQuad"]) < 1e-15
+    off = prob["spike_offsets"]
+    s3 = kms.IndPointsLocsAndAssocTimesKMS()
+    s3.setKernels(kernels=kernels)
+    s3.setInitialParams(initial_params=params0)
+    s3.setTimes(times=[t(prob["spike_times"][off[r]:off[r + 1]]) for r in range(prob["R"])])
+    s3.buildKernelsMatrices()
+    for k in range(prob["K"]):
+        got = torch.cat(s3.getKtz()[k]).cpu().numpy()
+        assert rel_err(got, ref[f"KtzSpikes_{k}"]) < 1e-12
+
+
+def test_predict_and_cifs(golden_dir):
+    prob, _ = load_golden("ragged_small")
+    pr = np.load(golden_dir + "/ragged_predict.npz")
+    model = _model(prob)
+    times = torch.from_numpy(pr["times"]).unsqueeze(-1)
+    mu, var = model.predictLatents(times=times)
+    assert rel_err(mu.cpu().numpy(), pr["mu"]) < 1e-9 and rel_err(var.cpu().numpy(), pr["var"]) < 1e-9
+    em, evar = model.predictEmbedding(times=times)
+    assert rel_err(em.cpu().numpy(), pr["emb_mean"]) < 1e-9 and rel_err(evar.cpu().numpy(), pr["emb_var"]) < 1e-9
+    cifs = model.computeExpectedPosteriorCIFs(times=times)
+    assert len(cifs) == prob["R"] and len(cifs[0]) == prob["N"]
+    assert rel_err(cifs[1][2].cpu().numpy(), np.exp(pr["emb_mean"][1, :, 2] + 0.5 * pr["emb_var"][1, :, 2])) < 1e-9
+
+
+def _optim_params(em_max_iter):
+    lb = dict(max_iter=20, lr=1.0, tolerance_grad=1e-7, tolerance_change=1e-9, line_search_fn="strong_wolfe")
+    op = {"em_max_iter": em_max_iter}
+    for step in ("estep", "mstep_embedding", "mstep_kernels", "mstep_indpointslocs"):
+        op[f"{step}_estimate"] = True
+        op[f"{step}_optim_params"] = dict(lb)
+    return op
+
+
+def test_em_small_matches_reference_history():
+    """The reference's SVEM_PyTorch.maximize (ECM, 2 iterations) vs the same loop over the HIP model."""
+    from svgpfa_amd.stats.svEM import SVEM_PyTorch, ErrorTerminationInfo
+    prob, ref = load_golden("em_small")
+    model = _model(prob)
+    out = io.StringIO()
+    hist, elapsed, info, _ = SVEM_PyTorch().maximize(model=model, optim_params=_optim_params(2), method="ECM", out=out)
+    assert not isinstance(info, ErrorTerminationInfo), info.message
+    assert len(hist) == 3 and len(elapsed) == 3
+    want = ref["lowerBoundHist"]
+    assert abs(hist[0] - want[0]) < 1e-10 * abs(want[0])
+    # L-BFGS line searches amplify rounding differences: loose tolerance on the iterates
+    assert abs(hist[1] - want[1]) < 1e-6 * abs(want[1]) and abs(hist[2] - want[2]) < 2e-5 * abs(want[2])
+    assert hist[2] > hist[1] > hist[0]
+    assert "Iteration 01, estep start" in out.getvalue() and "nfeval" in out.getvalue()
+    assert rel_err(model.getSVEmbeddingParams()[0].cpu().numpy(), ref["final_C"]) < 1e-4
+
+
+def test_config1_bundled_data_two_em_iterations():
+    """BASELINE config 1: bundled simulated data, ini 545, em_max_iter = 2."""
+    from svgpfa_amd.stats.svEM import SVEM_PyTorch, ErrorTerminationInfo
+    prob, ref = load_golden("cfg1_bundled")
+    model = _model(prob)
+    hist, _, info, _ = SVEM_PyTorch().maximize(model=model, optim_params=_optim_params(2), method="ECM",
+                                               out=io.StringIO())
+    assert not isinstance(info, ErrorTerminationInfo), info.message
+    want = ref["lowerBoundHist"]          # [277018.8745717274, 1003993.0510170484, 1007863.0982122809]
+    assert abs(hist[0] - 277018.8745717274) < 1e-10 * 277018.8745717274
+    assert abs(hist[1] - want[1]) < 1e-6 * abs(want[1])
+    assert abs(hist[2] - want[2]) < 1e-6 * abs(want[2])
+
+
+def test_not_pd_raises_linalg_error_and_em_reports_it():
+    """utils/miscUtils.py:215 raises torch.linalg.LinAlgError; svEM.py:150-163 turns it into ErrorTerminationInfo."""
+    prob = synthetic.make_problem(R=2, N=3, K=1, M=6, kernels="rbf", seed=9, n_quad=16, rate=5.0, reg=0.0)
+    prob["Z"][0][1, 3] = prob["Z"][0][1, 2]
+    with pytest.raises(torch.linalg.LinAlgError):
+        _model(prob)
+
+
+def test_pickle_roundtrip():
+    """svEM.py:89-92 pickles {"model": model}."""
+    prob, ref = load_golden("ragged_small")
+    model = _model(prob)
+    v0 = float(model.eval())
+    model2 = pickle.loads(pickle.dumps({"model": model}))["model"]
+    assert model2._engine is None
+    assert float(model2.eval()) == v0
