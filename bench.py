@@ -84,8 +84,8 @@ def cpu_baseline(config, variant, sample_trials):
         warm[key] = sample[key][:2]
     for key in ("Z", "mean", "cholVecs"):
         warm[key] = [a[:2] for a in sample[key]]
-    orc.elbo_and_grads(synthetic.to_oracle_problem(warm), mask)
-    p = synthetic.to_oracle_problem(sub)
+    orc.elbo_and_grads(orc.from_numpy_problem(warm), mask)
+    p = orc.from_numpy_problem(sub)
     t0 = time.perf_counter()
     orc.elbo_and_grads(p, mask)
     dt = time.perf_counter() - t0
@@ -119,8 +119,10 @@ def main():
         print(f"[bench] note: --gpus {args.gpus} but WORLD_SIZE={world}; using WORLD_SIZE", file=sys.stderr)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    use_dist = world > 1 or "RANK" in os.environ      # launched by torch.distributed.run (also with 1 rank)
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
         dist.init_process_group("nccl", device_id=dev)
 
     full = synthetic.make_config(args.config)
@@ -134,21 +136,21 @@ def main():
         if args.variant == "all":
             eng.build_kernels(P["Z"], P["theta"])
         eng.elbo(P["mean"], P["cholVecs"], P["C"], P["d"], mask, out=shared, grads=grads)
-        if world > 1:
+        if use_dist:
             dist.all_reduce(shared)   # RCCL sum of [ELBO, ELL, KL, dC, dd, dtheta]
 
     for _ in range(args.warmup):
         step()
     eng.sync()
     eng.enable_timing(True)
-    if world > 1:
+    if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
     torch.cuda.synchronize()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     elapsed = time.perf_counter() - t0
     spike_ms, launches = eng.spike_kernel_ms()
@@ -156,7 +158,7 @@ def main():
     eng.sync()
     elbo = float(shared[0])
 
-    if world > 1:
+    if use_dist:
         t = torch.tensor([elapsed, spike_ms / max(launches, 1)], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed, spike_avg_ms = float(t[0]), float(t[1])
@@ -193,7 +195,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.config, args.variant, args.cpu_sample_trials)
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -1,0 +1,23 @@
+"""Trial sharding over the GPUs of one node.
+
+Every per-trial quantity is independent across trials, so each rank owns a contiguous block of trials
+(balanced by spike count, svgpfa_amd.utils.synthetic.shard_trials) and runs its own engine.  The only
+exchange per evaluation is ONE all-reduce (sum) of the engine's `shared` vector
+[ELBO, ELL, KL, dC, dd, dtheta] -- 2 219 doubles at the north-star config, latency bound.
+Gradients of per-trial parameters (means, cholVecs, Z) never leave their owner.
+
+Backend: "nccl" (= RCCL over xGMI on ROCm) for device tensors, "gloo" in the CPU tests."""
+import torch.distributed as dist
+
+
+def allreduce_shared(shared, group=None):
+    """In-place sum of the shared vector over ranks; no-op without an initialised process group."""
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+        dist.all_reduce(shared, op=dist.ReduceOp.SUM, group=group)
+    return shared
+
+
+def attach(model, group=None):
+    """Make an svgpfa_amd.stats SVLowerBound (holding this rank's trials) reduce over `group`."""
+    model._reduce = lambda t: allreduce_shared(t, group)
+    return model

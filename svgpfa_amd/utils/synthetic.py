@@ -143,28 +143,3 @@ def shard_trials(prob, rank, world):
         out[key] = [a[lo:hi] for a in prob[key]]
     out["trial_range"] = (lo, hi)
     return out
-
-
-def to_oracle_problem(prob):
-    """numpy problem -> the dict of torch CPU fp64 tensors oracle/svgpfa_oracle.py expects."""
-    import torch
-    R = prob["R"]
-    off = prob["spike_offsets"]
-    t = torch.from_numpy(np.ascontiguousarray(prob["spike_times"])).double()
-    n = torch.from_numpy(np.ascontiguousarray(prob["spike_neuron"])).long()
-    return dict(
-        kernel_types=list(prob["kernel_types"]), reg=float(prob["reg"]),
-        scales=list(prob.get("scales", [1.0] * prob["K"])),
-        lengthscale_scales=list(prob.get("lengthscale_scales", [1.0] * prob["K"])),
-        period_scales=list(prob.get("period_scales", [1.0] * prob["K"])),
-        mean=[torch.from_numpy(a.copy()).double().unsqueeze(-1) for a in prob["mean"]],
-        cholVecs=[torch.from_numpy(a.copy()).double().unsqueeze(-1) for a in prob["cholVecs"]],
-        Z=[torch.from_numpy(a.copy()).double().unsqueeze(-1) for a in prob["Z"]],
-        theta=[torch.from_numpy(a.copy()).double() for a in prob["theta"]],
-        C=torch.from_numpy(prob["C"].copy()).double(),
-        d=torch.from_numpy(prob["d"].copy()).double(),
-        spike_times=[t[off[r]:off[r + 1]] for r in range(R)],
-        spike_neuron=[n[off[r]:off[r + 1]] for r in range(R)],
-        quad_points=torch.from_numpy(prob["quad_points"].copy()).double().unsqueeze(-1),
-        quad_weights=torch.from_numpy(prob["quad_weights"].copy()).double().unsqueeze(-1),
-    )

@@ -18,7 +18,7 @@ TOL_ARRAY = 1e-9
 def test_matlab_known_answers():
     """stats/tests/test_svLowerBound.py:106, test_expectedLogLikelihood.py:104, test_klDivergence.py:62."""
     prob, ref = load_golden("matlab_estep")
-    elbo, ell, kl = orc.elbo_terms(synthetic.to_oracle_problem(prob))
+    elbo, ell, kl = orc.elbo_terms(orc.from_numpy_problem(prob))
     assert abs(float(elbo) + float(ref["matlab_obj"])) < 3e-4
     assert abs(float(elbo) - (-6037.49359022)) < 3e-4
     assert abs(float(ell) - (-5499.83650875)) < 3e-4
@@ -30,7 +30,7 @@ def test_matlab_known_answers():
 @pytest.mark.parametrize("name", ["matlab_estep", "ragged_small"])
 def test_scalars_and_intermediates(name):
     prob, ref = load_golden(name)
-    p = synthetic.to_oracle_problem(prob)
+    p = orc.from_numpy_problem(prob)
     elbo, ell, kl = orc.elbo_terms(p)
     assert abs(float(elbo) - float(ref["ref_elbo"])) <= TOL_SCALAR * abs(float(ref["ref_elbo"])) + 1e-10
     assert abs(float(ell) - float(ref["ref_ell"])) <= TOL_SCALAR * abs(float(ref["ref_ell"])) + 1e-10
@@ -63,7 +63,7 @@ def test_scalars_and_intermediates(name):
 @pytest.mark.parametrize("name", ["matlab_estep", "ragged_small"])
 def test_gradients(name):
     prob, ref = load_golden(name)
-    out = orc.elbo_and_grads(synthetic.to_oracle_problem(prob), orc.GRAD_ALL)
+    out = orc.elbo_and_grads(orc.from_numpy_problem(prob), orc.GRAD_ALL)
     for k in range(prob["K"]):
         assert rel_err(out["g_mean"][k].numpy()[:, :, 0], ref[f"g_mean_{k}"]) < TOL_ARRAY
         assert rel_err(out["g_cholVecs"][k].numpy()[:, :, 0], ref[f"g_cholVecs_{k}"]) < TOL_ARRAY
@@ -80,7 +80,7 @@ def test_cfg2_seeded_inputs_and_outputs(golden_dir):
     assert int(prob["spike_offsets"][-1]) == int(ref["n_spikes"])
     assert prob["spike_times"].sum() == float(ref["spike_times_sum"])
     assert prob["C"].sum() == float(ref["C_sum"])
-    out = orc.elbo_and_grads(synthetic.to_oracle_problem(prob), orc.GRAD_ALL)
+    out = orc.elbo_and_grads(orc.from_numpy_problem(prob), orc.GRAD_ALL)
     assert abs(float(out["elbo"]) - float(ref["ref_elbo"])) < 1e-10 * abs(float(ref["ref_elbo"]))
     for k in range(prob["K"]):
         assert rel_err(out["g_mean"][k].numpy()[:, :, 0], ref[f"g_mean_{k}"]) < TOL_ARRAY
@@ -94,7 +94,7 @@ def test_cfg2_seeded_inputs_and_outputs(golden_dir):
 def test_embedding_mstep_closure(golden_dir):
     prob, _ = load_golden("ragged_small")
     ref = np.load(golden_dir + "/estep_embedding.npz")
-    p = synthetic.to_oracle_problem(prob)
+    p = orc.from_numpy_problem(prob)
     stats = orc.compute_latents_stats(p)
     ell, gC, gd = orc.ell_given_stats_and_grads(p, stats)
     assert abs(float(ell) - float(ref["ref_ell"])) < 1e-11 * max(1.0, abs(float(ref["ref_ell"])))
@@ -105,7 +105,7 @@ def test_embedding_mstep_closure(golden_dir):
 def test_predict_latents(golden_dir):
     prob, _ = load_golden("ragged_small")
     ref = np.load(golden_dir + "/ragged_predict.npz")
-    p = synthetic.to_oracle_problem(prob)
+    p = orc.from_numpy_problem(prob)
     mu, var = orc.predict_latents(p, torch.from_numpy(ref["times"]).unsqueeze(-1))
     assert rel_err(mu.numpy(), ref["mu"]) < TOL_ARRAY
     assert rel_err(var.numpy(), ref["var"]) < TOL_ARRAY
