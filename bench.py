@@ -76,6 +76,9 @@ def cpu_baseline(config, variant, sample_trials):
     for key in ("Z", "mean", "cholVecs"):
         sub[key] = [a[:ns] for a in sample[key]]
     mask = 15 if variant == "all" else 1
+    # the GPU box exposes every host core, but a 1-GPU job's share is 16 and intra-op threading of these
+    # small fp64 ops does not scale beyond that: use min(16, available)
+    torch.set_num_threads(max(1, min(16, len(os.sched_getaffinity(0)))))
     warm = dict(sub)   # tiny warm-up (2 trials) so that one-off torch initialisation is not timed
     warm["R"] = 2
     warm["spike_offsets"] = off[:3].copy()
@@ -103,7 +106,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--config", default="cfg3", choices=["cfg2", "cfg3", "cfg5"])
     ap.add_argument("--variant", default="all", choices=["all", "estep"])
-    ap.add_argument("--cpu-sample-trials", type=int, default=50)
+    ap.add_argument("--cpu-sample-trials", type=int, default=200)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
