@@ -67,6 +67,9 @@ __device__ void spike_body(const EngineView& ev, const double* __restrict__ C, i
   }
 
   double ts[SV_SPL], cw[SV_SPL], mu[SV_SPL];
+  // periodic: sin / cos of the spike phase 2 pi t / p, once per spike; the pair (spike, inducing point)
+  // then costs 4 FMAs by angle addition instead of a sincos
+  double st[SV_SPL], ct[SV_SPL];
   int nid[SV_SPL];
 #pragma unroll
   for (int i = 0; i < SV_SPL; ++i) {
@@ -77,7 +80,20 @@ __device__ void spike_body(const EngineView& ev, const double* __restrict__ C, i
     nid[i] = ok ? ev.spk_n[gs] : -1;
     cw[i] = ok ? C[(long long)nid[i] * K + k] : 0.0;
     mu[i] = 0.0;
+    if (KT == SV_PERIODIC) sv_sincos_quarter(ts[i], st[i], ct[i]);
   }
+  double* zsc = red + NV * 8 * 65;   // 3 * 64 doubles: scaled z, and (periodic) sin / cos of its phase
+  if (lane < M) {
+    const double zq = z[lane] * sc;
+    zsc[lane] = zq;
+    if (KT == SV_PERIODIC) {
+      double sz, cz;
+      sv_sincos_quarter(zq, sz, cz);
+      zsc[64 + lane] = sz;
+      zsc[128 + lane] = cz;
+    }
+  }
+  __syncthreads();
   double t0acc = 0.0, t1acc = 0.0;
 
   for (int jb = 0; jb < M; jb += 8) {
@@ -86,25 +102,35 @@ __device__ void spike_body(const EngineView& ev, const double* __restrict__ C, i
       const int j = jb + jj;
       double p0 = 0.0, p1 = 0.0, p2 = 0.0, p3 = 0.0;
       if (j < M) {
-        const double zs = z[j] * sc, aj = a[j];
+        const double zs = zsc[j], aj = a[j];
+        double sz = 0.0, cz = 0.0;
+        if (KT == SV_PERIODIC) {
+          sz = zsc[64 + j];
+          cz = zsc[128 + j];
+        }
 #pragma unroll
         for (int i = 0; i < SV_SPL; ++i) {
-          const double u = ts[i] - zs;
-          double y, sn = 0.0;
+          double y, sn = 0.0, u = 0.0;
           if (KT == SV_RBF) {
+            u = ts[i] - zs;
             y = -(u * u);
           } else {
-            double cs;
-            sv_sincos_quarter(u, sn, cs);
+            const double cs = fma(st[i], sz, ct[i] * cz);     // cos(2 pi (t - z) / p)
+            sn = fma(st[i], cz, -(ct[i] * sz));               // sin(2 pi (t - z) / p)
             y = fma(cs, hh, -hh);
           }
           const double kt = sv_exp2_neg(y);
           if (FULL) {
             const double ck = cw[i] * kt;
             p0 += ck;
-            p1 = fma(ck, (KT == SV_RBF) ? u : sn, p1);
             p2 = fma(ck, y, p2);
-            if (KT == SV_PERIODIC) p3 = fma(ck, u * sn, p3);
+            if (KT == SV_RBF) {
+              p1 = fma(ck, u, p1);
+            } else {
+              const double cks = ck * sn;
+              p1 += cks;
+              p3 = fma(cks, ts[i], p3);    // sum c ktil sn (t - z) = p3 - z p1, finished after the reduction
+            }
             mu[i] = fma(kt, aj, mu[i]);
           } else {
             p0 = fma(cw[i], kt, p0);
@@ -120,6 +146,7 @@ __device__ void spike_body(const EngineView& ev, const double* __restrict__ C, i
     }
     __syncthreads();
     // transposed reduction: lane (v, quarter) sums 16 of the 64 lane-partials of vector v
+    double p1keep = 0.0;   // lane 8 + jj holds P1_j in round 0 and the periodic P3_j in round 1
 #pragma unroll
     for (int v0 = 0; v0 < NV * 8; v0 += 16) {
       const int v = v0 + (lane & 15), qd = lane >> 4;
@@ -136,12 +163,13 @@ __device__ void spike_body(const EngineView& ev, const double* __restrict__ C, i
         const int type = v >> 3;
         if (type == 0)
           ev.P0[o] = s;
-        else if (type == 1)
+        else if (type == 1) {
           ev.P1[o] = s * w1;
-        else if (type == 2)
+          p1keep = s;
+        } else if (type == 2)
           t0acc = fma(a[j], s, t0acc);
-        else
-          t1acc = fma(a[j], s, t1acc);
+        else   // sum_s c ktil sn (t - z_j) = P3_j - z_j P1_j   (scaled units)
+          t1acc = fma(a[j], s - zsc[j] * p1keep, t1acc);
       }
     }
     __syncthreads();
@@ -175,7 +203,7 @@ __device__ void spike_body(const EngineView& ev, const double* __restrict__ C, i
 template <int KT, bool FULL>
 __global__ __launch_bounds__(64) void k_spike(EngineView ev, const double* __restrict__ C) {
   constexpr int NV = FULL ? (KT == SV_RBF ? 3 : 4) : 1;
-  __shared__ double red[NV * 8 * 65];
+  __shared__ double red[NV * 8 * 65 + 3 * 64];
   const int item = blockIdx.x;
   const int nk = ev.ntype[KT];
   const int ch = item / nk, k = ev.klist[KT][item % nk];
