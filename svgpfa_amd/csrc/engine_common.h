@@ -47,6 +47,10 @@ struct LatentPtrs {
 // (trial, neuron) segments, so the wavefront that owns the chunk is the only writer of those
 // neurons' spike sums.  A neuron with more than SV_SPIKE_CHUNK spikes in a trial gets dedicated
 // chunks (split = 1, all spikes of that one neuron); their sums are added in chunk order later.
+struct LatentPtrTable {
+  LatentPtrs p[SV_MAX_K];
+};
+
 struct SpikeChunk {
   int trial;
   int count;

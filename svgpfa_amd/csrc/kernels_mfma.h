@@ -559,3 +559,77 @@ __device__ void bwd_mfma_body(const EngineView& ev, const LatentPtrs pt, unsigne
     ev.gthitem[item * 2 + 1] = t1 + ev.gthq[item * 2 + 1] + p.c1 * s1;
   }
 }
+
+// ----------------------------------------------------------------------------- k_prep_mfma
+// ut = Linv m, a = Linv^T ut, Vt = Linv L_S and the KL term per (trial, latent), on the f64 MFMA.
+// One wavefront per item; Linv and L_S are staged in LDS with coalesced loads; the vector m rides
+// along as an extra 16-column panel (column 0) so that ut and a come out of the same tri_chain.
+template <int NT>
+__global__ __launch_bounds__(64) void k_prep_mfma(EngineView ev, LatentPtrTable ptab) {
+  extern __shared__ double sm[];
+  constexpr int MP = 16 * NT, LD = MP + 2;
+  const int item = blockIdx.x, lane = threadIdx.x, li = lane & 15, lg = lane >> 4;
+  const int r = item / ev.K, k = item % ev.K;
+  const LatentMeta m = ev.meta[k];
+  const LatentPtrs pt = ptab.p[k];
+  const int M = m.M;
+  double* Li = sm;               // MP*LD
+  double* Ls = Li + MP * LD;     // MP*LD
+  const long long base = m.offMM + (long long)r * M * M;
+  const long long vbase = m.offM + (long long)r * M;
+  const double* cv = pt.cholvec + (long long)r * m.P;
+  for (int e = lane; e < MP * MP; e += 64) {
+    int i = e / MP, j = e % MP;
+    bool in = (i < M) && (j < M);
+    Li[i * LD + j] = in ? ev.Linv[base + i * M + j] : 0.0;
+    Ls[i * LD + j] = (in && j <= i) ? cv[i * (i + 1) / 2 + j] : 0.0;
+  }
+  __syncthreads();
+
+  // panels of L_S (NT of them) -> Vt ; |Vt|_F^2
+  double fro = 0.0;
+#pragma unroll
+  for (int c = 0; c < NT; ++c) {
+    d4 P[NT], V[NT];
+#pragma unroll
+    for (int b = 0; b < NT; ++b)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) P[b][q] = Ls[(16 * b + 4 * q + lg) * LD + 16 * c + li];
+    tri_chain<NT, 0>(V, Li, LD, P, li, lg);
+#pragma unroll
+    for (int a = 0; a < NT; ++a)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        int i = 16 * a + 4 * q + lg, j = 16 * c + li;
+        if (i < M && j < M) ev.Vt[base + i * M + j] = V[a][q];
+        fro = fma(V[a][q], V[a][q], fro);
+      }
+  }
+  // the mean as column 0 of an extra panel: ut = Linv m, a = Linv^T ut
+  d4 Pm[NT], U[NT], A[NT];
+#pragma unroll
+  for (int b = 0; b < NT; ++b)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      int i = 16 * b + 4 * q + lg;
+      Pm[b][q] = (li == 0 && i < M) ? pt.mean[(long long)r * M + i] : 0.0;
+    }
+  tri_chain<NT, 0>(U, Li, LD, Pm, li, lg);
+  tri_chain<NT, 1>(A, Li, LD, U, li, lg);
+  double quad = 0.0;
+#pragma unroll
+  for (int a = 0; a < NT; ++a)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      int i = 16 * a + 4 * q + lg;
+      if (li == 0 && i < M) {
+        ev.ut[vbase + i] = U[a][q];
+        ev.a[vbase + i] = A[a][q];
+        quad = fma(U[a][q], U[a][q], quad);
+      }
+    }
+  double ld = 0.0;
+  if (lane < M) ld = -2.0 * log(Li[lane * LD + lane]) - 2.0 * log(fabs(Ls[lane * LD + lane]));
+  const double tot = wave_sum(fro + quad + ld);
+  if (lane == 0) ev.klpart[item] = 0.5 * (tot - (double)M);
+}

@@ -15,14 +15,10 @@
 #include "kernels_spike.h"
 #include "kernels_times.h"
 
-struct PtrTable {
-  LatentPtrs p[SV_MAX_K];
-};
+typedef LatentPtrTable PtrTable;
 
 // k_prep / k_bwd read the caller's per-latent tensors: the pointer table travels by value in
 // the kernarg segment, so nothing has to be staged through HBM when the caller's tensors move.
-__global__ __launch_bounds__(64) void k_prep_entry(EngineView ev, PtrTable pt);
-__global__ __launch_bounds__(64) void k_bwd_entry(EngineView ev, PtrTable pt, unsigned mask);
 
 struct svgpfa_engine {
   EngineView v{};
@@ -30,7 +26,7 @@ struct svgpfa_engine {
   std::vector<void*> allocs;
   hipStream_t stream = nullptr;
   int device = 0;
-  int Mmax = 0, KT = 0, NT = 1;
+  int Mmax = 0, KT = 0, NT = 1, pack = 1;
   long long totM = 0, totMM = 0;  // R*sum M, R*sum M^2
   bool have_quad = false, have_spikes = false, have_kernels = false, have_stats = false;
   bool timing = false;
@@ -78,9 +74,8 @@ static int dalloc(svgpfa_engine* e, T** p, size_t n) {
     if (_r) return _r;                       \
   } while (0)
 
-static size_t lds_build(int M) { return (size_t)2 * M * (M + 1) * 8; }
-static size_t lds_prep(int M) { return ((size_t)M * (M + 1) + 128) * 8; }
-static size_t lds_bwd(int M) { return ((size_t)4 * M * (M + 1) + 256) * 8; }
+static size_t lds_build(int M, int pack) { return ((size_t)2 * M * (M + 1) + 64) * 8 * pack; }
+static size_t lds_prep(int M, int pack) { return ((size_t)M * (M + 1) + 128) * 8 * pack; }
 static size_t lds_times(int M) { return ((size_t)2 * M * (M + 1) + 128 * (M + 1) + 128 + 768) * 8; }
 static size_t lds_qbwd(int M) {
   int QB = (M <= 32) ? 64 : 32;
@@ -105,13 +100,10 @@ static size_t lds_qell(const svgpfa_engine* e) {
   return ((size_t)2 * e->v.qtile * e->KT + e->v.qtile + (size_t)e->v.N * e->KT + e->v.N + 4) * 8;
 }
 
+template <int PACK>
 __global__ __launch_bounds__(64) void k_prep_entry(EngineView ev, PtrTable pt) {
   extern __shared__ double sm[];
-  k_prep_body(ev, pt.p[blockIdx.x % ev.K], sm);
-}
-__global__ __launch_bounds__(64) void k_bwd_entry(EngineView ev, PtrTable pt, unsigned mask) {
-  extern __shared__ double sm[];
-  k_bwd_body(ev, pt.p[blockIdx.x % ev.K], mask, sm);
+  k_prep_body<PACK>(ev, pt.p, sm);
 }
 template <int NT, int KT>
 __global__ __launch_bounds__(64) void k_bwd_mfma(EngineView ev, PtrTable pt, unsigned mask) {
@@ -235,9 +227,14 @@ int svgpfa_create(const svgpfa_dims* d, int device, svgpfa_engine** out) {
   HIPCHK(e, hipEventCreateWithFlags(&e->ev_join, hipEventDisableTiming));
 
   int rc;
-  if ((rc = allow_lds(e, k_build, lds_build(e->Mmax)))) return rc;
-  if ((rc = allow_lds(e, k_prep_entry, lds_prep(e->Mmax)))) return rc;
-  if ((rc = allow_lds(e, k_bwd_entry, lds_bwd(e->Mmax)))) return rc;
+  e->pack = 1;   // two items per wavefront (pack = 2) measured no faster: these kernels are latency-bound per item
+  if (e->pack == 2) {
+    if ((rc = allow_lds(e, k_build<2>, lds_build(e->Mmax, 2)))) return rc;
+    if ((rc = allow_lds(e, k_prep_entry<2>, lds_prep(e->Mmax, 2)))) return rc;
+  } else {
+    if ((rc = allow_lds(e, k_build<1>, lds_build(e->Mmax, 1)))) return rc;
+    if ((rc = allow_lds(e, k_prep_entry<1>, lds_prep(e->Mmax, 1)))) return rc;
+  }
   rc = 0;
   DISPATCH_NT(e->NT, FOR_KT(e, if (!rc) rc = allow_lds(e, (k_bwd_mfma<NT_, KT_>), lds_bwd_mfma(NT_))));
   if (rc) return rc;
@@ -417,7 +414,10 @@ int svgpfa_build_kernels(svgpfa_engine* e, const double* const* Z, const double*
     int gx = std::max(1, std::min(64, (v.R * e->Mmax + 255) / 256));
     hipLaunchKernelGGL(k_snapshot, dim3(gx, v.K), dim3(256), 0, e->stream, v, st);
   }
-  hipLaunchKernelGGL(k_build, dim3(v.R * v.K), dim3(64), lds_build(e->Mmax), e->stream, v);
+  if (e->pack == 2)
+    hipLaunchKernelGGL(k_build<2>, dim3(v.K * ((v.R + 1) / 2)), dim3(64), lds_build(e->Mmax, 2), e->stream, v);
+  else
+    hipLaunchKernelGGL(k_build<1>, dim3(v.K * v.R), dim3(64), lds_build(e->Mmax, 1), e->stream, v);
   HIPCHK(e, hipGetLastError());
   e->have_kernels = true;
   e->have_stats = false;
@@ -475,6 +475,22 @@ static int launch_times(svgpfa_engine* e, const double* times, const long long* 
   return SVGPFA_OK;
 }
 
+static size_t lds_prep_mfma(int NT) {
+  size_t MP = 16 * NT, LD = MP + 2;
+  return 2 * MP * LD * 8;
+}
+static void launch_prep(svgpfa_engine* e, const PtrTable& pt) {
+  EngineView& v = e->v;
+  if (e->NT <= 2) {   // larger M: keep the scalar kernel (register budget of 3-4 tile panels)
+    DISPATCH_NT(e->NT, hipLaunchKernelGGL(k_prep_mfma<NT_>, dim3(v.R * v.K), dim3(64), lds_prep_mfma(NT_), e->stream, v, pt));
+    return;
+  }
+  if (e->pack == 2)
+    hipLaunchKernelGGL(k_prep_entry<2>, dim3(v.K * ((v.R + 1) / 2)), dim3(64), lds_prep(e->Mmax, 2), e->stream, v, pt);
+  else
+    hipLaunchKernelGGL(k_prep_entry<1>, dim3(v.K * v.R), dim3(64), lds_prep(e->Mmax, 1), e->stream, v, pt);
+}
+
 static int check_ready(svgpfa_engine* e) {
   if (!e->have_quad) FAIL(e, SVGPFA_ERR_STATE, "svgpfa_set_quad has not been called");
   if (!e->have_spikes) FAIL(e, SVGPFA_ERR_STATE, "svgpfa_set_spikes has not been called");
@@ -495,7 +511,7 @@ int svgpfa_elbo(svgpfa_engine* e, const double* const* mean, const double* const
   const bool want_lat = (mask & (1u | 4u | 8u)) != 0;
   const bool full = (mask & (2u | 4u | 8u)) != 0;
 
-  hipLaunchKernelGGL(k_prep_entry, dim3(RK), dim3(64), lds_prep(e->Mmax), e->stream, v, pt);
+  launch_prep(e, pt);
   // fork: the spike pass (fp64 VALU bound) needs only a = Kzz^-1 m from k_prep; it runs on the side
   // stream while the quadrature chain (f64 MFMA) runs on the main stream; k_bwd joins both.
   hipStream_t sps = e->overlap ? e->side : e->stream;
@@ -552,7 +568,7 @@ int svgpfa_latent_stats(svgpfa_engine* e, const double* const* mean, const doubl
   PtrTable pt;
   if ((rc = fill_ptrs(e, pt, mean, cholvec, nullptr, nullptr, nullptr, 0))) return rc;
   const int RK = v.R * v.K;
-  hipLaunchKernelGGL(k_prep_entry, dim3(RK), dim3(64), lds_prep(e->Mmax), e->stream, v, pt);
+  launch_prep(e, pt);
   if ((rc = launch_times(e, v.tq, nullptr, v.Q, v.muq, v.varq, (long long)v.K, 1LL, 1))) return rc;
   if ((rc = launch_times(e, v.spk_t, v.spk_off, 0, v.muspk, v.varspk, 1LL, (long long)v.S, 1))) return rc;
   hipLaunchKernelGGL(k_mseg, dim3((v.N * v.K + 255) / 256), dim3(256), 0, e->stream, v);
@@ -591,7 +607,7 @@ int svgpfa_predict(svgpfa_engine* e, const double* const* mean, const double* co
   int rc;
   if ((rc = fill_ptrs(e, pt, mean, cholvec, nullptr, nullptr, nullptr, 0))) return rc;
   const int RK = v.R * v.K;
-  hipLaunchKernelGGL(k_prep_entry, dim3(RK), dim3(64), lds_prep(e->Mmax), e->stream, v, pt);
+  launch_prep(e, pt);
   if ((rc = launch_times(e, times, nullptr, (int)T, mu, var ? var : mu, (long long)v.K, 1LL, var ? 1 : 0))) return rc;
   HIPCHK(e, hipGetLastError());
   e->have_stats = false;  // k_prep overwrote a / W with these parameters; stats must be recomputed

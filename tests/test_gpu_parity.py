@@ -150,8 +150,8 @@ def test_not_positive_definite_raises():
     """Reference: torch.linalg.cholesky raises (utils/miscUtils.py:215); the EM loop relies on it."""
     from svgpfa_amd.engine import SVGPFAEngineError
     from svgpfa_amd import _lib
-    prob = synthetic.make_problem(R=2, N=3, K=1, M=6, kernels="rbf", seed=9, n_quad=16, rate=5.0, reg=0.0)
-    prob["Z"][0][1, 3] = prob["Z"][0][1, 2]      # duplicated inducing point, no jitter: singular Kzz
+    prob = synthetic.make_problem(R=2, N=3, K=1, M=6, kernels="rbf", seed=9, n_quad=16, rate=5.0, reg=-0.5)
+    prob["Z"][0][1, 3] = prob["Z"][0][1, 2]      # duplicated inducing point and negative jitter: indefinite Kzz
     with pytest.raises(SVGPFAEngineError) as ei:
         eng, P = _engine(prob)
         eng.sync()

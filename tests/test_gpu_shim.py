@@ -203,7 +203,7 @@ def test_config1_bundled_data_two_em_iterations():
 
 def test_not_pd_raises_linalg_error_and_em_reports_it():
     """utils/miscUtils.py:215 raises torch.linalg.LinAlgError; svEM.py:150-163 turns it into ErrorTerminationInfo."""
-    prob = synthetic.make_problem(R=2, N=3, K=1, M=6, kernels="rbf", seed=9, n_quad=16, rate=5.0, reg=0.0)
+    prob = synthetic.make_problem(R=2, N=3, K=1, M=6, kernels="rbf", seed=9, n_quad=16, rate=5.0, reg=-0.5)
     prob["Z"][0][1, 3] = prob["Z"][0][1, 2]
     with pytest.raises(torch.linalg.LinAlgError):
         _model(prob)
