@@ -177,20 +177,15 @@ __device__ void quad_bwd_mfma_body(const EngineView& ev, double* sm) {
   double* gvs = S + 4 * 16 * LD;      // 4 * 16
   double* vred = gvs + 64;            // 4 * 2 * MP  (gu / dz partials per wave)
   double* tred = vred + 8 * MP;       // 8
+  double* szl = tred + 8;             // MP  sin of the inducing-point phases (periodic)
+  double* czl = szl + MP;             // MP  cos
   const KPar p = make_kpar(m, ev.theta + 2 * k);
   const long long base = m.offMM + (long long)r * M * M;
   const long long vbase = m.offM + (long long)r * M;
   load_factors<NT>(ev, m, r, Li, Vl, ul, zl, FULL);
   __syncthreads();
-
-  double uj[NT][4], zj[NT][4];
-#pragma unroll
-  for (int a = 0; a < NT; ++a)
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      uj[a][q] = ul[16 * a + 4 * q + lg];
-      zj[a][q] = zl[16 * a + 4 * q + lg];
-    }
+  if (KT == SV_PERIODIC && tid < MP) sv_sincos_quarter(zl[tid] * p.q4, szl[tid], czl[tid]);
+  __syncthreads();
   d4 gu[NT], dz[NT], GW[NTRI];
 #pragma unroll
   for (int a = 0; a < NT; ++a) {
@@ -202,6 +197,10 @@ __device__ void quad_bwd_mfma_body(const EngineView& ev, double* sm) {
   double th0 = 0.0, th1 = 0.0;
   double* Sw = S + wave * 16 * LD;
   double* gvw = gvs + wave * 16;
+  // periodic: kappa and its derivative bases follow from the node's own sin / cos and the inducing
+  // points' (szl, czl) by angle addition (no per-pair sincos, no second exp).  Per-j constants are read
+  // from LDS at their use sites (jo is an opaque 0: it keeps them out of long-lived registers).
+  const double inv_s2 = 1.0 / p.s2;
 
   const int ntiles = (Q + 15) >> 4;
   for (int tile = wave; tile < ntiles; tile += 4) {
@@ -211,20 +210,22 @@ __device__ void quad_bwd_mfma_body(const EngineView& ev, double* sm) {
     const double tq = ev.tq[gi];
     const double gm = ok ? ev.gmuq[gi * K + k] : 0.0;
     const double gvv = ok ? ev.gvarq[gi * K + k] : 0.0;
-    d4 X0[NT], kbz[NT], kb0[NT], kb1[NT];
+    double stq = 0.0, ctq = 0.0;
+    if (KT == SV_PERIODIC) sv_sincos_quarter(tq * p.q4, stq, ctq);
+    int jo = lg;
+    asm volatile("" : "+v"(jo));
+    d4 X0[NT];
 #pragma unroll
     for (int a = 0; a < NT; ++a)
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
-        if (FULL) {
-          double kt, bz, b0v, b1v;
-          kern_eval<KT>(tq - zj[a][q], p, kt, bz, b0v, b1v);
-          X0[a][q] = p.s2 * kt;
-          kbz[a][q] = kt * bz;
-          kb0[a][q] = kt * b0v;
-          kb1[a][q] = kt * b1v;
+        const int j = 16 * a + 4 * q + jo;
+        if (KT == SV_RBF) {
+          const double dd = tq - zl[j];
+          X0[a][q] = p.s2 * sv_exp2_neg(-(dd * dd) * p.h2);
         } else {
-          X0[a][q] = p.s2 * kern_val<KT>(tq - zj[a][q], p);
+          const double cs = fma(stq, szl[j], ctq * czl[j]);
+          X0[a][q] = p.s2 * sv_exp2_neg(fma(cs, p.h2, -p.h2));
         }
       }
     d4 Kw[NT];
@@ -240,15 +241,28 @@ __device__ void quad_bwd_mfma_body(const EngineView& ev, double* sm) {
 #pragma unroll
       for (int a = 0; a < NT; ++a)
 #pragma unroll
-        for (int q = 0; q < 4; ++q) Y[a][q] = gm * uj[a][q] + 2.0 * gvv * (Y[a][q] - Kw[a][q]);
+        for (int q = 0; q < 4; ++q) Y[a][q] = gm * ul[16 * a + 4 * q + jo] + 2.0 * gvv * (Y[a][q] - Kw[a][q]);
       tri_chain<NT, 1>(Gk, Li, LD, Y, li, lg);
+      asm volatile("" : "+v"(jo));
 #pragma unroll
       for (int a = 0; a < NT; ++a)
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-          th0 = fma(Gk[a][q], kb0[a][q], th0);
-          if (KT == SV_PERIODIC) th1 = fma(Gk[a][q], kb1[a][q], th1);
-          dz[a][q] = fma(Gk[a][q], kbz[a][q], dz[a][q]);
+          const int j = 16 * a + 4 * q + jo;
+          const double gkk = Gk[a][q] * (X0[a][q] * inv_s2);    // gk * ktil
+          const double dd = tq - zl[j];
+          if (KT == SV_RBF) {
+            const double gd = gkk * dd;
+            dz[a][q] += gd;                                    // bz = delta
+            th0 = fma(gd, dd, th0);                            // b0 = delta^2
+          } else {
+            const double cs = fma(stq, szl[j], ctq * czl[j]);
+            const double sn = fma(stq, czl[j], -(ctq * szl[j]));
+            const double gs = gkk * sn;
+            dz[a][q] += gs;                                    // bz = sin(2 pi delta / p)
+            th0 = fma(gkk, 0.5 - 0.5 * cs, th0);               // b0 = sin^2(pi delta / p)
+            th1 = fma(gs, dd, th1);                            // b1 = delta sin(2 pi delta / p)
+          }
         }
     }
     // Gt += Kw^T diag(gvar) Kw : contraction over the time index -> transpose through LDS

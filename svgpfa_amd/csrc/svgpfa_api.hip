@@ -87,7 +87,7 @@ static size_t lds_times_mfma(int NT) {
 }
 static size_t lds_qbwd_mfma(int NT) {
   size_t MP = 16 * NT, LD = MP + 2;
-  return (2 * MP * LD + 2 * MP + 4 * 16 * LD + 64 + 8 * MP + 8) * 8;
+  return (2 * MP * LD + 2 * MP + 4 * 16 * LD + 64 + 8 * MP + 8 + 2 * MP) * 8;
 }
 #define DISPATCH_NT(nt, ...)                                 \
   switch (nt) {                                              \
