@@ -368,10 +368,10 @@ __device__ void bwd_mfma_body(const EngineView& ev, const LatentPtrs pt, unsigne
   const LatentMeta m = ev.meta[k];
   const int M = m.M;
   double* Li = sm;               // MP*LD
-  double* Vl = Li + MP * LD;     // MP*LD
+  double* Vl = Li + MP * LD;     // MP*LD  Vt; once C and Vt Vt^T are in registers it is reused for C
   double* Gl = Vl + MP * LD;     // MP*LD  Gt, later At
-  double* Cs = Gl + MP * LD;     // MP*LD  C = Vt Vt^T Gt
-  double* gt = Cs + MP * LD;     // MP
+  double* Cs = Vl;
+  double* gt = Gl + MP * LD;     // MP
   double* ul = gt + MP;          // MP
   double* gs = ul + MP;          // MP
   double* zl = gs + MP;          // MP
@@ -385,11 +385,21 @@ __device__ void bwd_mfma_body(const EngineView& ev, const LatentPtrs pt, unsigne
   for (int i = lane; i < MP; i += 64) {
     gs[i] = 0.0; ul[i] = 0.0; zl[i] = 0.0; gt[i] = 0.0;
   }
+  const int c0 = ev.chunk_first[r], c1 = ev.chunk_first[r + 1];
   if (lane < M) {
     double p0 = 0.0;
-    for (int c = ev.chunk_first[r]; c < ev.chunk_first[r + 1]; ++c) {
-      p0 += ev.P0[(long long)c * ev.sumM + m.colM + lane];
-      if (want_zt) p1sum += ev.P1[(long long)c * ev.sumM + m.colM + lane];
+    for (int c = c0; c < c1; c += 4) {          // 4 chunks per step: independent loads in flight, fixed order
+      double v[4], w[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const bool in = c + u < c1;
+        const long long o = (long long)(in ? c + u : c) * ev.sumM + m.colM + lane;
+        v[u] = ev.P0[o];
+        w[u] = want_zt ? ev.P1[o] : 0.0;
+        if (!in) { v[u] = 0.0; w[u] = 0.0; }
+      }
+      p0 += (v[0] + v[1]) + (v[2] + v[3]);
+      p1sum += (w[0] + w[1]) + (w[2] + w[3]);
     }
     a_l = ev.a[vbase + lane];
     double gsp = p.s2 * p0;
@@ -399,6 +409,16 @@ __device__ void bwd_mfma_body(const EngineView& ev, const LatentPtrs pt, unsigne
     zl[lane] = ev.Zs[vbase + lane];
   }
   espk = wave_sum(espk);
+  // spike-direct theta partials: one chunk per lane, then a fixed-order wave tree
+  double tp0 = 0.0, tp1 = 0.0;
+  if (want_zt) {
+    for (int c = c0 + lane; c < c1; c += 64) {
+      tp0 += ev.Tpart[((long long)c * ev.K + k) * 2 + 0];
+      tp1 += ev.Tpart[((long long)c * ev.K + k) * 2 + 1];
+    }
+    tp0 = wave_sum(tp0);
+    tp1 = wave_sum(tp1);
+  }
   if (lane == 0) ev.ells[item] = espk;
   if ((mask & (1u | 4u | 8u)) == 0) return;
 
@@ -475,27 +495,30 @@ __device__ void bwd_mfma_body(const EngineView& ev, const LatentPtrs pt, unsigne
   }
   if (!want_zt) return;
 
-  // ---- C = Vt Vt^T Gt (-> LDS) and VV = Vt Vt^T (registers), panel by panel
-  d4 VV[NT][NT];
+  // ---- C = Vt Vt^T Gt and VV = Vt Vt^T, panel by panel, both kept in registers until Vt is dead
+  d4 VV[NT][NT], Cm[NT][NT];
 #pragma unroll
   for (int c = 0; c < NT; ++c) {
-    d4 P[NT], Bm[NT], Cm[NT];
+    d4 P[NT], Bm[NT];
 #pragma unroll
     for (int b = 0; b < NT; ++b)
 #pragma unroll
       for (int q = 0; q < 4; ++q) P[b][q] = Gl[(16 * b + 4 * q + lg) * LD + 16 * c + li];
     tri_chain<NT, 1>(Bm, Vl, LD, P, li, lg);
-    tri_chain<NT, 0>(Cm, Vl, LD, Bm, li, lg);
-#pragma unroll
-    for (int a = 0; a < NT; ++a)
-#pragma unroll
-      for (int q = 0; q < 4; ++q) Cs[(16 * a + 4 * q + lg) * LD + 16 * c + li] = Cm[a][q];
+    tri_chain<NT, 0>(Cm[c], Vl, LD, Bm, li, lg);
 #pragma unroll
     for (int b = 0; b < NT; ++b)
 #pragma unroll
       for (int q = 0; q < 4; ++q) P[b][q] = Vl[(16 * c + li) * LD + 16 * b + 4 * q + lg];   // Vt^T panel
     tri_chain<NT, 0>(VV[c], Vl, LD, P, li, lg);
   }
+  __syncthreads();
+#pragma unroll
+  for (int c = 0; c < NT; ++c)
+#pragma unroll
+    for (int a = 0; a < NT; ++a)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) Cs[(16 * a + 4 * q + lg) * LD + 16 * c + li] = Cm[c][a][q];
   __syncthreads();
   // ---- At (in place over Gt): each element is read and written by exactly one lane
 #pragma unroll
@@ -564,13 +587,8 @@ __device__ void bwd_mfma_body(const EngineView& ev, const LatentPtrs pt, unsigne
       if ((mask & 8u) && li == 0 && i < M) pt.g_Z[(long long)r * M + i] = g + ev.gZq[vbase + i] + gs[i];
     }
   if (lane == 0) {
-    double s0 = 0.0, s1 = 0.0;
-    for (int c = ev.chunk_first[r]; c < ev.chunk_first[r + 1]; ++c) {
-      s0 += ev.Tpart[((long long)c * ev.K + k) * 2 + 0];
-      s1 += ev.Tpart[((long long)c * ev.K + k) * 2 + 1];
-    }
-    ev.gthitem[item * 2 + 0] = t0 + ev.gthq[item * 2 + 0] + p.c0 * s0;
-    ev.gthitem[item * 2 + 1] = t1 + ev.gthq[item * 2 + 1] + p.c1 * s1;
+    ev.gthitem[item * 2 + 0] = t0 + ev.gthq[item * 2 + 0] + p.c0 * tp0;
+    ev.gthitem[item * 2 + 1] = t1 + ev.gthq[item * 2 + 1] + p.c1 * tp1;
   }
 }
 

@@ -119,7 +119,7 @@ __global__ __launch_bounds__(64) void k_bwd_mfma(EngineView ev, PtrTable pt, uns
   } while (0)
 static size_t lds_bwd_mfma(int NT) {
   size_t MP = 16 * NT, LD = MP + 2;
-  return (4 * MP * LD + 4 * MP) * 8;
+  return (3 * MP * LD + 4 * MP) * 8;
 }
 
 // Snapshot Z_k / theta_k of all latents into engine-owned HBM in ONE launch (reference semantics:
