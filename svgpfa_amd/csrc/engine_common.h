@@ -63,6 +63,7 @@ struct SpikeChunk {
 struct EngineView {
   int R, N, K, Q, S;
   int sumM, nchunks, nqt, qtile, nth_total;
+  int ncd, nell;              // rows of dC / dd partials ([ncd][N][2K], [ncd][N]) and number of ELL partials
   int ntype[2];               // number of RBF / periodic latents
   int klist[2][SV_MAX_K];     // their indices: kernels are launched once per covariance type
   double reg;
@@ -89,7 +90,7 @@ struct EngineView {
   double* splitPart;                               // [nchunks][K] spike part of dC of split chunks
   double* muspk;                                   // [K][S] (stats API only)
   double* varspk;                                  // [K][S] (stats API only)
-  double* gCpart; double* gdpart; double* ellq;    // [R*nqt][N][K], [R*nqt][N], [R*nqt]
+  double* gCpart; double* gdpart; double* ellq;    // [ncd][N][2K] raw sums (E^T mu | E^T var), [ncd][N], [nell]
   double* ells; double* gthitem;                   // [R*K], [R*K*2]
   double* Mseg;                                    // [N][K] sum over spikes of mu_spk per neuron (stats path)
   int* status;

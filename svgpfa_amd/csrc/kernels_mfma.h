@@ -665,3 +665,180 @@ __global__ __launch_bounds__(64) void k_prep_mfma(EngineView ev, LatentPtrTable 
   const double tot = wave_sum(fro + quad + ld);
   if (lane == 0) ev.klpart[item] = 0.5 * (tot - (double)M);
 }
+
+// ------------------------------------------------------------------------- k_quad_ell_mfma
+// Quadrature term of the expected log-likelihood in GEMM form (reference svEmbedding.py:80-84,
+// expectedLogLikelihood.py:107-135,205-208), per trial:
+//   h = [mu | var] (Q x 2K) . [C | C^2/2]^T (2K x N) + d        E = w_q exp(h)          ELL_quad = -sum E
+//   ROLE 0 (n-tile per wave, loop q-tiles): [A1 | A2]^T = [mu | var]^T E -> dC = -(A1 + C A2), dd = -colsum E
+//   ROLE 1 (q-tile per wave, loop n-tiles): [gmu | gvar]^T = -[C | C^2/2]^T E^T   (latent adjoints)
+// A 16x16 tile of E lives in accumulator layout and is the B operand of the sum products as is; role 1
+// recomputes the transposed tile instead of transposing through LDS.  log2(e) is folded into the LDS copy
+// of [C | C^2/2] and d, so that E = w 2^h.  The LOOPED operand matrix of the whole trial sits in LDS
+// (rows padded to LDK = 4 KS + 2 doubles: conflict-free fragment reads); the wave's own 16 rows of the
+// other matrix sit in a small per-wave LDS slice.  grid = R * parts blocks of 256 threads.
+template <int KS, int ROLE>
+__global__ __launch_bounds__(256) void k_quad_ell_mfma(EngineView ev, const double* C, const double* d,
+                                                       int want_sums, int write_ell, int parts) {
+  extern __shared__ double sm[];
+  constexpr int KKP = 4 * KS, LDK = KKP + 2, KKT = (KKP + 15) / 16;
+  const double L2E = 1.4426950408889634074, LN2 = 0.69314718055994530942;
+  const int K = ev.K, N = ev.N, Q = ev.Q, K2 = 2 * K;
+  const int QT = (Q + 15) >> 4, NTl = (N + 15) >> 4;
+  const int LT = (ROLE == 0) ? QT : NTl;      // tiles of the looped dimension
+  const int OT = (ROLE == 0) ? NTl : QT;      // tiles of the wave-owned dimension
+  const int Lp = LT * 16;
+  const int blk = blockIdx.x, r = blk / parts, part = blk % parts;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 15, lg = lane >> 4;
+  double* LM = sm;                          // (Lp + 1) * LDK  looped matrix: ROLE 0 [mu | var], ROLE 1 log2e [C | C^2/2]
+  double* lv = LM + (Lp + 1) * LDK;         // Lp   looped vector: ROLE 0 w_q, ROLE 1 log2e d_n
+  double* OW = lv + Lp;                     // 4 * 16 * LDK  per-wave rows of the other matrix
+  double* red = OW + 4 * 16 * LDK;          // 8
+
+  // ---- fill the looped matrix: zero the padding, then batched independent loads (8 in flight per thread)
+  //      over the contiguous sources mu/var [Q x K] (ROLE 0) or C [N x K] (ROLE 1)
+  for (int e = tid; e < (Lp + 1) * LDK; e += 256) LM[e] = 0.0;
+  for (int i = tid; i < Lp; i += 256)
+    lv[i] = (ROLE == 0) ? ((i < Q) ? ev.wq[(long long)r * Q + i] : 0.0) : ((i < N) ? d[i] * L2E : 0.0);
+  __syncthreads();
+  {
+    const int tot = ((ROLE == 0) ? Q : N) * K;
+    const double* s0 = (ROLE == 0) ? ev.muq + (long long)r * Q * K : C;
+    const double* s1 = (ROLE == 0) ? ev.varq + (long long)r * Q * K : C;
+    for (int b0 = 0; b0 < tot; b0 += 256 * 8) {
+      double v0[8], v1[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int idx = b0 + u * 256 + tid;
+        const bool ok = idx < tot;
+        v0[u] = ok ? s0[idx] : 0.0;
+        v1[u] = (ROLE == 0) ? (ok ? s1[idx] : 0.0) : v0[u];
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int idx = b0 + u * 256 + tid;
+        if (idx < tot) {
+          const int row = idx / K, c = idx - row * K;
+          if (ROLE == 0) {
+            LM[row * LDK + c] = v0[u];
+            LM[row * LDK + K + c] = v1[u];
+          } else {
+            LM[row * LDK + c] = v0[u] * L2E;
+            LM[row * LDK + K + c] = 0.5 * v0[u] * v0[u] * L2E;
+          }
+        }
+      }
+    }
+  }
+  __syncthreads();
+
+  double esum = 0.0;
+  double* ow = OW + wave * 16 * LDK;
+  for (int ot = part * 4 + wave; ot < OT; ot += parts * 4) {
+    // own 16 rows -> per-wave LDS slice (wave-local: no block barrier needed); the source rows are
+    // contiguous (16 K doubles): batched loads again
+    for (int e = lane; e < 16 * LDK; e += 64) ow[e] = 0.0;
+    lds_wave_fence();
+    {
+      const int orows = (ROLE == 0) ? N : Q;
+      const int nrow = (orows - ot * 16 < 16) ? (orows - ot * 16) : 16;
+      const int tot = nrow * K;
+      const double* s0 = (ROLE == 0) ? C + (long long)ot * 16 * K : ev.muq + ((long long)r * Q + ot * 16) * K;
+      const double* s1 = (ROLE == 0) ? s0 : ev.varq + ((long long)r * Q + ot * 16) * K;
+      double v0[8], v1[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int idx = u * 64 + lane;
+        const bool ok = idx < tot;
+        v0[u] = ok ? s0[idx] : 0.0;
+        v1[u] = (ROLE == 0) ? v0[u] : (ok ? s1[idx] : 0.0);
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int idx = u * 64 + lane;
+        if (idx < tot) {
+          const int row = idx / K, c = idx - row * K;
+          if (ROLE == 0) {
+            ow[row * LDK + c] = v0[u] * L2E;
+            ow[row * LDK + K + c] = 0.5 * v0[u] * v0[u] * L2E;
+          } else {
+            ow[row * LDK + c] = v0[u];
+            ow[row * LDK + K + c] = v1[u];
+          }
+        }
+      }
+    }
+    lds_wave_fence();
+    const int oi = ot * 16 + li;              // own index of this lane's column
+    const bool ook = oi < ((ROLE == 0) ? N : Q);
+    const double ov = (ROLE == 0) ? ((oi < N) ? d[oi] * L2E : 0.0) : ((oi < Q) ? ev.wq[(long long)r * Q + oi] : 0.0);
+    double bfrag[KS];                         // own rows as the B operand of the h product
+#pragma unroll
+    for (int c = 0; c < KS; ++c) bfrag[c] = ow[li * LDK + 4 * c + lg];
+    d4 acc[KKT];
+#pragma unroll
+    for (int t = 0; t < KKT; ++t) acc[t] = (d4){0.0, 0.0, 0.0, 0.0};
+    double colsum = 0.0;
+    for (int lt = 0; lt < LT; ++lt) {
+      d4 h = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+      for (int c = 0; c < KS; ++c)
+        h = __builtin_amdgcn_mfma_f64_16x16x4f64(LM[(lt * 16 + li) * LDK + 4 * c + lg], bfrag[c], h, 0, 0, 0);
+      double afrag[KKT][4];                   // looped rows, transposed, for the sum product (independent of E)
+      if (want_sums) {
+#pragma unroll
+        for (int t = 0; t < KKT; ++t)
+#pragma unroll
+          for (int c = 0; c < 4; ++c) afrag[t][c] = LM[(lt * 16 + 4 * c + lg) * LDK + 16 * t + li];
+      }
+      d4 E;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int l = lt * 16 + lg + 4 * q;   // looped index of this element's row
+        // ROLE 0: E = w_q 2^(h + d_n) ; ROLE 1: E^T = w_q 2^(h^T + d_n)
+        const double x = (ROLE == 0) ? lv[l] * sv_exp2_neg(h[q] + ov) : ov * sv_exp2_neg(h[q] + lv[l]);
+        const bool lok = l < ((ROLE == 0) ? Q : N);
+        E[q] = (ook && lok) ? x : 0.0;
+        colsum += E[q];
+      }
+      if (want_sums) {
+#pragma unroll
+        for (int t = 0; t < KKT; ++t)
+#pragma unroll
+          for (int c = 0; c < 4; ++c)
+            acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(afrag[t][c], E[c], acc[t], 0, 0, 0);
+      }
+    }
+    esum += colsum;
+    if (want_sums && ook) {
+      if (ROLE == 0) {
+#pragma unroll
+        for (int t = 0; t < KKT; ++t)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const int kk = 16 * t + lg + 4 * q;
+            if (kk < K2) ev.gCpart[((long long)r * N + oi) * K2 + kk] = acc[t][q];
+          }
+      } else {
+        const long long gi = ((long long)r * Q + oi) * K;
+#pragma unroll
+        for (int t = 0; t < KKT; ++t)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const int kk = 16 * t + lg + 4 * q;
+            if (kk < K) ev.gmuq[gi + kk] = -acc[t][q] * LN2;
+            else if (kk < K2) ev.gvarq[gi + kk - K] = -acc[t][q] * LN2;
+          }
+      }
+    }
+    if (ROLE == 0 && want_sums) {
+      colsum = grp4_sum(colsum);
+      if (lg == 0 && ook) ev.gdpart[(long long)r * N + oi] = -colsum;
+    }
+    lds_wave_fence();
+  }
+  if (write_ell) {
+    const double tot = block_sum(esum, red);
+    if (tid == 0) ev.ellq[blk] = -tot;
+  }
+}

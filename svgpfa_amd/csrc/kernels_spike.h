@@ -233,16 +233,16 @@ __global__ void k_mseg(EngineView ev) {
 //                            through LDS
 //   [nbC, nbC+nbD)      dd, [.., +nbT) dtheta : same scheme
 //   last block          the three scalars
-__global__ __launch_bounds__(256) void k_finalize(EngineView ev, const double* d, unsigned mask,
+__global__ __launch_bounds__(256) void k_finalize(EngineView ev, const double* C, const double* d, unsigned mask,
                                                   double* shared) {
   __shared__ double red[8 * 32];
   const int tid = threadIdx.x, o = tid & 31, pg = tid >> 5;
-  const int NK = ev.N * ev.K, N = ev.N, K = ev.K, R = ev.R, nqt = ev.nqt;
+  const int NK = ev.N * ev.K, N = ev.N, K = ev.K, R = ev.R;
   const int nbC = (NK + 31) / 32, nbD = (N + 31) / 32, nbT = (ev.nth_total + 31) / 32;
   int blk = blockIdx.x;
   if (blk == nbC + nbD + nbT) {
     double e = 0.0, kl = 0.0;
-    for (int i = tid; i < R * nqt; i += 256) e += ev.ellq[i];
+    for (int i = tid; i < ev.nell; i += 256) e += ev.ellq[i];
     for (int i = tid; i < R * K; i += 256) {
       e += ev.ells[i];
       kl += ev.klpart[i];
@@ -265,10 +265,11 @@ __global__ __launch_bounds__(256) void k_finalize(EngineView ev, const double* d
       out = 3 + id;
       if (mask & 2u) {
         const int n = id / K, k = id % K;
-        for (int r = pg; r < R; r += 8) {
-          double v = ev.gCspk[(long long)r * NK + id];
-          for (int qt = 0; qt < nqt; ++qt) v += ev.gCpart[((long long)r * nqt + qt) * NK + id];
-          s += v;
+        const double cnk = C[id];
+        for (int r = pg; r < R; r += 8) s += ev.gCspk[(long long)r * NK + id];
+        for (int b = pg; b < ev.ncd; b += 8) {      // dC = -(E^T mu + C . E^T var)
+          const long long o = ((long long)b * N + n) * 2 * K + k;
+          s -= ev.gCpart[o] + cnk * ev.gCpart[o + K];
         }
         if (pg == 0)
           for (int l = 0; l < ev.nsplit; ++l) {
@@ -282,7 +283,7 @@ __global__ __launch_bounds__(256) void k_finalize(EngineView ev, const double* d
     if (n < N) {
       out = 3 + NK + n;
       if (mask & 2u) {
-        for (int b = pg; b < R * nqt; b += 8) s += ev.gdpart[(long long)b * N + n];
+        for (int b = pg; b < ev.ncd; b += 8) s += ev.gdpart[(long long)b * N + n];
         if (pg == 0) s += ev.spk_cnt[n];
       }
     }
@@ -313,10 +314,10 @@ __global__ __launch_bounds__(256) void k_finalize_stats(EngineView ev, const dou
                                                         int want_grad, double* out) {
   __shared__ double red[4];
   const int tid = threadIdx.x;
-  const int NK = ev.N * ev.K, nblk = ev.R * ev.nqt;
+  const int NK = ev.N * ev.K;
   if (blockIdx.x == gridDim.x - 1) {
     double e = 0.0;
-    for (int i = tid; i < nblk; i += 256) e += ev.ellq[i];
+    for (int i = tid; i < ev.nell; i += 256) e += ev.ellq[i];
     for (int i = tid; i < NK; i += 256) e += C[i] * ev.Mseg[i];
     for (int n = tid; n < ev.N; n += 256) e += ev.spk_cnt[n] * d[n];
     e = block_sum(e, red);
@@ -326,13 +327,18 @@ __global__ __launch_bounds__(256) void k_finalize_stats(EngineView ev, const dou
   if (!want_grad) return;
   int id = blockIdx.x * 256 + tid;
   if (id < NK) {
+    const int n = id / ev.K, k = id % ev.K;
+    const double cnk = C[id];
     double s = 0.0;
-    for (int b = 0; b < nblk; ++b) s += ev.gCpart[(long long)b * NK + id];
+    for (int b = 0; b < ev.ncd; ++b) {
+      const long long o = ((long long)b * ev.N + n) * 2 * ev.K + k;
+      s -= ev.gCpart[o] + cnk * ev.gCpart[o + ev.K];
+    }
     out[1 + id] = s + ev.Mseg[id];
   } else if (id < NK + ev.N) {
     int n = id - NK;
     double s = 0.0;
-    for (int b = 0; b < nblk; ++b) s += ev.gdpart[(long long)b * ev.N + n];
+    for (int b = 0; b < ev.ncd; ++b) s += ev.gdpart[(long long)b * ev.N + n];
     out[1 + id] = s + ev.spk_cnt[n];
   }
 }

@@ -157,7 +157,10 @@ __global__ __launch_bounds__(256) void k_quad_ell(EngineView ev, const double* C
     if (want_cd) {
 #pragma unroll
       for (int k = 0; k < KT; ++k)
-        if (k < K) ev.gCpart[((long long)blk * N + n) * K + k] = -(gA[k] + Cn[k] * gB[k]);
+        if (k < K) {
+          ev.gCpart[((long long)blk * N + n) * 2 * K + k] = gA[k];
+          ev.gCpart[((long long)blk * N + n) * 2 * K + K + k] = gB[k];
+        }
       ev.gdpart[(long long)blk * N + n] = -gd;
     }
   }

@@ -27,6 +27,7 @@ struct svgpfa_engine {
   hipStream_t stream = nullptr;
   int device = 0;
   int Mmax = 0, KT = 0, NT = 1, pack = 1;
+  int ell_parts = 0, KKT = 1;  // ell_parts > 0: MFMA GEMM form of the quadrature term (fits LDS)
   long long totM = 0, totMM = 0;  // R*sum M, R*sum M^2
   bool have_quad = false, have_spikes = false, have_kernels = false, have_stats = false;
   bool timing = false;
@@ -95,6 +96,22 @@ static size_t lds_qbwd_mfma(int NT) {
     case 2: { constexpr int NT_ = 2; __VA_ARGS__; } break;   \
     case 3: { constexpr int NT_ = 3; __VA_ARGS__; } break;   \
     default: { constexpr int NT_ = 4; __VA_ARGS__; } break;  \
+  }
+static size_t lds_qell_mfma(const svgpfa_engine* e, int role) {
+  size_t K2 = 2 * e->v.K, KKP = (K2 + 3) & ~(size_t)3, LDK = KKP + 2;
+  size_t Lp = (((role == 0 ? e->v.Q : e->v.N) + 15) / 16) * 16;
+  return ((Lp + 1) * LDK + Lp + 4 * 16 * LDK + 8) * 8;
+}
+#define DISPATCH_KS(ks, ...)                                                                            \
+  switch (ks) {                                                                                         \
+    case 1: { constexpr int KS_ = 1; __VA_ARGS__; } break;   case 2: { constexpr int KS_ = 2; __VA_ARGS__; } break;   \
+    case 3: { constexpr int KS_ = 3; __VA_ARGS__; } break;   case 4: { constexpr int KS_ = 4; __VA_ARGS__; } break;   \
+    case 5: { constexpr int KS_ = 5; __VA_ARGS__; } break;   case 6: { constexpr int KS_ = 6; __VA_ARGS__; } break;   \
+    case 7: { constexpr int KS_ = 7; __VA_ARGS__; } break;   case 8: { constexpr int KS_ = 8; __VA_ARGS__; } break;   \
+    case 9: { constexpr int KS_ = 9; __VA_ARGS__; } break;   case 10: { constexpr int KS_ = 10; __VA_ARGS__; } break; \
+    case 11: { constexpr int KS_ = 11; __VA_ARGS__; } break; case 12: { constexpr int KS_ = 12; __VA_ARGS__; } break; \
+    case 13: { constexpr int KS_ = 13; __VA_ARGS__; } break; case 14: { constexpr int KS_ = 14; __VA_ARGS__; } break; \
+    case 15: { constexpr int KS_ = 15; __VA_ARGS__; } break; default: { constexpr int KS_ = 16; __VA_ARGS__; } break; \
   }
 static size_t lds_qell(const svgpfa_engine* e) {
   return ((size_t)2 * e->v.qtile * e->KT + e->v.qtile + (size_t)e->v.N * e->KT + e->v.N + 4) * 8;
@@ -208,7 +225,12 @@ int svgpfa_create(const svgpfa_dims* d, int device, svgpfa_engine** out) {
   DALLOC(e, v.gaq, e->totM); DALLOC(e, v.GW, e->totMM); DALLOC(e, v.gZq, e->totM);
   DALLOC(e, v.gthq, (size_t)v.R * v.K * 2);
   size_t nblk = (size_t)v.R * v.nqt;
-  DALLOC(e, v.gCpart, nblk * v.N * v.K); DALLOC(e, v.gdpart, nblk * v.N); DALLOC(e, v.ellq, nblk);
+  e->KKT = (2 * v.K + 3) / 4;   // KS: k-steps of the h product
+  e->ell_parts = (std::max(lds_qell_mfma(e, 0), lds_qell_mfma(e, 1)) <= 64 * 1024) ? 4 : 0;
+  v.ncd = e->ell_parts ? v.R : (int)nblk;
+  v.nell = e->ell_parts ? v.R * e->ell_parts : (int)nblk;
+  DALLOC(e, v.gCpart, (size_t)v.ncd * v.N * 2 * v.K); DALLOC(e, v.gdpart, (size_t)v.ncd * v.N);
+  DALLOC(e, v.ellq, (size_t)v.nell);
   DALLOC(e, v.ells, (size_t)v.R * v.K); DALLOC(e, v.gthitem, (size_t)v.R * v.K * 2);
   DALLOC(e, v.Mseg, (size_t)v.N * v.K);
   DALLOC(e, v.status, 1);
@@ -244,6 +266,12 @@ int svgpfa_create(const svgpfa_dims* d, int device, svgpfa_engine** out) {
   if (rc) return rc;
   DISPATCH_NT(e->NT, FOR_KT(e, if (!rc) rc = allow_lds(e, (k_quad_bwd_mfma<NT_, KT_, false>), lds_qbwd_mfma(NT_))));
   if (rc) return rc;
+  if (e->ell_parts) {
+    rc = 0;
+    DISPATCH_KS(e->KKT, rc = allow_lds(e, (k_quad_ell_mfma<KS_, 0>), lds_qell_mfma(e, 0));
+                if (!rc) rc = allow_lds(e, (k_quad_ell_mfma<KS_, 1>), lds_qell_mfma(e, 1)));
+    if (rc) return rc;
+  }
   size_t lq = lds_qell(e);
   switch (e->KT) {
 #define CASE_KT(X) case X: rc = allow_lds(e, k_quad_ell<X>, lq); break;
@@ -454,6 +482,17 @@ static int fill_ptrs(svgpfa_engine* e, PtrTable& pt, const double* const* mean, 
 
 static int launch_quad_ell(svgpfa_engine* e, const double* C, const double* d, int want_cd, int want_lat) {
   EngineView& v = e->v;
+  if (e->ell_parts) {
+    // role 0 (dC, dd and the ELL value) always runs: its column sums give sum E; role 1 only for latent adjoints
+    dim3 gm(v.R * e->ell_parts), bm(256);
+    DISPATCH_KS(e->KKT,
+                hipLaunchKernelGGL((k_quad_ell_mfma<KS_, 0>), gm, bm, lds_qell_mfma(e, 0), e->stream, v, C, d, want_cd, 1,
+                                   e->ell_parts);
+                if (want_lat) hipLaunchKernelGGL((k_quad_ell_mfma<KS_, 1>), gm, bm, lds_qell_mfma(e, 1), e->stream, v, C,
+                                                 d, 1, 0, e->ell_parts));
+    HIPCHK(e, hipGetLastError());
+    return SVGPFA_OK;
+  }
   size_t lq = lds_qell(e);
   dim3 g(v.R * v.nqt), b(256);
   switch (e->KT) {
@@ -554,7 +593,7 @@ int svgpfa_elbo(svgpfa_engine* e, const double* const* mean, const double* const
   DISPATCH_NT(e->NT, FOR_KT(e, hipLaunchKernelGGL((k_bwd_mfma<NT_, KT_>), dim3(v.R * v.ntype[KT_]), dim3(64),
                                                   lds_bwd_mfma(NT_), e->stream, v, pt, mask)));
   int nfin = (v.N * v.K + 31) / 32 + (v.N + 31) / 32 + (v.nth_total + 31) / 32 + 1;
-  hipLaunchKernelGGL(k_finalize, dim3(nfin), dim3(256), 0, e->stream, v, d, mask, shared);
+  hipLaunchKernelGGL(k_finalize, dim3(nfin), dim3(256), 0, e->stream, v, C, d, mask, shared);
   HIPCHK(e, hipGetLastError());
   return SVGPFA_OK;
 }
