@@ -796,7 +796,7 @@ __global__ __launch_bounds__(256) void k_quad_ell_mfma(EngineView ev, const doub
       for (int q = 0; q < 4; ++q) {
         const int l = lt * 16 + lg + 4 * q;   // looped index of this element's row
         // ROLE 0: E = w_q 2^(h + d_n) ; ROLE 1: E^T = w_q 2^(h^T + d_n)
-        const double x = (ROLE == 0) ? lv[l] * sv_exp2_neg(h[q] + ov) : ov * sv_exp2_neg(h[q] + lv[l]);
+        const double x = (ROLE == 0) ? lv[l] * sv_exp2(h[q] + ov) : ov * sv_exp2(h[q] + lv[l]);
         const bool lok = l < ((ROLE == 0) ? Q : N);
         E[q] = (ook && lok) ? x : 0.0;
         colsum += E[q];

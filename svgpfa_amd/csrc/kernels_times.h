@@ -143,7 +143,7 @@ __global__ __launch_bounds__(256) void k_quad_ell(EngineView ev, const double* C
       double h = dn;
 #pragma unroll
       for (int k = 0; k < KT; ++k) h = fma(Cn[k], fma(hC[k], varl[q * KT + k], mul[q * KT + k]), h);
-      double E = wl[q] * exp(h);
+      double E = wl[q] * sv_exp2(h * 1.4426950408889634074);
       gd += E;
       if (want_cd) {
 #pragma unroll
@@ -185,7 +185,7 @@ __global__ __launch_bounds__(256) void k_quad_ell(EngineView ev, const double* C
           double c = Cl[n * KT + k];
           h = fma(c, fma(0.5 * c, vq[k], mq[k]), h);
         }
-        double E = w * exp(h);
+        double E = w * sv_exp2(h * 1.4426950408889634074);
 #pragma unroll
         for (int k = 0; k < KT; ++k) {
           double c = Cl[n * KT + k];

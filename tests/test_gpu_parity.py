@@ -96,6 +96,8 @@ CASES = [
     dict(R=2, N=3, K=1, M=[64], kernels="rbf", n_quad=64, rate=15.0, seed=3),          # max M
     dict(R=2, N=300, K=5, M=8, kernels="periodic", n_quad=32, rate=3.0, seed=4),       # N > 256
     dict(R=1, N=2, K=4, M=1, kernels="mix", n_quad=16, rate=700.0, seed=5),            # M = 1, > 1 spike chunk
+    dict(R=2, N=500, K=20, M=64, kernels="mix", n_quad=200, rate=2.0, seed=6),         # cfg5 shape class (small R)
+    dict(R=3, N=40, K=7, M=[48, 20, 33, 9, 16, 40, 5], kernels="mix", n_quad=50, rate=10.0, seed=7),   # NT = 3, ragged M
 ]
 
 
