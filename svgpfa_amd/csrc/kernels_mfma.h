@@ -109,10 +109,16 @@ __device__ void times_fwd_body(const EngineView& ev, const double* times, const 
     }
 
   const int ntiles = (nt + 15) >> 4;
+  // the time of the NEXT tile is fetched one iteration ahead (global latency hidden behind the MFMA chain)
+  double tq_next = (wave < ntiles) ? times[t0 + ((16 * wave + li < nt) ? 16 * wave + li : 0)] : 0.0;
   for (int tile = wave; tile < ntiles; tile += 4) {
     const int node = 16 * tile + li;
     const bool ok = node < nt;
-    const double tq = times[t0 + (ok ? node : 0)];
+    const double tq = tq_next;
+    {
+      const int nn = node + 64;
+      if (tile + 4 < ntiles) tq_next = times[t0 + ((nn < nt) ? nn : 0)];
+    }
     d4 X0[NT];
 #pragma unroll
     for (int a = 0; a < NT; ++a)
@@ -203,13 +209,24 @@ __device__ void quad_bwd_mfma_body(const EngineView& ev, double* sm) {
   const double inv_s2 = 1.0 / p.s2;
 
   const int ntiles = (Q + 15) >> 4;
+  // inputs of the NEXT tile are fetched one iteration ahead (global latency hidden behind the MFMA chain)
+  double tq_n = 0.0, gm_n = 0.0, gv_n = 0.0;
+  if (wave < ntiles) {
+    const int nn = 16 * wave + li;
+    const long long gi = (long long)r * Q + ((nn < Q) ? nn : 0);
+    tq_n = ev.tq[gi];
+    gm_n = (nn < Q) ? ev.gmuq[gi * K + k] : 0.0;
+    gv_n = (nn < Q) ? ev.gvarq[gi * K + k] : 0.0;
+  }
   for (int tile = wave; tile < ntiles; tile += 4) {
-    const int node = 16 * tile + li;
-    const bool ok = node < Q;
-    const long long gi = (long long)r * Q + (ok ? node : 0);
-    const double tq = ev.tq[gi];
-    const double gm = ok ? ev.gmuq[gi * K + k] : 0.0;
-    const double gvv = ok ? ev.gvarq[gi * K + k] : 0.0;
+    const double tq = tq_n, gm = gm_n, gvv = gv_n;
+    if (tile + 4 < ntiles) {
+      const int nn = 16 * (tile + 4) + li;
+      const long long gi = (long long)r * Q + ((nn < Q) ? nn : 0);
+      tq_n = ev.tq[gi];
+      gm_n = (nn < Q) ? ev.gmuq[gi * K + k] : 0.0;
+      gv_n = (nn < Q) ? ev.gvarq[gi * K + k] : 0.0;
+    }
     double stq = 0.0, ctq = 0.0;
     if (KT == SV_PERIODIC) sv_sincos_quarter(tq * p.q4, stq, ctq);
     int jo = lg;

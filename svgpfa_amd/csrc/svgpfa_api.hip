@@ -77,11 +77,6 @@ static int dalloc(svgpfa_engine* e, T** p, size_t n) {
 
 static size_t lds_build(int M, int pack) { return ((size_t)2 * M * (M + 1) + 64) * 8 * pack; }
 static size_t lds_prep(int M, int pack) { return ((size_t)M * (M + 1) + 128) * 8 * pack; }
-static size_t lds_times(int M) { return ((size_t)2 * M * (M + 1) + 128 * (M + 1) + 128 + 768) * 8; }
-static size_t lds_qbwd(int M) {
-  int QB = (M <= 32) ? 64 : 32;
-  return ((size_t)2 * M * (M + 1) + (size_t)3 * QB * (M + 1) + 64 * 5 + 4) * 8;
-}
 static size_t lds_times_mfma(int NT) {
   size_t MP = 16 * NT, LD = MP + 2;
   return (2 * MP * LD + 2 * MP) * 8;
