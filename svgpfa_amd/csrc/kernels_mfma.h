@@ -80,14 +80,12 @@ __device__ __forceinline__ void load_factors(const EngineView& ev, const LatentM
 // svPosteriorOnLatents.py:185-216, :265-300).  grid = R*K blocks of 256 threads; each wavefront
 // walks tiles of 16 time points.  Output element (time gi, latent k) at gi*os_t + k*os_k.
 template <int NT, int KT>
-__device__ void times_fwd_body(const EngineView& ev, const double* times, const long long* toff, int nper,
-                               double* mu_out, double* var_out, long long os_t, long long os_k,
-                               int want_var, double* sm) {
+__device__ void times_fwd_body(const EngineView& ev, const int r, const int k, const double* times,
+                               const long long* toff, int nper, double* mu_out, double* var_out, long long os_t,
+                               long long os_k, int want_var, double* sm) {
   constexpr int MP = 16 * NT, LD = MP + 2;
-  const int item = blockIdx.x, tid = threadIdx.x;
+  const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6, li = lane & 15, lg = lane >> 4;
-  const int nk = ev.ntype[KT];
-  const int r = item / nk, k = ev.klist[KT][item % nk];
   const LatentMeta m = ev.meta[k];
   double* Li = sm;
   double* Vl = Li + MP * LD;
@@ -153,25 +151,44 @@ __device__ void times_fwd_body(const EngineView& ev, const double* times, const 
   }
 }
 
+// Block -> (trial, latent).  KT = SV_RBF / SV_PERIODIC: one launch per covariance type over that type's
+// latents (best occupancy at full size).  KT = SV_ANYTYPE: one launch over all latents, type resolved per
+// block (fewer single-round kernels on small shards).
+#define SV_ANYTYPE 2
+template <int KT>
+__device__ __forceinline__ void block_item(const EngineView& ev, int& r, int& k) {
+  if (KT == SV_ANYTYPE) {
+    r = blockIdx.x / ev.K;
+    k = blockIdx.x % ev.K;
+  } else {
+    const int nk = ev.ntype[KT];
+    r = blockIdx.x / nk;
+    k = ev.klist[KT][blockIdx.x % nk];
+  }
+}
+
 template <int NT, int KT>
 __global__ __launch_bounds__(256) void k_times_fwd_mfma(EngineView ev, const double* times,
                                                         const long long* toff, int nper, double* mu_out,
                                                         double* var_out, long long os_t, long long os_k,
                                                         int want_var) {
   extern __shared__ double sm[];
-  times_fwd_body<NT, KT>(ev, times, toff, nper, mu_out, var_out, os_t, os_k, want_var, sm);
+  int r, k;
+  block_item<KT>(ev, r, k);
+  if (KT == SV_RBF || (KT == SV_ANYTYPE && ev.meta[k].ktype == SV_RBF))
+    times_fwd_body<NT, SV_RBF>(ev, r, k, times, toff, nper, mu_out, var_out, os_t, os_k, want_var, sm);
+  else
+    times_fwd_body<NT, SV_PERIODIC>(ev, r, k, times, toff, nper, mu_out, var_out, os_t, os_k, want_var, sm);
 }
 
 // ------------------------------------------------------------------------- k_quad_bwd_mfma
 // Adjoints of the quadrature term wrt ut (gt), Vt Vt^T (Gt) and -- FULL -- the direct dependence
 // on Z / theta through kappa(t_q, Z).  grid = R*K blocks of 256 threads.
 template <int NT, int KT, bool FULL>
-__device__ void quad_bwd_mfma_body(const EngineView& ev, double* sm) {
+__device__ void quad_bwd_mfma_body(const EngineView& ev, const int r, const int k, double* sm) {
   constexpr int MP = 16 * NT, LD = MP + 2, NTRI = NT * (NT + 1) / 2;
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6, li = lane & 15, lg = lane >> 4;
-  const int nk = ev.ntype[KT];
-  const int r = blockIdx.x / nk, k = ev.klist[KT][blockIdx.x % nk];
   const int item = r * ev.K + k;
   const LatentMeta m = ev.meta[k];
   const int M = m.M, Q = ev.Q, K = ev.K;
@@ -368,7 +385,12 @@ __device__ void quad_bwd_mfma_body(const EngineView& ev, double* sm) {
 template <int NT, int KT, bool FULL>
 __global__ __launch_bounds__(256) void k_quad_bwd_mfma(EngineView ev) {
   extern __shared__ double sm[];
-  quad_bwd_mfma_body<NT, KT, FULL>(ev, sm);
+  int r, k;
+  block_item<KT>(ev, r, k);
+  if (KT == SV_RBF || (KT == SV_ANYTYPE && ev.meta[k].ktype == SV_RBF))
+    quad_bwd_mfma_body<NT, SV_RBF, FULL>(ev, r, k, sm);
+  else
+    quad_bwd_mfma_body<NT, SV_PERIODIC, FULL>(ev, r, k, sm);
 }
 
 // ------------------------------------------------------------------------------ k_bwd_mfma
@@ -376,11 +398,10 @@ __global__ __launch_bounds__(256) void k_quad_bwd_mfma(EngineView ev) {
 // One wavefront per item; every M x M product runs on the f64 MFMA with the left operand read
 // from LDS as A fragments and the right operand held as register tiles, one 16-column panel at a time.
 template <int NT, int KT>
-__device__ void bwd_mfma_body(const EngineView& ev, const LatentPtrs pt, unsigned mask, double* sm) {
+__device__ void bwd_mfma_body(const EngineView& ev, const int r, const int k, const LatentPtrs pt, unsigned mask,
+                              double* sm) {
   constexpr int MP = 16 * NT, LD = MP + 2;
   const int lane = threadIdx.x, li = lane & 15, lg = lane >> 4;
-  const int nk = ev.ntype[KT];
-  const int r = blockIdx.x / nk, k = ev.klist[KT][blockIdx.x % nk];
   const int item = r * ev.K + k;
   const LatentMeta m = ev.meta[k];
   const int M = m.M;

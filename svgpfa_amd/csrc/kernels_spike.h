@@ -82,7 +82,7 @@ __device__ void spike_body(const EngineView& ev, const double* __restrict__ C, i
     mu[i] = 0.0;
     if (KT == SV_PERIODIC) sv_sincos_quarter(ts[i], st[i], ct[i]);
   }
-  double* zsc = red + NV * 8 * 65;   // 3 * 64 doubles: scaled z, and (periodic) sin / cos of its phase
+  double* zsc = red + 4 * 8 * 65;    // 3 * 64 doubles behind the (maximal) reduction area: scaled z, sin / cos of its phase
   if (lane < M) {
     const double zq = z[lane] * sc;
     zsc[lane] = zq;
@@ -200,14 +200,23 @@ __device__ void spike_body(const EngineView& ev, const double* __restrict__ C, i
   }
 }
 
+// KT = SV_RBF / SV_PERIODIC: one launch per covariance type; KT = 2 (any): type resolved per block (small shards).
 template <int KT, bool FULL>
 __global__ __launch_bounds__(64) void k_spike(EngineView ev, const double* __restrict__ C) {
   constexpr int NV = FULL ? (KT == SV_RBF ? 3 : 4) : 1;
-  __shared__ double red[NV * 8 * 65 + 3 * 64];
+  __shared__ double red[4 * 8 * 65 + 3 * 64];
   const int item = blockIdx.x;
-  const int nk = ev.ntype[KT];
-  const int ch = item / nk, k = ev.klist[KT][item % nk];
-  spike_body<KT, FULL>(ev, C, ch, k, red);
+  if (KT == 2) {
+    const int ch = item / ev.K, k = item % ev.K;
+    if (ev.meta[k].ktype == SV_RBF)
+      spike_body<SV_RBF, FULL>(ev, C, ch, k, red);
+    else
+      spike_body<SV_PERIODIC, FULL>(ev, C, ch, k, red);
+  } else {
+    const int nk = ev.ntype[KT == 2 ? 0 : KT];
+    const int ch = item / nk, k = ev.klist[KT == 2 ? 0 : KT][item % nk];
+    spike_body<(KT == 2 ? SV_RBF : KT), FULL>(ev, C, ch, k, red);
+  }
 }
 
 // Mseg[n][k] = sum over all local spikes of neuron n of mu_k(t_s)   (embedding M-step path)

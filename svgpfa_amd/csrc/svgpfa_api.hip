@@ -35,10 +35,16 @@ struct svgpfa_engine {
   size_t ev_used = 0;
   std::string err;
   int* status_host = nullptr;  // pinned
-  hipStream_t side = nullptr;  // the spike pass runs here, concurrently with the quadrature chain
-  bool overlap = false;        // SVGPFA_OVERLAP=1: spike pass on a side stream (measured slower: both
-                               // kernels fill the chip, so they time-slice instead of co-issuing)
-  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+  // Concurrency for SMALL shards (strong scaling): when a shard's grids are below ~2 GPU rounds the
+  // pipeline is a chain of per-kernel latency floors, so the spike pass (2 streams, one per covariance
+  // type) and the periodic-type MFMA kernels (1 stream) run beside the main chain.  At full size both
+  // sides fill the chip and time-slice, which measured SLOWER, hence the size threshold.
+  // SVGPFA_OVERLAP = 0 never (default: measured no gain on MI355X / ROCm 7.2) | 1 always | 2 automatic
+  hipStream_t s_spk[2] = {nullptr, nullptr}, s_per = nullptr;
+  int overlap_mode = 0;
+  long long overlap_thresh = 8192;
+  long long merge_items = 2048, merge_spike_blocks = 8192;   // merged-type launches below these grid sizes
+  hipEvent_t ev_prep = nullptr, ev_t1 = nullptr, ev_ell = nullptr, ev_spk[2] = {nullptr, nullptr}, ev_b1 = nullptr;
 };
 
 #define HIPCHK(e, call)                                                                  \
@@ -120,10 +126,31 @@ __global__ __launch_bounds__(64) void k_prep_entry(EngineView ev, PtrTable pt) {
 template <int NT, int KT>
 __global__ __launch_bounds__(64) void k_bwd_mfma(EngineView ev, PtrTable pt, unsigned mask) {
   extern __shared__ double sm[];
-  const int k = ev.klist[KT][blockIdx.x % ev.ntype[KT]];
-  bwd_mfma_body<NT, KT>(ev, pt.p[k], mask, sm);
+  int r, k;
+  block_item<KT>(ev, r, k);
+  if (KT == SV_RBF || (KT == SV_ANYTYPE && ev.meta[k].ktype == SV_RBF))
+    bwd_mfma_body<NT, SV_RBF>(ev, r, k, pt.p[k], mask, sm);
+  else
+    bwd_mfma_body<NT, SV_PERIODIC>(ev, r, k, pt.p[k], mask, sm);
 }
 // launch STMT once per covariance type that has latents; KT_ is the compile-time type
+// Launch over covariance types.  merged = true: ONE launch with KT_ = SV_ANYTYPE over all latents (NKT_ = K);
+// merged = false: one launch per type that has latents (NKT_ = that type's latent count).
+#define FOR_TYPES(e, merged, ST0, ST1, ...)                                                                  \
+  do {                                                                                                       \
+    if (merged) {                                                                                            \
+      constexpr int KT_ = SV_ANYTYPE; const int NKT_ = (e)->v.K; hipStream_t ST_ = (ST0); __VA_ARGS__;        \
+    } else {                                                                                                 \
+      if ((e)->v.ntype[0] > 0) { constexpr int KT_ = SV_RBF; const int NKT_ = (e)->v.ntype[0]; hipStream_t ST_ = (ST0); __VA_ARGS__; }      \
+      if ((e)->v.ntype[1] > 0) { constexpr int KT_ = SV_PERIODIC; const int NKT_ = (e)->v.ntype[1]; hipStream_t ST_ = (ST1); __VA_ARGS__; } \
+    }                                                                                                        \
+  } while (0)
+// same, with an explicit stream per covariance type (ST_ inside the statement)
+#define FOR_KT_ST(e, ST0, ST1, ...)                                                              \
+  do {                                                                                           \
+    if ((e)->v.ntype[0] > 0) { constexpr int KT_ = SV_RBF; hipStream_t ST_ = (ST0); __VA_ARGS__; }      \
+    if ((e)->v.ntype[1] > 0) { constexpr int KT_ = SV_PERIODIC; hipStream_t ST_ = (ST1); __VA_ARGS__; } \
+  } while (0)
 #define FOR_KT(e, ...)                                                        \
   do {                                                                        \
     if ((e)->v.ntype[0] > 0) { constexpr int KT_ = SV_RBF; __VA_ARGS__; }      \
@@ -235,13 +262,27 @@ int svgpfa_create(const svgpfa_dims* d, int device, svgpfa_engine** out) {
   HIPCHK(e, hipMemset(v.gZq, 0, sizeof(double) * e->totM));
   HIPCHK(e, hipMemset(v.gthq, 0, sizeof(double) * v.R * v.K * 2));
   HIPCHK(e, hipHostMalloc((void**)&e->status_host, sizeof(int)));
-  HIPCHK(e, hipStreamCreateWithFlags(&e->side, hipStreamNonBlocking));
+  {
+    // the spike pass is bulk throughput work: lowest priority, so that the short dependent MFMA chain
+    // (whose kernels are single-round latency floors on small shards) gets wave slots first
+    int lo = 0, hi = 0;
+    HIPCHK(e, hipDeviceGetStreamPriorityRange(&lo, &hi));
+    HIPCHK(e, hipStreamCreateWithPriority(&e->s_spk[0], hipStreamNonBlocking, lo));
+    HIPCHK(e, hipStreamCreateWithPriority(&e->s_spk[1], hipStreamNonBlocking, lo));
+    HIPCHK(e, hipStreamCreateWithPriority(&e->s_per, hipStreamNonBlocking, hi));
+  }
   {
     const char* ov = getenv("SVGPFA_OVERLAP");
-    e->overlap = (ov && ov[0] == '1');
+    if (ov && ov[0] >= '0' && ov[0] <= '2') e->overlap_mode = ov[0] - '0';
+    const char* th = getenv("SVGPFA_OVERLAP_THRESH");
+    if (th) e->overlap_thresh = atoll(th);
+    const char* mi = getenv("SVGPFA_MERGE_ITEMS");
+    if (mi) e->merge_items = atoll(mi);
+    const char* ms = getenv("SVGPFA_MERGE_SPIKE_BLOCKS");
+    if (ms) e->merge_spike_blocks = atoll(ms);
   }
-  HIPCHK(e, hipEventCreateWithFlags(&e->ev_fork, hipEventDisableTiming));
-  HIPCHK(e, hipEventCreateWithFlags(&e->ev_join, hipEventDisableTiming));
+  for (hipEvent_t* ev : {&e->ev_prep, &e->ev_t1, &e->ev_ell, &e->ev_spk[0], &e->ev_spk[1], &e->ev_b1})
+    HIPCHK(e, hipEventCreateWithFlags(ev, hipEventDisableTiming));
 
   int rc;
   e->pack = 1;   // two items per wavefront (pack = 2) measured no faster: these kernels are latency-bound per item
@@ -254,6 +295,11 @@ int svgpfa_create(const svgpfa_dims* d, int device, svgpfa_engine** out) {
   }
   rc = 0;
   DISPATCH_NT(e->NT, FOR_KT(e, if (!rc) rc = allow_lds(e, (k_bwd_mfma<NT_, KT_>), lds_bwd_mfma(NT_))));
+  if (rc) return rc;
+  DISPATCH_NT(e->NT, rc = allow_lds(e, (k_bwd_mfma<NT_, SV_ANYTYPE>), lds_bwd_mfma(NT_));
+              if (!rc) rc = allow_lds(e, (k_times_fwd_mfma<NT_, SV_ANYTYPE>), lds_times_mfma(NT_));
+              if (!rc) rc = allow_lds(e, (k_quad_bwd_mfma<NT_, SV_ANYTYPE, true>), lds_qbwd_mfma(NT_));
+              if (!rc) rc = allow_lds(e, (k_quad_bwd_mfma<NT_, SV_ANYTYPE, false>), lds_qbwd_mfma(NT_)));
   if (rc) return rc;
   DISPATCH_NT(e->NT, FOR_KT(e, if (!rc) rc = allow_lds(e, (k_times_fwd_mfma<NT_, KT_>), lds_times_mfma(NT_))));
   if (rc) return rc;
@@ -284,9 +330,10 @@ void svgpfa_destroy(svgpfa_engine* e) {
   (void)hipDeviceSynchronize();
   for (void* p : e->allocs) (void)hipFree(p);
   if (e->status_host) (void)hipHostFree(e->status_host);
-  if (e->side) (void)hipStreamDestroy(e->side);
-  if (e->ev_fork) (void)hipEventDestroy(e->ev_fork);
-  if (e->ev_join) (void)hipEventDestroy(e->ev_join);
+  for (hipStream_t st : {e->s_spk[0], e->s_spk[1], e->s_per})
+    if (st) (void)hipStreamDestroy(st);
+  for (hipEvent_t ev : {e->ev_prep, e->ev_t1, e->ev_ell, e->ev_spk[0], e->ev_spk[1], e->ev_b1})
+    if (ev) (void)hipEventDestroy(ev);
   for (auto& pr : e->ev_pool) {
     (void)hipEventDestroy(pr.first);
     (void)hipEventDestroy(pr.second);
@@ -500,11 +547,15 @@ static int launch_quad_ell(svgpfa_engine* e, const double* C, const double* d, i
 }
 
 static int launch_times(svgpfa_engine* e, const double* times, const long long* toff, int nper, double* mu,
-                        double* var, long long os_t, long long os_k, int want_var) {
+                        double* var, long long os_t, long long os_k, int want_var, hipStream_t st0 = nullptr,
+                        hipStream_t st1 = nullptr) {
   EngineView& v = e->v;
-  DISPATCH_NT(e->NT, FOR_KT(e, hipLaunchKernelGGL((k_times_fwd_mfma<NT_, KT_>), dim3(v.R * v.ntype[KT_]), dim3(256),
-                                                  lds_times_mfma(NT_), e->stream, v, times, toff, nper, mu, var,
-                                                  os_t, os_k, want_var)));
+  if (!st0) st0 = e->stream;
+  if (!st1) st1 = e->stream;
+  const bool merged = (long long)v.R * v.K <= e->merge_items;
+  DISPATCH_NT(e->NT, FOR_TYPES(e, merged, st0, st1, hipLaunchKernelGGL((k_times_fwd_mfma<NT_, KT_>), dim3(v.R * NKT_),
+                                                                     dim3(256), lds_times_mfma(NT_), ST_, v, times, toff,
+                                                                     nper, mu, var, os_t, os_k, want_var)));
   HIPCHK(e, hipGetLastError());
   return SVGPFA_OK;
 }
@@ -546,15 +597,22 @@ int svgpfa_elbo(svgpfa_engine* e, const double* const* mean, const double* const
   const bool full = (mask & (2u | 4u | 8u)) != 0;
 
   launch_prep(e, pt);
-  // fork: the spike pass (fp64 VALU bound) needs only a = Kzz^-1 m from k_prep; it runs on the side
-  // stream while the quadrature chain (f64 MFMA) runs on the main stream; k_bwd joins both.
-  hipStream_t sps = e->overlap ? e->side : e->stream;
+  const long long spk_blocks = (long long)v.nchunks * std::max(v.ntype[0], v.ntype[1]);
+  const bool ov = e->overlap_mode == 1 || (e->overlap_mode == 2 && spk_blocks <= e->overlap_thresh);
+  const bool mitems = !ov && (long long)v.R * v.K <= e->merge_items;   // merged-type launches on small shards
+  hipStream_t sm = e->stream;
+  hipStream_t sp = ov ? e->s_per : sm;                      // periodic-type MFMA kernels
+  hipStream_t sk[2] = {ov ? e->s_spk[0] : sm, ov ? e->s_spk[1] : sm};   // spike pass per type
+  if (ov) {
+    HIPCHK(e, hipEventRecord(e->ev_prep, sm));
+    HIPCHK(e, hipStreamWaitEvent(sp, e->ev_prep, 0));
+    HIPCHK(e, hipStreamWaitEvent(sk[0], e->ev_prep, 0));
+    HIPCHK(e, hipStreamWaitEvent(sk[1], e->ev_prep, 0));
+  }
+  // ---- spike pass (fp64 VALU bound): needs only a = Kzz^-1 m from k_prep
   if (v.nchunks > 0) {
-    if (e->overlap) {
-      HIPCHK(e, hipEventRecord(e->ev_fork, e->stream));
-      HIPCHK(e, hipStreamWaitEvent(e->side, e->ev_fork, 0));
-    }
     std::pair<hipEvent_t, hipEvent_t>* evp = nullptr;
+    const int tfirst = v.ntype[0] > 0 ? 0 : 1, tlast = v.ntype[1] > 0 ? 1 : 0;
     if (e->timing) {
       if (e->ev_used == e->ev_pool.size()) {
         std::pair<hipEvent_t, hipEvent_t> pr;
@@ -563,30 +621,51 @@ int svgpfa_elbo(svgpfa_engine* e, const double* const* mean, const double* const
         e->ev_pool.push_back(pr);
       }
       evp = &e->ev_pool[e->ev_used++];
-      HIPCHK(e, hipEventRecord(evp->first, sps));
+      HIPCHK(e, hipEventRecord(evp->first, sk[tfirst]));
     }
+    const bool mspk = !ov && (long long)v.nchunks * v.K <= e->merge_spike_blocks;
     if (full) {
-      FOR_KT(e, hipLaunchKernelGGL((k_spike<KT_, true>), dim3(v.nchunks * v.ntype[KT_]), dim3(64), 0, sps, v, C));
+      FOR_TYPES(e, mspk, sk[0], sk[1], hipLaunchKernelGGL((k_spike<KT_, true>), dim3(v.nchunks * NKT_), dim3(64), 0, ST_, v, C));
     } else {
-      FOR_KT(e, hipLaunchKernelGGL((k_spike<KT_, false>), dim3(v.nchunks * v.ntype[KT_]), dim3(64), 0, sps, v, C));
+      FOR_TYPES(e, mspk, sk[0], sk[1], hipLaunchKernelGGL((k_spike<KT_, false>), dim3(v.nchunks * NKT_), dim3(64), 0, ST_, v, C));
     }
-    if (evp) HIPCHK(e, hipEventRecord(evp->second, sps));
-    if (e->overlap) HIPCHK(e, hipEventRecord(e->ev_join, e->side));
+    if (evp) HIPCHK(e, hipEventRecord(evp->second, sk[tlast]));
+    if (ov) {
+      HIPCHK(e, hipEventRecord(e->ev_spk[0], sk[0]));
+      HIPCHK(e, hipEventRecord(e->ev_spk[1], sk[1]));
+    }
   }
-  if ((rc = launch_times(e, v.tq, nullptr, v.Q, v.muq, v.varq, (long long)v.K, 1LL, 1))) return rc;
+  // ---- quadrature chain (f64 MFMA): posterior stats -> ELL term -> adjoints
+  if ((rc = launch_times(e, v.tq, nullptr, v.Q, v.muq, v.varq, (long long)v.K, 1LL, 1, sm, sp))) return rc;
+  if (ov) {
+    HIPCHK(e, hipEventRecord(e->ev_t1, sp));
+    HIPCHK(e, hipStreamWaitEvent(sm, e->ev_t1, 0));
+  }
   if ((rc = launch_quad_ell(e, C, d, (mask & 2u) ? 1 : 0, want_lat ? 1 : 0))) return rc;
+  if (ov) {
+    HIPCHK(e, hipEventRecord(e->ev_ell, sm));
+    HIPCHK(e, hipStreamWaitEvent(sp, e->ev_ell, 0));
+  }
   if (want_lat) {
     if (mask & (4u | 8u)) {
-      DISPATCH_NT(e->NT, FOR_KT(e, hipLaunchKernelGGL((k_quad_bwd_mfma<NT_, KT_, true>), dim3(v.R * v.ntype[KT_]),
-                                                      dim3(256), lds_qbwd_mfma(NT_), e->stream, v)));
+      DISPATCH_NT(e->NT, FOR_TYPES(e, mitems, sm, sp, hipLaunchKernelGGL((k_quad_bwd_mfma<NT_, KT_, true>), dim3(v.R * NKT_),
+                                                                         dim3(256), lds_qbwd_mfma(NT_), ST_, v)));
     } else {
-      DISPATCH_NT(e->NT, FOR_KT(e, hipLaunchKernelGGL((k_quad_bwd_mfma<NT_, KT_, false>), dim3(v.R * v.ntype[KT_]),
-                                                      dim3(256), lds_qbwd_mfma(NT_), e->stream, v)));
+      DISPATCH_NT(e->NT, FOR_TYPES(e, mitems, sm, sp, hipLaunchKernelGGL((k_quad_bwd_mfma<NT_, KT_, false>), dim3(v.R * NKT_),
+                                                                         dim3(256), lds_qbwd_mfma(NT_), ST_, v)));
     }
   }
-  if (v.nchunks > 0 && e->overlap) HIPCHK(e, hipStreamWaitEvent(e->stream, e->ev_join, 0));
-  DISPATCH_NT(e->NT, FOR_KT(e, hipLaunchKernelGGL((k_bwd_mfma<NT_, KT_>), dim3(v.R * v.ntype[KT_]), dim3(64),
-                                                  lds_bwd_mfma(NT_), e->stream, v, pt, mask)));
+  // ---- join the spike pass per type, per-item backward, then the fixed-order reductions
+  if (ov && v.nchunks > 0) {
+    HIPCHK(e, hipStreamWaitEvent(sm, e->ev_spk[0], 0));
+    HIPCHK(e, hipStreamWaitEvent(sp, e->ev_spk[1], 0));
+  }
+  DISPATCH_NT(e->NT, FOR_TYPES(e, mitems, sm, sp, hipLaunchKernelGGL((k_bwd_mfma<NT_, KT_>), dim3(v.R * NKT_), dim3(64),
+                                                                     lds_bwd_mfma(NT_), ST_, v, pt, mask)));
+  if (ov) {
+    HIPCHK(e, hipEventRecord(e->ev_b1, sp));
+    HIPCHK(e, hipStreamWaitEvent(sm, e->ev_b1, 0));
+  }
   int nfin = (v.N * v.K + 31) / 32 + (v.N + 31) / 32 + (v.nth_total + 31) / 32 + 1;
   hipLaunchKernelGGL(k_finalize, dim3(nfin), dim3(256), 0, e->stream, v, C, d, mask, shared);
   HIPCHK(e, hipGetLastError());

@@ -160,6 +160,27 @@ def test_not_positive_definite_raises():
     assert ei.value.code == _lib.ERR_NOT_PD
 
 
+def test_launch_strategies_agree(monkeypatch):
+    """Per-covariance-type launches (full-size strategy), merged-type launches (small-shard strategy) and the
+    multi-stream variant must give the same numbers (fixed-order reductions: bit-identical)."""
+    prob = synthetic.make_problem(R=5, N=12, K=4, M=[10, 12, 9, 16], kernels="mix", seed=13, n_quad=60, rate=25.0, jitter=1.0)
+    outs = []
+    for env in ({"SVGPFA_MERGE_ITEMS": "0", "SVGPFA_MERGE_SPIKE_BLOCKS": "0"}, {"SVGPFA_MERGE_ITEMS": "1000000", "SVGPFA_MERGE_SPIKE_BLOCKS": "1000000"},
+                {"SVGPFA_OVERLAP": "1"}):
+        for k in ("SVGPFA_MERGE_ITEMS", "SVGPFA_MERGE_SPIKE_BLOCKS", "SVGPFA_OVERLAP"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        eng, P = _engine(prob)
+        shared, gm, gc, gz = eng.elbo(P["mean"], P["cholVecs"], P["C"], P["d"], 15)
+        eng.sync()
+        outs.append([shared.clone()] + [t.clone() for t in gm + gc + gz])
+        eng.close()
+    for other in outs[1:]:
+        for a, b in zip(outs[0], other):
+            assert torch.equal(a, b)
+
+
 def test_repeatable_bitwise():
     """Fixed-order reductions: two evaluations of the same inputs are bit-identical."""
     prob = synthetic.make_problem(R=6, N=20, K=3, M=12, kernels="mix", seed=11, n_quad=100, rate=40.0, jitter=1.0)

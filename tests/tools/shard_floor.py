@@ -1,0 +1,26 @@
+"""Per-step time of one rank's shard at 1/2/4/8-way sharding of cfg3 (emulated on one GPU, no all-reduce):
+exposes the host-side floor (Python marshalling + kernel launches) that limits strong scaling."""
+import os, sys, time
+sys.path.insert(0, os.path.join(os.path.dirname(__file__), "..", ".."))
+import torch
+from svgpfa_amd.engine import engine_from_problem
+from svgpfa_amd.utils import synthetic
+full = synthetic.make_config("cfg3")
+for world, mode in [(w, m) for w in (1, 2, 4, 8) for m in ("0", "1")]:
+    os.environ["SVGPFA_OVERLAP"] = mode
+    prob = synthetic.shard_trials(full, 0, world)
+    eng, P = engine_from_problem(prob)
+    shared = torch.empty(eng.shared_len, dtype=torch.float64, device=eng.device)
+    grads = eng.alloc_grads(15)
+    def step():
+        eng.build_kernels(P["Z"], P["theta"])
+        eng.elbo(P["mean"], P["cholVecs"], P["C"], P["d"], 15, out=shared, grads=grads)
+    for _ in range(5): step()
+    eng.sync()
+    t0 = time.perf_counter()
+    for _ in range(50): step()
+    t_enq = time.perf_counter() - t0
+    torch.cuda.synchronize()
+    t = time.perf_counter() - t0
+    print(f"world {world} overlap {mode}: trials {prob['R']:4d}  step {1e3*t/50:.3f} ms  (host enqueue only {1e3*t_enq/50:.3f} ms)  elbo {float(shared[0]):.6f}")
+    eng.close()
