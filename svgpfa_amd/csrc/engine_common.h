@@ -104,6 +104,13 @@ struct EngineView {
 //   d kappa / d x2      = ktil * bz * cz
 //   d kappa / d theta_0 = ktil * b0 * c0        (lengthscale, unscaled parameter)
 //   d kappa / d theta_1 = ktil * b1 * c1        (period, unscaled parameter; periodic only)
+// LDS hand-off between lanes of ONE wavefront (no s_barrier needed)
+__device__ __forceinline__ void lds_wave_fence() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
+
 struct KPar {
   double s2, h, ip, cz, c0, c1;
   double h2;   // base-2 exponent scale: RBF h log2(e); periodic h log2(e) / 2

@@ -191,3 +191,97 @@ __device__ void k_prep_body(const EngineView& ev, const LatentPtrs* ptab, double
   if (l == 0 && im.active) ev.klpart[item] = 0.5 * (fro + quad + ld - (double)M);
 }
 
+// ------------------------------------------------------------------------------ k_build_reg
+// Register-resident build for M <= MP (MP = 16 or 32): 64 / MP (trial, latent) items per wavefront.
+// Lane i of an item holds ROW i of Kzz + eps I (then of its Cholesky factor L) and COLUMN i of Linv = L^-1
+// in VGPRs.  Factorisation and inverse advance together, one row j per step: both need exactly row j of L
+// (L[j][q], q < j), which every lane reads from a small LDS copy with one uniform-address (broadcast)
+// ds_read_b64 per value; the pivot is broadcast with a wave shuffle.  One wave per block, so the only
+// synchronisation is a wave-level LDS fence; loops are fully unrolled (static register indices).
+// Padding rows / columns are the identity.  write_aux = 1 additionally stores Kzz and L (only the
+// KernelsMatricesStore getters read them).
+template <int MP>
+__global__ __launch_bounds__(64) void k_build_reg(EngineView ev, int write_aux) {
+  constexpr int IPW = 64 / MP;
+  __shared__ double Lt[IPW][MP][MP];       // Lt[item][q][i] = L[i][q]  (column-major: conflict-free writes)
+  const int lane = threadIdx.x, sub = lane / MP, i = lane % MP, lbase = lane - i;
+  const int rp = (ev.R + IPW - 1) / IPW;
+  const int k = blockIdx.x / rp;
+  int r = (blockIdx.x % rp) * IPW + sub;
+  const bool active = r < ev.R;
+  if (!active) r = ev.R - 1;
+  const LatentMeta m = ev.meta[k];
+  const int M = m.M;
+  const KPar p = make_kpar(m, ev.theta + 2 * k);
+  const long long base = m.offMM + (long long)r * M * M;
+  const double* z = ev.Zs + m.offM + (long long)r * M;
+  const bool rowok = i < M;
+  const double zi = rowok ? z[i] : 0.0;
+
+  double a[MP];
+  if (m.ktype == SV_RBF) {
+#pragma unroll
+    for (int q = 0; q < MP; ++q) {
+      const double d = zi - __shfl(zi, lbase + q, 64);
+      a[q] = p.s2 * sv_exp2_neg(-(d * d) * p.h2);
+      if ((q & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+    }
+  } else {   // cos(2 pi (zi - zq) / p) by angle addition: one sincos per lane
+    double si, ci;
+    sv_sincos_quarter(zi * p.q4, si, ci);
+#pragma unroll
+    for (int q = 0; q < MP; ++q) {
+      const double cs = fma(ci, __shfl(ci, lbase + q, 64), si * __shfl(si, lbase + q, 64));
+      a[q] = p.s2 * sv_exp2_neg(fmin(fma(cs, p.h2, -p.h2), 0.0));
+      if ((q & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+#pragma unroll
+  for (int q = 0; q < MP; ++q) {
+    const bool in = rowok && q < M;
+    a[q] = (q == i) ? (in ? p.s2 + ev.reg : 1.0) : (in ? a[q] : 0.0);
+  }
+  if (write_aux && active && rowok) {
+#pragma unroll
+    for (int q = 0; q < MP; ++q)
+      if (q < M) ev.Kzz[base + i * M + q] = a[q];
+  }
+
+  // step j: column j of L (all rows i >= j) and row j of Linv (all columns), pivots through v_rsq_f64 + 2 Newton
+  double x[MP];
+  bool bad = false;
+  const double* Lrow = &Lt[sub][0][0];
+#pragma unroll
+  for (int j = 0; j < MP; ++j) {
+    double s = a[j];
+    double sx = (i == j) ? 1.0 : 0.0;
+#pragma unroll
+    for (int q = 0; q < j; ++q) {
+      const double l = Lrow[q * MP + j];        // L[j][q]: same address in every lane of the item
+      s = fma(-a[q], l, s);
+      sx = fma(-l, x[q], sx);                   // lanes c > j: x[q] = 0 for q < c, so X[j][c] stays 0
+    }
+    const double d = __shfl(s, lbase + j, 64);
+    if (!(d > 0.0)) bad = true;
+    double ri = __builtin_amdgcn_rsq(d);
+    ri = ri * fma(-0.5 * d * ri, ri, 1.5);
+    ri = ri * fma(-0.5 * d * ri, ri, 1.5);
+    a[j] = (i > j) ? s * ri : ((i == j) ? d * ri : 0.0);
+    x[j] = sx * ri;
+    Lt[sub][j][i] = a[j];
+    lds_wave_fence();
+    __builtin_amdgcn_sched_barrier(0);          // keep later rows' LDS reads from being hoisted (register pressure)
+  }
+  if (bad && i == 0 && active) atomicCAS(ev.status, 0, 1 + r * ev.K + k);
+
+#pragma unroll
+  for (int q = 0; q < MP; ++q) asm volatile("" : "+v"(x[q]));   // finish the solve before the (branchy) stores
+  if (active && rowok) {
+#pragma unroll
+    for (int q = 0; q < MP; ++q)
+      if (q < M) {
+        ev.Linv[base + q * M + i] = x[q];                       // column i: lanes write consecutive addresses
+        if (write_aux) ev.L[base + i * M + q] = a[q];            // row i
+      }
+  }
+}

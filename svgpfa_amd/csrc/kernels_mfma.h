@@ -50,11 +50,6 @@ __device__ __forceinline__ double grp4_sum(double x) {    // sum over the 4 lane
   x += __shfl_xor(x, 32, 64);
   return x;
 }
-__device__ __forceinline__ void lds_wave_fence() {
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-  __builtin_amdgcn_wave_barrier();
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-}
 
 template <int NT>
 __device__ __forceinline__ void load_factors(const EngineView& ev, const LatentMeta& m, int r, double* Li,

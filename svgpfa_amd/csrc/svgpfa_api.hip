@@ -30,6 +30,7 @@ struct svgpfa_engine {
   int ell_parts = 0, KKT = 1;  // ell_parts > 0: MFMA GEMM form of the quadrature term (fits LDS)
   long long totM = 0, totMM = 0;  // R*sum M, R*sum M^2
   bool have_quad = false, have_spikes = false, have_kernels = false, have_stats = false;
+  bool aux_valid = false;   // Kzz / L buffers hold the matrices of the current kernel snapshot (getters only)
   bool timing = false;
   std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool;  // event pairs, reused
   size_t ev_used = 0;
@@ -470,6 +471,17 @@ int svgpfa_set_spikes(svgpfa_engine* e, const int64_t* off, const double* times,
   return SVGPFA_OK;
 }
 
+// write_aux: also store Kzz and L (getter path).  M <= 32: register-resident kernel, several items per wave.
+static void launch_build(svgpfa_engine* e, int write_aux) {
+  EngineView& v = e->v;
+  if (e->Mmax <= 16)
+    hipLaunchKernelGGL(k_build_reg<16>, dim3(v.K * ((v.R + 3) / 4)), dim3(64), 0, e->stream, v, write_aux);
+  else if (e->Mmax <= 32)
+    hipLaunchKernelGGL(k_build_reg<32>, dim3(v.K * ((v.R + 1) / 2)), dim3(64), 0, e->stream, v, write_aux);
+  else
+    hipLaunchKernelGGL(k_build<1>, dim3(v.K * v.R), dim3(64), lds_build(e->Mmax, 1), e->stream, v);
+}
+
 int svgpfa_build_kernels(svgpfa_engine* e, const double* const* Z, const double* const* theta) {
   if (!e || !Z || !theta) return SVGPFA_ERR_INVALID;
   EngineView& v = e->v;
@@ -484,10 +496,8 @@ int svgpfa_build_kernels(svgpfa_engine* e, const double* const* Z, const double*
     int gx = std::max(1, std::min(64, (v.R * e->Mmax + 255) / 256));
     hipLaunchKernelGGL(k_snapshot, dim3(gx, v.K), dim3(256), 0, e->stream, v, st);
   }
-  if (e->pack == 2)
-    hipLaunchKernelGGL(k_build<2>, dim3(v.K * ((v.R + 1) / 2)), dim3(64), lds_build(e->Mmax, 2), e->stream, v);
-  else
-    hipLaunchKernelGGL(k_build<1>, dim3(v.K * v.R), dim3(64), lds_build(e->Mmax, 1), e->stream, v);
+  launch_build(e, 0);
+  e->aux_valid = false;
   HIPCHK(e, hipGetLastError());
   e->have_kernels = true;
   e->have_stats = false;
@@ -730,6 +740,11 @@ int svgpfa_predict(svgpfa_engine* e, const double* const* mean, const double* co
 static int get_mm(svgpfa_engine* e, int k, const double* src, double* out) {
   if (!e || !out || k < 0 || k >= e->v.K) return SVGPFA_ERR_INVALID;
   if (!e->have_kernels) FAIL(e, SVGPFA_ERR_STATE, "svgpfa_build_kernels has not been called");
+  if (!e->aux_valid && e->Mmax <= 32) {   // Kzz / L are materialised on demand from the current snapshot
+    launch_build(e, 1);
+    HIPCHK(e, hipGetLastError());
+    e->aux_valid = true;
+  }
   const LatentMeta& m = e->meta[k];
   HIPCHK(e, hipMemcpyAsync(out, src + m.offMM, sizeof(double) * e->v.R * m.M * m.M, hipMemcpyDeviceToDevice, e->stream));
   return SVGPFA_OK;
