@@ -53,7 +53,11 @@ def algorithmic_work(prob, variant):
                                                            for t in prob["kernel_types"])
     bytes_eval = 8 * (S + 2 * R * Q + sum(R * (2 * M + M * (M + 1) // 2) for M in Ms) + N * K + N) \
         + 4 * S + 8 * ngrad + 8
-    return dict(flops_eval=flops_eval, flops_spike=flops_spike, bytes_eval=bytes_eval, kernel_evals=T_fwd)
+    # spike pass, compulsory traffic: spike times + neuron ids once per latent type list are NOT counted twice
+    # (algorithmic = once), whitened factors u~ (M), V~ (M^2) in, P0/P1/P2/P3-style partials (4M) out
+    bytes_spike = 12 * S + 8 * sum(R * (M * M + 5 * M) for M in Ms)
+    return dict(flops_eval=flops_eval, flops_spike=flops_spike, bytes_eval=bytes_eval, bytes_spike=bytes_spike,
+                kernel_evals=T_fwd)
 
 
 def cpu_baseline(config, variant, sample_trials):
@@ -97,6 +101,32 @@ def cpu_baseline(config, variant, sample_trials):
                 sample=f"oracle ({'ALL' if mask == 15 else 'E-step'} closure) on the first {ns} of {R} trials of "
                        f"{config} ({int(off[ns])} spikes), {dt:.2f} s; value = ({ns}/{R}) / time "
                        f"(linear in trials; the reference itself is super-linear, SURVEY 3.4)")
+
+
+def measured_traffic(config, variant, full_mask):
+    """HBM bytes per k_spike launch from the committed PMC digest (profiles/*_pmc.json, made by
+    tests/tools/collect_profiles.sh + digest_profiles.py in separate rocprofv3 --pmc passes of this same
+    command).  Counters cannot be read inside the timed run, so the figure is the latest committed one for
+    the same config / variant; None when there is none."""
+    import glob
+    best = None
+    for f in sorted(glob.glob(os.path.join(REPO, "profiles", "*_pmc.json"))):
+        try:
+            with open(f) as fh:
+                d = json.load(fh)
+        except (OSError, ValueError):
+            continue
+        if d.get("config") != config or d.get("variant") != variant:
+            continue
+        tot, n = 0.0, 0     # the spike pass of one evaluation = the k_spike launches of all covariance types
+        for k, e in d.get("kernels", {}).items():
+            if k.startswith("k_spike<") and k.endswith("true>" if full_mask else "false>") \
+                    and "hbm_read_bytes_raw" in e and "hbm_write_bytes" in e:
+                tot += e["hbm_read_bytes_raw"] + e["hbm_write_bytes"]
+                n += 1
+        if n:
+            best = (tot, os.path.basename(f))
+    return best
 
 
 def main():
@@ -173,6 +203,7 @@ def main():
         work_full = algorithmic_work(full, args.variant)
         ms_per_step = 1e3 * elapsed / args.steps
         achieved = work["flops_spike"] / (spike_avg_ms * 1e-3) / 1e12 if spike_avg_ms > 0 else None
+        traffic = measured_traffic(args.config, args.variant, bool(mask & 14)) if world == 1 else None
         out = {
             "metric": "ELBO+grad evals/sec at (trials,neurons,latents,ind)=(%d,%d,%d,%d)" % (
                 full["R"], full["N"], full["K"], full["Ms"][0]),
@@ -186,7 +217,11 @@ def main():
                        "parallelism": f"trials sharded {world}-way by spike count, 1 RCCL all-reduce/step" if world > 1 else "single GPU"},
             "elbo": elbo,
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": (achieved / FP64_PEAK_TFLOPS) if achieved else None, "traffic": None,
+                         "frac": (achieved / FP64_PEAK_TFLOPS) if achieved else None,
+                         "traffic": traffic[0] if traffic else None,
+                         "traffic_unit": "HBM bytes per spike pass (FETCH_SIZE + WRITE_SIZE of its k_spike launches, separate PMC passes)",
+                         "traffic_source": ("profiles/" + traffic[1]) if traffic else None,
+                         "algorithmic_bytes_per_launch": work.get("bytes_spike"),
                          "kernel": "k_spike<%s>" % ("true" if mask & 14 else "false"),
                          "kernel_avg_ms": spike_avg_ms, "kernel_launches": launches,
                          "algorithmic_flops_per_launch": work["flops_spike"],

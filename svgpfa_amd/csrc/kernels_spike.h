@@ -1,6 +1,6 @@
 // Spike-time pass: the dominant kernel (sum_k R M_k S_r kernel evaluations per ELBO).
 //
-// One wavefront per (spike chunk, latent).  Each lane owns SV_SPL spikes of the chunk (times and
+// One wavefront per (spike chunk, latent).  Each lane owns SPL (= 8, or 4 on small shards) spikes of the chunk (times and
 // embedding weights c_s = C[n_s, k] in registers); the inducing points z_j and a_j = (Kzz^-1 m)_j
 // are wave-uniform.  For the exponential link the spike term of the ELL needs only the posterior
 // MEAN, whose adjoint is known a priori (d ELL / d mu_k(t_s) = C[n_s, k]), so value and all
@@ -36,7 +36,7 @@ __device__ __forceinline__ void seg_emit(int key, double v, int& ck, double& cv,
   cv = __shfl(v, 63, 64);
 }
 
-template <int KT, bool FULL>
+template <int KT, bool FULL, int SPL>
 __device__ void spike_body(const EngineView& ev, const double* __restrict__ C, int ch, int k,
                            double* red) {
   // NV partial-sum vectors per inducing point: P0 | P0 P1 P2 (RBF) | P0 P1 P2 P3 (periodic)
@@ -66,13 +66,13 @@ __device__ void spike_body(const EngineView& ev, const double* __restrict__ C, i
     w3 = 1.0 / sc;
   }
 
-  double ts[SV_SPL], cw[SV_SPL], mu[SV_SPL];
+  double ts[SPL], cw[SPL], mu[SPL];
   // periodic: sin / cos of the spike phase 2 pi t / p, once per spike; the pair (spike, inducing point)
   // then costs 4 FMAs by angle addition instead of a sincos
-  double st[SV_SPL], ct[SV_SPL];
-  int nid[SV_SPL];
+  double st[SPL], ct[SPL];
+  int nid[SPL];
 #pragma unroll
-  for (int i = 0; i < SV_SPL; ++i) {
+  for (int i = 0; i < SPL; ++i) {
     int idx = i * 64 + lane;
     bool ok = idx < c.count;
     long long gs = c.start + (ok ? idx : 0);
@@ -109,7 +109,7 @@ __device__ void spike_body(const EngineView& ev, const double* __restrict__ C, i
           cz = zsc[128 + j];
         }
 #pragma unroll
-        for (int i = 0; i < SV_SPL; ++i) {
+        for (int i = 0; i < SPL; ++i) {
           double y, sn = 0.0, u = 0.0;
           if (KT == SV_RBF) {
             u = ts[i] - zs;
@@ -186,7 +186,7 @@ __device__ void spike_body(const EngineView& ev, const double* __restrict__ C, i
     if (c.split) {
       double tot = 0.0;
 #pragma unroll
-      for (int i = 0; i < SV_SPL; ++i) tot += (nid[i] >= 0) ? mu[i] : 0.0;
+      for (int i = 0; i < SPL; ++i) tot += (nid[i] >= 0) ? mu[i] : 0.0;
       tot = wave_sum(tot);
       if (lane == 0) ev.splitPart[(long long)ch * K + k] = p.s2 * tot;
     } else {
@@ -194,14 +194,14 @@ __device__ void spike_body(const EngineView& ev, const double* __restrict__ C, i
       int ck = -1;
       double cv = 0.0;
 #pragma unroll
-      for (int i = 0; i < SV_SPL; ++i) seg_emit(nid[i], p.s2 * mu[i], ck, cv, out, K, lane);
+      for (int i = 0; i < SPL; ++i) seg_emit(nid[i], p.s2 * mu[i], ck, cv, out, K, lane);
       if (ck >= 0 && lane == 0) out[(long long)ck * K] = cv;
     }
   }
 }
 
 // KT = SV_RBF / SV_PERIODIC: one launch per covariance type; KT = 2 (any): type resolved per block (small shards).
-template <int KT, bool FULL>
+template <int KT, bool FULL, int SPL>
 __global__ __launch_bounds__(64) void k_spike(EngineView ev, const double* __restrict__ C) {
   constexpr int NV = FULL ? (KT == SV_RBF ? 3 : 4) : 1;
   __shared__ double red[4 * 8 * 65 + 3 * 64];
@@ -209,13 +209,13 @@ __global__ __launch_bounds__(64) void k_spike(EngineView ev, const double* __res
   if (KT == 2) {
     const int ch = item / ev.K, k = item % ev.K;
     if (ev.meta[k].ktype == SV_RBF)
-      spike_body<SV_RBF, FULL>(ev, C, ch, k, red);
+      spike_body<SV_RBF, FULL, SPL>(ev, C, ch, k, red);
     else
-      spike_body<SV_PERIODIC, FULL>(ev, C, ch, k, red);
+      spike_body<SV_PERIODIC, FULL, SPL>(ev, C, ch, k, red);
   } else {
     const int nk = ev.ntype[KT == 2 ? 0 : KT];
     const int ch = item / nk, k = ev.klist[KT == 2 ? 0 : KT][item % nk];
-    spike_body<(KT == 2 ? SV_RBF : KT), FULL>(ev, C, ch, k, red);
+    spike_body<(KT == 2 ? SV_RBF : KT), FULL, SPL>(ev, C, ch, k, red);
   }
 }
 

@@ -43,6 +43,9 @@ struct svgpfa_engine {
   // SVGPFA_OVERLAP = 0 never (default: measured no gain on MI355X / ROCm 7.2) | 1 always | 2 automatic
   hipStream_t s_spk[2] = {nullptr, nullptr}, s_per = nullptr;
   int overlap_mode = 0;
+  int spl = SV_SPL;            // spikes per lane of the spike pass: 8, or 4 when the shard has few chunks (set_spikes)
+  long long small_spike_waves = 0;       // below this many (chunk, latent) waves at SPL = 8, use SPL = 4 (measured slower on
+                                         // cfg3 shards: per-wave epilogue dominates; kept as an option, SVGPFA_SMALL_SPIKE_WAVES)
   long long overlap_thresh = 8192;
   long long merge_items = 2048, merge_spike_blocks = 8192;   // merged-type launches below these grid sizes
   hipEvent_t ev_prep = nullptr, ev_t1 = nullptr, ev_ell = nullptr, ev_spk[2] = {nullptr, nullptr}, ev_b1 = nullptr;
@@ -281,6 +284,8 @@ int svgpfa_create(const svgpfa_dims* d, int device, svgpfa_engine** out) {
     if (mi) e->merge_items = atoll(mi);
     const char* ms = getenv("SVGPFA_MERGE_SPIKE_BLOCKS");
     if (ms) e->merge_spike_blocks = atoll(ms);
+    const char* sw = getenv("SVGPFA_SMALL_SPIKE_WAVES");
+    if (sw) e->small_spike_waves = atoll(sw);
   }
   for (hipEvent_t* ev : {&e->ev_prep, &e->ev_t1, &e->ev_ell, &e->ev_spk[0], &e->ev_spk[1], &e->ev_b1})
     HIPCHK(e, hipEventCreateWithFlags(ev, hipEventDisableTiming));
@@ -395,6 +400,9 @@ int svgpfa_set_spikes(svgpfa_engine* e, const int64_t* off, const double* times,
   if (S > 0 && (!times || !neuron)) return SVGPFA_ERR_INVALID;
   if (S > 2000000000LL) FAIL(e, SVGPFA_ERR_UNSUPPORTED, "more than 2e9 spikes on one GPU");
   v.S = (int)S;
+  // granularity of the spike pass: a small shard gets half-size chunks so that its waves still fill the chip evenly
+  e->spl = ((S + 459) / 460) * v.K < e->small_spike_waves ? 4 : 8;
+  const long long CHUNK = 64LL * e->spl;
   std::vector<int32_t> nh((size_t)S);
   if (S) HIPCHK(e, hipMemcpy(nh.data(), neuron, sizeof(int32_t) * S, hipMemcpyDeviceToHost));
   std::vector<long long> seg((size_t)v.R * v.N + 1);
@@ -416,16 +424,16 @@ int svgpfa_set_spikes(svgpfa_engine* e, const int64_t* off, const double* times,
       while (i < s1 && nh[i] == n) { ++i; cnt[n] += 1.0; }
       long long len = i - b;
       if (len == 0) continue;
-      if (len > SV_SPIKE_CHUNK) {             // oversize segment: dedicated split chunks
+      if (len > CHUNK) {             // oversize segment: dedicated split chunks
         flush();
-        for (long long c = b; c < i; c += SV_SPIKE_CHUNK) {
-          SpikeChunk sc{r, (int)std::min<long long>(SV_SPIKE_CHUNK, i - c), c, 1, n};
+        for (long long c = b; c < i; c += CHUNK) {
+          SpikeChunk sc{r, (int)std::min<long long>(CHUNK, i - c), c, 1, n};
           splits.push_back((int)chunks.size());
           chunks.push_back(sc);
         }
         cur.start = i;
       } else {
-        if (cur.count + len > SV_SPIKE_CHUNK) flush();
+        if (cur.count + len > CHUNK) flush();
         if (cur.count == 0) cur.start = b;
         cur.count += (int)len;
       }
@@ -633,11 +641,17 @@ int svgpfa_elbo(svgpfa_engine* e, const double* const* mean, const double* const
       evp = &e->ev_pool[e->ev_used++];
       HIPCHK(e, hipEventRecord(evp->first, sk[tfirst]));
     }
-    const bool mspk = !ov && (long long)v.nchunks * v.K <= e->merge_spike_blocks;
-    if (full) {
-      FOR_TYPES(e, mspk, sk[0], sk[1], hipLaunchKernelGGL((k_spike<KT_, true>), dim3(v.nchunks * NKT_), dim3(64), 0, ST_, v, C));
+    const bool mspk = !ov && (long long)v.nchunks * v.K * e->spl / 8 <= e->merge_spike_blocks;
+    if (e->spl == 4) {
+      if (full) {
+        FOR_TYPES(e, mspk, sk[0], sk[1], hipLaunchKernelGGL((k_spike<KT_, true, 4>), dim3(v.nchunks * NKT_), dim3(64), 0, ST_, v, C));
+      } else {
+        FOR_TYPES(e, mspk, sk[0], sk[1], hipLaunchKernelGGL((k_spike<KT_, false, 4>), dim3(v.nchunks * NKT_), dim3(64), 0, ST_, v, C));
+      }
+    } else if (full) {
+      FOR_TYPES(e, mspk, sk[0], sk[1], hipLaunchKernelGGL((k_spike<KT_, true, 8>), dim3(v.nchunks * NKT_), dim3(64), 0, ST_, v, C));
     } else {
-      FOR_TYPES(e, mspk, sk[0], sk[1], hipLaunchKernelGGL((k_spike<KT_, false>), dim3(v.nchunks * NKT_), dim3(64), 0, ST_, v, C));
+      FOR_TYPES(e, mspk, sk[0], sk[1], hipLaunchKernelGGL((k_spike<KT_, false, 8>), dim3(v.nchunks * NKT_), dim3(64), 0, ST_, v, C));
     }
     if (evp) HIPCHK(e, hipEventRecord(evp->second, sk[tlast]));
     if (ov) {

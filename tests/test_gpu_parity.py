@@ -181,6 +181,23 @@ def test_launch_strategies_agree(monkeypatch):
             assert torch.equal(a, b)
 
 
+def test_half_size_spike_chunks(monkeypatch):
+    """Optional 4-spikes-per-lane granularity of the spike pass (SVGPFA_SMALL_SPIKE_WAVES): different chunking,
+    same sums to rounding (tolerance 1e-11 relative on the ELBO, 1e-9 on gradients)."""
+    prob = synthetic.make_problem(R=4, N=15, K=3, M=[12, 16, 9], kernels="mix", seed=21, n_quad=60, rate=60.0, jitter=1.0)
+    outs = []
+    for val in ("0", "1000000000"):
+        monkeypatch.setenv("SVGPFA_SMALL_SPIKE_WAVES", val)
+        eng, P = _engine(prob)
+        shared, gm, gc, gz = eng.elbo(P["mean"], P["cholVecs"], P["C"], P["d"], 15)
+        eng.sync()
+        outs.append([shared.clone()] + [t.clone() for t in gm + gc + gz])
+        eng.close()
+    assert abs(float(outs[0][0][0] - outs[1][0][0])) <= 1e-11 * abs(float(outs[0][0][0]))
+    for a, b in zip(outs[0], outs[1]):
+        assert rel_err(b.cpu().numpy(), a.cpu().numpy()) < 1e-9
+
+
 def test_repeatable_bitwise():
     """Fixed-order reductions: two evaluations of the same inputs are bit-identical."""
     prob = synthetic.make_problem(R=6, N=20, K=3, M=12, kernels="mix", seed=11, n_quad=100, rate=40.0, jitter=1.0)
