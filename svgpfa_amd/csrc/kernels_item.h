@@ -200,8 +200,15 @@ __device__ void k_prep_body(const EngineView& ev, const LatentPtrs* ptab, double
 // synchronisation is a wave-level LDS fence; loops are fully unrolled (static register indices).
 // Padding rows / columns are the identity.  write_aux = 1 additionally stores Kzz and L (only the
 // KernelsMatricesStore getters read them).
+// snap != 0: Z / theta come from the caller's tensors (st) and are snapshotted into engine-owned HBM on the way
+// (reference semantics: later evaluations keep using the matrices of the last buildKernelsMatrices() call).
+struct SnapTable {
+  const double* Z[SV_MAX_K];
+  const double* theta[SV_MAX_K];
+};
+
 template <int MP>
-__global__ __launch_bounds__(64) void k_build_reg(EngineView ev, int write_aux) {
+__global__ __launch_bounds__(64) void k_build_reg(EngineView ev, int write_aux, int snap, SnapTable st) {
   constexpr int IPW = 64 / MP;
   __shared__ double Lt[IPW][MP][MP];       // Lt[item][q][i] = L[i][q]  (column-major: conflict-free writes)
   const int lane = threadIdx.x, sub = lane / MP, i = lane % MP, lbase = lane - i;
@@ -212,11 +219,15 @@ __global__ __launch_bounds__(64) void k_build_reg(EngineView ev, int write_aux) 
   if (!active) r = ev.R - 1;
   const LatentMeta m = ev.meta[k];
   const int M = m.M;
-  const KPar p = make_kpar(m, ev.theta + 2 * k);
+  const KPar p = make_kpar(m, snap ? st.theta[k] : ev.theta + 2 * k);
   const long long base = m.offMM + (long long)r * M * M;
-  const double* z = ev.Zs + m.offM + (long long)r * M;
+  const double* z = (snap ? st.Z[k] : ev.Zs + m.offM) + (long long)r * M;
   const bool rowok = i < M;
   const double zi = rowok ? z[i] : 0.0;
+  if (snap) {
+    if (active && rowok) ev.Zs[m.offM + (long long)r * M + i] = zi;
+    if (blockIdx.x % rp == 0 && lane < m.nth) ev.theta[2 * k + lane] = st.theta[k][lane];
+  }
 
   double a[MP];
   if (m.ktype == SV_RBF) {

@@ -711,9 +711,8 @@ __global__ __launch_bounds__(64) void k_prep_mfma(EngineView ev, LatentPtrTable 
 // (rows padded to LDK = 4 KS + 2 doubles: conflict-free fragment reads); the wave's own 16 rows of the
 // other matrix sit in a small per-wave LDS slice.  grid = R * parts blocks of 256 threads.
 template <int KS, int ROLE>
-__global__ __launch_bounds__(256) void k_quad_ell_mfma(EngineView ev, const double* C, const double* d,
-                                                       int want_sums, int write_ell, int parts) {
-  extern __shared__ double sm[];
+__device__ __forceinline__ void quad_ell_mfma_body(const EngineView& ev, const double* C, const double* d,
+                                                   int want_sums, int write_ell, int parts, int blk, double* sm) {
   constexpr int KKP = 4 * KS, LDK = KKP + 2, KKT = (KKP + 15) / 16;
   const double L2E = 1.4426950408889634074, LN2 = 0.69314718055994530942;
   const int K = ev.K, N = ev.N, Q = ev.Q, K2 = 2 * K;
@@ -721,7 +720,7 @@ __global__ __launch_bounds__(256) void k_quad_ell_mfma(EngineView ev, const doub
   const int LT = (ROLE == 0) ? QT : NTl;      // tiles of the looped dimension
   const int OT = (ROLE == 0) ? NTl : QT;      // tiles of the wave-owned dimension
   const int Lp = LT * 16;
-  const int blk = blockIdx.x, r = blk / parts, part = blk % parts;
+  const int r = blk / parts, part = blk % parts;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 15, lg = lane >> 4;
   double* LM = sm;                          // (Lp + 1) * LDK  looped matrix: ROLE 0 [mu | var], ROLE 1 log2e [C | C^2/2]
   double* lv = LM + (Lp + 1) * LDK;         // Lp   looped vector: ROLE 0 w_q, ROLE 1 log2e d_n
@@ -873,5 +872,22 @@ __global__ __launch_bounds__(256) void k_quad_ell_mfma(EngineView ev, const doub
   if (write_ell) {
     const double tot = block_sum(esum, red);
     if (tid == 0) ev.ellq[blk] = -tot;
+  }
+}
+
+// ROLE 0 / 1: one role per launch.  ROLE 2: both roles in one launch (blocks [0, nb) role 0, [nb, 2 nb) role 1) for
+// small shards, where each launch is latency- rather than throughput-bound.
+template <int KS, int ROLE>
+__global__ __launch_bounds__(256) void k_quad_ell_mfma(EngineView ev, const double* C, const double* d,
+                                                       int want_sums, int write_ell, int parts) {
+  extern __shared__ double sm[];
+  if (ROLE == 2) {
+    const int nb = ev.R * parts;
+    if ((int)blockIdx.x < nb)
+      quad_ell_mfma_body<KS, 0>(ev, C, d, want_sums, 1, parts, blockIdx.x, sm);
+    else
+      quad_ell_mfma_body<KS, 1>(ev, C, d, 1, 0, parts, blockIdx.x - nb, sm);
+  } else {
+    quad_ell_mfma_body<KS, (ROLE == 2 ? 0 : ROLE)>(ev, C, d, want_sums, write_ell, parts, blockIdx.x, sm);
   }
 }

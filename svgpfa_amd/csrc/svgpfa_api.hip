@@ -167,10 +167,6 @@ static size_t lds_bwd_mfma(int NT) {
 
 // Snapshot Z_k / theta_k of all latents into engine-owned HBM in ONE launch (reference semantics:
 // later evaluations keep using the matrices of the last buildKernelsMatrices() call).
-struct SnapTable {
-  const double* Z[SV_MAX_K];
-  const double* theta[SV_MAX_K];
-};
 __global__ void k_snapshot(EngineView ev, SnapTable st) {
   const int k = blockIdx.y;
   const LatentMeta m = ev.meta[k];
@@ -316,7 +312,8 @@ int svgpfa_create(const svgpfa_dims* d, int device, svgpfa_engine** out) {
   if (e->ell_parts) {
     rc = 0;
     DISPATCH_KS(e->KKT, rc = allow_lds(e, (k_quad_ell_mfma<KS_, 0>), lds_qell_mfma(e, 0));
-                if (!rc) rc = allow_lds(e, (k_quad_ell_mfma<KS_, 1>), lds_qell_mfma(e, 1)));
+                if (!rc) rc = allow_lds(e, (k_quad_ell_mfma<KS_, 1>), lds_qell_mfma(e, 1));
+                if (!rc) rc = allow_lds(e, (k_quad_ell_mfma<KS_, 2>), std::max(lds_qell_mfma(e, 0), lds_qell_mfma(e, 1))));
     if (rc) return rc;
   }
   size_t lq = lds_qell(e);
@@ -480,14 +477,24 @@ int svgpfa_set_spikes(svgpfa_engine* e, const int64_t* off, const double* times,
 }
 
 // write_aux: also store Kzz and L (getter path).  M <= 32: register-resident kernel, several items per wave.
-static void launch_build(svgpfa_engine* e, int write_aux) {
+// snap != nullptr: read Z / theta from the caller's tensors and snapshot them in the same launch.
+static void launch_build(svgpfa_engine* e, int write_aux, const SnapTable* snap) {
   EngineView& v = e->v;
-  if (e->Mmax <= 16)
-    hipLaunchKernelGGL(k_build_reg<16>, dim3(v.K * ((v.R + 3) / 4)), dim3(64), 0, e->stream, v, write_aux);
-  else if (e->Mmax <= 32)
-    hipLaunchKernelGGL(k_build_reg<32>, dim3(v.K * ((v.R + 1) / 2)), dim3(64), 0, e->stream, v, write_aux);
-  else
+  SnapTable none;
+  memset(&none, 0, sizeof none);
+  if (e->Mmax <= 16) {
+    hipLaunchKernelGGL(k_build_reg<16>, dim3(v.K * ((v.R + 3) / 4)), dim3(64), 0, e->stream, v, write_aux, snap ? 1 : 0,
+                       snap ? *snap : none);
+  } else if (e->Mmax <= 32) {
+    hipLaunchKernelGGL(k_build_reg<32>, dim3(v.K * ((v.R + 1) / 2)), dim3(64), 0, e->stream, v, write_aux, snap ? 1 : 0,
+                       snap ? *snap : none);
+  } else {
+    if (snap) {
+      int gx = std::max(1, std::min(64, (v.R * e->Mmax + 255) / 256));
+      hipLaunchKernelGGL(k_snapshot, dim3(gx, v.K), dim3(256), 0, e->stream, v, *snap);
+    }
     hipLaunchKernelGGL(k_build<1>, dim3(v.K * v.R), dim3(64), lds_build(e->Mmax, 1), e->stream, v);
+  }
 }
 
 int svgpfa_build_kernels(svgpfa_engine* e, const double* const* Z, const double* const* theta) {
@@ -500,11 +507,7 @@ int svgpfa_build_kernels(svgpfa_engine* e, const double* const* Z, const double*
     st.Z[k] = Z[k];
     st.theta[k] = theta[k];
   }
-  {
-    int gx = std::max(1, std::min(64, (v.R * e->Mmax + 255) / 256));
-    hipLaunchKernelGGL(k_snapshot, dim3(gx, v.K), dim3(256), 0, e->stream, v, st);
-  }
-  launch_build(e, 0);
+  launch_build(e, 0, &st);
   e->aux_valid = false;
   HIPCHK(e, hipGetLastError());
   e->have_kernels = true;
@@ -545,11 +548,17 @@ static int launch_quad_ell(svgpfa_engine* e, const double* C, const double* d, i
   if (e->ell_parts) {
     // role 0 (dC, dd and the ELL value) always runs: its column sums give sum E; role 1 only for latent adjoints
     dim3 gm(v.R * e->ell_parts), bm(256);
-    DISPATCH_KS(e->KKT,
-                hipLaunchKernelGGL((k_quad_ell_mfma<KS_, 0>), gm, bm, lds_qell_mfma(e, 0), e->stream, v, C, d, want_cd, 1,
-                                   e->ell_parts);
-                if (want_lat) hipLaunchKernelGGL((k_quad_ell_mfma<KS_, 1>), gm, bm, lds_qell_mfma(e, 1), e->stream, v, C,
-                                                 d, 1, 0, e->ell_parts));
+    if (want_lat && (long long)v.R * v.K <= e->merge_items) {   // small shard: both roles in one launch
+      const size_t l2 = std::max(lds_qell_mfma(e, 0), lds_qell_mfma(e, 1));
+      DISPATCH_KS(e->KKT, hipLaunchKernelGGL((k_quad_ell_mfma<KS_, 2>), dim3(2 * gm.x), bm, l2, e->stream, v, C, d, want_cd,
+                                             1, e->ell_parts));
+    } else {
+      DISPATCH_KS(e->KKT,
+                  hipLaunchKernelGGL((k_quad_ell_mfma<KS_, 0>), gm, bm, lds_qell_mfma(e, 0), e->stream, v, C, d, want_cd, 1,
+                                     e->ell_parts);
+                  if (want_lat) hipLaunchKernelGGL((k_quad_ell_mfma<KS_, 1>), gm, bm, lds_qell_mfma(e, 1), e->stream, v, C,
+                                                   d, 1, 0, e->ell_parts));
+    }
     HIPCHK(e, hipGetLastError());
     return SVGPFA_OK;
   }
@@ -755,7 +764,7 @@ static int get_mm(svgpfa_engine* e, int k, const double* src, double* out) {
   if (!e || !out || k < 0 || k >= e->v.K) return SVGPFA_ERR_INVALID;
   if (!e->have_kernels) FAIL(e, SVGPFA_ERR_STATE, "svgpfa_build_kernels has not been called");
   if (!e->aux_valid && e->Mmax <= 32) {   // Kzz / L are materialised on demand from the current snapshot
-    launch_build(e, 1);
+    launch_build(e, 1, nullptr);
     HIPCHK(e, hipGetLastError());
     e->aux_valid = true;
   }
