@@ -42,7 +42,10 @@ struct svgpfa_engine {
   // sides fill the chip and time-slice, which measured SLOWER, hence the size threshold.
   // SVGPFA_OVERLAP = 0 never (default: measured no gain on MI355X / ROCm 7.2) | 1 always | 2 automatic
   hipStream_t s_spk[2] = {nullptr, nullptr}, s_per = nullptr;
-  int overlap_mode = 0;
+  int overlap_mode = 0;        // 0 (default) one stream | 1 multi-stream per type | 2 = 1 below overlap_thresh | 3 spike pass on a
+                               // side stream | 4 = 3 on small shards only.  Measured on MI355X: every concurrent variant is
+                               // SLOWER than one stream (cfg3 8-way shard 0.41 vs 0.27 ms), so they stay opt-in (SVGPFA_OVERLAP)
+  hipStream_t s_side = nullptr;
   int spl = SV_SPL;            // spikes per lane of the spike pass: 8, or 4 when the shard has few chunks (set_spikes)
   long long small_spike_waves = 0;       // below this many (chunk, latent) waves at SPL = 8, use SPL = 4 (measured slower on
                                          // cfg3 shards: per-wave epilogue dominates; kept as an option, SVGPFA_SMALL_SPIKE_WAVES)
@@ -270,10 +273,11 @@ int svgpfa_create(const svgpfa_dims* d, int device, svgpfa_engine** out) {
     HIPCHK(e, hipStreamCreateWithPriority(&e->s_spk[0], hipStreamNonBlocking, lo));
     HIPCHK(e, hipStreamCreateWithPriority(&e->s_spk[1], hipStreamNonBlocking, lo));
     HIPCHK(e, hipStreamCreateWithPriority(&e->s_per, hipStreamNonBlocking, hi));
+    HIPCHK(e, hipStreamCreateWithFlags(&e->s_side, hipStreamNonBlocking));
   }
   {
     const char* ov = getenv("SVGPFA_OVERLAP");
-    if (ov && ov[0] >= '0' && ov[0] <= '2') e->overlap_mode = ov[0] - '0';
+    if (ov && ov[0] >= '0' && ov[0] <= '4') e->overlap_mode = ov[0] - '0';
     const char* th = getenv("SVGPFA_OVERLAP_THRESH");
     if (th) e->overlap_thresh = atoll(th);
     const char* mi = getenv("SVGPFA_MERGE_ITEMS");
@@ -333,7 +337,7 @@ void svgpfa_destroy(svgpfa_engine* e) {
   (void)hipDeviceSynchronize();
   for (void* p : e->allocs) (void)hipFree(p);
   if (e->status_host) (void)hipHostFree(e->status_host);
-  for (hipStream_t st : {e->s_spk[0], e->s_spk[1], e->s_per})
+  for (hipStream_t st : {e->s_spk[0], e->s_spk[1], e->s_per, e->s_side})
     if (st) (void)hipStreamDestroy(st);
   for (hipEvent_t ev : {e->ev_prep, e->ev_t1, e->ev_ell, e->ev_spk[0], e->ev_spk[1], e->ev_b1})
     if (ev) (void)hipEventDestroy(ev);
@@ -629,7 +633,15 @@ int svgpfa_elbo(svgpfa_engine* e, const double* const* mean, const double* const
   const bool mitems = !ov && (long long)v.R * v.K <= e->merge_items;   // merged-type launches on small shards
   hipStream_t sm = e->stream;
   hipStream_t sp = ov ? e->s_per : sm;                      // periodic-type MFMA kernels
-  hipStream_t sk[2] = {ov ? e->s_spk[0] : sm, ov ? e->s_spk[1] : sm};   // spike pass per type
+  // small shards: every launch is latency-bound and under-fills the chip, so the spike pass runs beside the
+  // quadrature chain on one side stream (two cross-stream edges: prep -> spike, spike -> bwd)
+  const bool side = !ov && v.nchunks > 0 &&
+                    (e->overlap_mode == 3 || (e->overlap_mode == 4 && (long long)v.R * v.K <= e->merge_items));
+  hipStream_t sk[2] = {ov ? e->s_spk[0] : (side ? e->s_side : sm), ov ? e->s_spk[1] : (side ? e->s_side : sm)};
+  if (side) {
+    HIPCHK(e, hipEventRecord(e->ev_prep, sm));
+    HIPCHK(e, hipStreamWaitEvent(e->s_side, e->ev_prep, 0));
+  }
   if (ov) {
     HIPCHK(e, hipEventRecord(e->ev_prep, sm));
     HIPCHK(e, hipStreamWaitEvent(sp, e->ev_prep, 0));
@@ -667,6 +679,7 @@ int svgpfa_elbo(svgpfa_engine* e, const double* const* mean, const double* const
       HIPCHK(e, hipEventRecord(e->ev_spk[0], sk[0]));
       HIPCHK(e, hipEventRecord(e->ev_spk[1], sk[1]));
     }
+    if (side) HIPCHK(e, hipEventRecord(e->ev_spk[0], e->s_side));
   }
   // ---- quadrature chain (f64 MFMA): posterior stats -> ELL term -> adjoints
   if ((rc = launch_times(e, v.tq, nullptr, v.Q, v.muq, v.varq, (long long)v.K, 1LL, 1, sm, sp))) return rc;
@@ -693,6 +706,7 @@ int svgpfa_elbo(svgpfa_engine* e, const double* const* mean, const double* const
     HIPCHK(e, hipStreamWaitEvent(sm, e->ev_spk[0], 0));
     HIPCHK(e, hipStreamWaitEvent(sp, e->ev_spk[1], 0));
   }
+  if (side) HIPCHK(e, hipStreamWaitEvent(sm, e->ev_spk[0], 0));
   DISPATCH_NT(e->NT, FOR_TYPES(e, mitems, sm, sp, hipLaunchKernelGGL((k_bwd_mfma<NT_, KT_>), dim3(v.R * NKT_), dim3(64),
                                                                      lds_bwd_mfma(NT_), ST_, v, pt, mask)));
   if (ov) {
