@@ -82,7 +82,7 @@ __device__ void spike_body(const EngineView& ev, const double* __restrict__ C, i
     mu[i] = 0.0;
     if (KT == SV_PERIODIC) sv_sincos_quarter(ts[i], st[i], ct[i]);
   }
-  double* zsc = red + 4 * 8 * 65;    // 3 * 64 doubles behind the (maximal) reduction area: scaled z, sin / cos of its phase
+  double* zsc = red + NV * 8 * 65;   // 3 * 64 doubles behind the reduction area: scaled z, sin / cos of its phase
   if (lane < M) {
     const double zq = z[lane] * sc;
     zsc[lane] = zq;
@@ -203,8 +203,8 @@ __device__ void spike_body(const EngineView& ev, const double* __restrict__ C, i
 // KT = SV_RBF / SV_PERIODIC: one launch per covariance type; KT = 2 (any): type resolved per block (small shards).
 template <int KT, bool FULL, int SPL>
 __global__ __launch_bounds__(64) void k_spike(EngineView ev, const double* __restrict__ C) {
-  constexpr int NV = FULL ? (KT == SV_RBF ? 3 : 4) : 1;
-  __shared__ double red[4 * 8 * 65 + 3 * 64];
+  constexpr int NVM = FULL ? (KT == SV_RBF ? 3 : 4) : 1;     // reduction vectors (the larger count for the merged kernel)
+  __shared__ double red[NVM * 8 * 65 + 3 * 64];             // LDS bounds the waves per CU: keep it to what the type needs
   const int item = blockIdx.x;
   if (KT == 2) {
     const int ch = item / ev.K, k = item % ev.K;

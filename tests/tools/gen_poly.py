@@ -22,7 +22,7 @@ for deg in (10, 11, 12):
     exact = np.array([float(mp.mpf(2) ** mp.mpf(float(t))) for t in x[::200]])
     err = np.max(np.abs(approx[::200] / exact - 1))
     print("exp2 degree", deg, "max rel err", err)
-    if deg == 11:
+    if deg == 10:
         print("EXP2_C (low->high):", ", ".join(mp.nstr(v, 20) for v in c[::-1]))
 
 g = np.linspace(0, 0.25, 100001)
