@@ -390,13 +390,14 @@ __global__ __launch_bounds__(256) void k_quad_bwd_mfma(EngineView ev) {
 
 // ------------------------------------------------------------------------------ k_bwd_mfma
 // Per-(trial, latent) backward through the whitened algebra (derivation: kernels_item.h header).
-// One wavefront per item; every M x M product runs on the f64 MFMA with the left operand read
-// from LDS as A fragments and the right operand held as register tiles, one 16-column panel at a time.
+// NT wavefronts per item (block = 64 NT threads): wave c owns the 16-column panel c of every M x M product, all on
+// the f64 MFMA with the left operand read from LDS as A fragments and the right operand held as register tiles.
+// The panels only meet at the LDS hand-offs (C, At) and in the fixed-order sums of the dZ / dtheta partials.
 template <int NT, int KT>
 __device__ void bwd_mfma_body(const EngineView& ev, const int r, const int k, const LatentPtrs pt, unsigned mask,
                               double* sm) {
-  constexpr int MP = 16 * NT, LD = MP + 2;
-  const int lane = threadIdx.x, li = lane & 15, lg = lane >> 4;
+  constexpr int MP = 16 * NT, LD = MP + 2, NTH = 64 * NT;
+  const int tid = threadIdx.x, lane = tid & 63, c = tid >> 6, li = lane & 15, lg = lane >> 4;
   const int item = r * ev.K + k;
   const LatentMeta m = ev.meta[k];
   const int M = m.M;
@@ -408,25 +409,27 @@ __device__ void bwd_mfma_body(const EngineView& ev, const int r, const int k, co
   double* ul = gt + MP;          // MP
   double* gs = ul + MP;          // MP
   double* zl = gs + MP;          // MP
+  double* redz = zl + MP;        // NT*MP  per-panel row sums of the dZ contraction
+  double* redt = redz + NT * MP; // NT*2   per-panel dtheta partials
   const long long base = m.offMM + (long long)r * M * M;
   const long long vbase = m.offM + (long long)r * M;
   const KPar p = make_kpar(m, ev.theta + 2 * k);
   const bool want_zt = (mask & (4u | 8u)) != 0;
 
-  // ---- gather the spike partial sums of this trial (fixed chunk order)
+  // ---- gather the spike partial sums of this trial (fixed chunk order); thread j < M owns inducing point j
   double p1sum = 0.0, espk = 0.0, a_l = 0.0;
-  for (int i = lane; i < MP; i += 64) {
+  for (int i = tid; i < MP; i += NTH) {
     gs[i] = 0.0; ul[i] = 0.0; zl[i] = 0.0; gt[i] = 0.0;
   }
   const int c0 = ev.chunk_first[r], c1 = ev.chunk_first[r + 1];
-  if (lane < M) {
+  if (tid < M) {
     double p0 = 0.0;
-    for (int c = c0; c < c1; c += 4) {          // 4 chunks per step: independent loads in flight, fixed order
+    for (int ch = c0; ch < c1; ch += 4) {          // 4 chunks per step: independent loads in flight, fixed order
       double v[4], w[4];
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
-        const bool in = c + u < c1;
-        const long long o = (long long)(in ? c + u : c) * ev.sumM + m.colM + lane;
+        const bool in = ch + u < c1;
+        const long long o = (long long)(in ? ch + u : ch) * ev.sumM + m.colM + tid;
         v[u] = ev.P0[o];
         w[u] = want_zt ? ev.P1[o] : 0.0;
         if (!in) { v[u] = 0.0; w[u] = 0.0; }
@@ -434,28 +437,30 @@ __device__ void bwd_mfma_body(const EngineView& ev, const int r, const int k, co
       p0 += (v[0] + v[1]) + (v[2] + v[3]);
       p1sum += (w[0] + w[1]) + (w[2] + w[3]);
     }
-    a_l = ev.a[vbase + lane];
+    a_l = ev.a[vbase + tid];
     double gsp = p.s2 * p0;
     espk = a_l * gsp;
-    gs[lane] = gsp;
-    ul[lane] = ev.ut[vbase + lane];
-    zl[lane] = ev.Zs[vbase + lane];
+    gs[tid] = gsp;
+    ul[tid] = ev.ut[vbase + tid];
+    zl[tid] = ev.Zs[vbase + tid];
   }
-  espk = wave_sum(espk);
-  // spike-direct theta partials: one chunk per lane, then a fixed-order wave tree
+  // spike-direct theta partials: one chunk per lane of wave 0, then a fixed-order wave tree
   double tp0 = 0.0, tp1 = 0.0;
-  if (want_zt) {
-    for (int c = c0 + lane; c < c1; c += 64) {
-      tp0 += ev.Tpart[((long long)c * ev.K + k) * 2 + 0];
-      tp1 += ev.Tpart[((long long)c * ev.K + k) * 2 + 1];
+  if (c == 0) {
+    espk = wave_sum(espk);
+    if (want_zt) {
+      for (int ch = c0 + lane; ch < c1; ch += 64) {
+        tp0 += ev.Tpart[((long long)ch * ev.K + k) * 2 + 0];
+        tp1 += ev.Tpart[((long long)ch * ev.K + k) * 2 + 1];
+      }
+      tp0 = wave_sum(tp0);
+      tp1 = wave_sum(tp1);
     }
-    tp0 = wave_sum(tp0);
-    tp1 = wave_sum(tp1);
+    if (lane == 0) ev.ells[item] = espk;
   }
-  if (lane == 0) ev.ells[item] = espk;
   if ((mask & (1u | 4u | 8u)) == 0) return;
 
-  for (int e = lane; e < MP * MP; e += 64) {
+  for (int e = tid; e < MP * MP; e += NTH) {
     int i = e / MP, j = e % MP;
     bool in = (i < M) && (j < M);
     Li[i * LD + j] = in ? ev.Linv[base + i * M + j] : 0.0;
@@ -463,64 +468,61 @@ __device__ void bwd_mfma_body(const EngineView& ev, const int r, const int k, co
     Gl[i * LD + j] = in ? ev.GW[base + i * M + j] : 0.0;
   }
   __syncthreads();
-  if (lane < M) {
-    double s = ev.gaq[vbase + lane];
-    for (int q = 0; q <= lane; ++q) s += Li[lane * LD + q] * gs[q];
-    gt[lane] = s;
+  if (tid < M) {
+    double s = ev.gaq[vbase + tid];
+    for (int q = 0; q <= tid; ++q) s += Li[tid * LD + q] * gs[q];
+    gt[tid] = s;
   }
   __syncthreads();
 
   if (mask & 1u) {
-    if (lane < M) {
+    if (tid < M) {
       double s = 0.0;
-      for (int q = lane; q < M; ++q) s += Li[q * LD + lane] * (gt[q] - ul[q]);
-      pt.g_mean[(long long)r * M + lane] = s;
+      for (int q = tid; q < M; ++q) s += Li[q * LD + tid] * (gt[q] - ul[q]);
+      pt.g_mean[(long long)r * M + tid] = s;
     }
-    // dL_S = tril(Linv^T (2 Gt - I) Vt) + diag(1 / L_S,ii), one 16-column panel at a time
+    // dL_S = tril(Linv^T (2 Gt - I) Vt) + diag(1 / L_S,ii): this wave's 16-column panel
     const double* cv = pt.cholvec + (long long)r * m.P;
     double* gcv = pt.g_cholvec + (long long)r * m.P;
+    d4 P[NT], X[NT];
 #pragma unroll
-    for (int c = 0; c < NT; ++c) {
-      d4 P[NT], X[NT];
+    for (int b = 0; b < NT; ++b)
 #pragma unroll
-      for (int b = 0; b < NT; ++b)
+      for (int q = 0; q < 4; ++q) P[b][q] = Vl[(16 * b + 4 * q + lg) * LD + 16 * c + li];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) P[b][q] = Vl[(16 * b + 4 * q + lg) * LD + 16 * c + li];
+    for (int a = 0; a < NT; ++a) {
+      d4 acc = {0.0, 0.0, 0.0, 0.0};
+      if (a >= c) {
 #pragma unroll
-      for (int a = 0; a < NT; ++a) {
-        d4 acc = {0.0, 0.0, 0.0, 0.0};
-        if (a >= c) {
+        for (int b = 0; b < NT; ++b) {
+          if (b >= c) {   // Vt lower triangular: panel c has zero tiles above the diagonal
 #pragma unroll
-          for (int b = 0; b < NT; ++b) {
-            if (b >= c) {   // Vt lower triangular: panel c has zero tiles above the diagonal
-#pragma unroll
-              for (int q = 0; q < 4; ++q) {
-                int row = 16 * a + li, col = 16 * b + 4 * q + lg;
-                double av = 2.0 * Gl[row * LD + col] - (row == col ? 1.0 : 0.0);
-                acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, P[b][q], acc, 0, 0, 0);
-              }
+            for (int q = 0; q < 4; ++q) {
+              int row = 16 * a + li, col = 16 * b + 4 * q + lg;
+              double av = 2.0 * Gl[row * LD + col] - (row == col ? 1.0 : 0.0);
+              acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, P[b][q], acc, 0, 0, 0);
             }
           }
         }
-        X[a] = acc;
       }
+      X[a] = acc;
+    }
 #pragma unroll
-      for (int a = 0; a < NT; ++a) {
-        if (a >= c) {
-          d4 acc = {0.0, 0.0, 0.0, 0.0};
+    for (int a = 0; a < NT; ++a) {
+      if (a >= c) {
+        d4 acc = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-          for (int b = a; b < NT; ++b)
+        for (int b = a; b < NT; ++b)
 #pragma unroll
-            for (int q = 0; q < 4; ++q)
-              acc = __builtin_amdgcn_mfma_f64_16x16x4f64(Li[(16 * b + 4 * q + lg) * LD + 16 * a + li], X[b][q], acc, 0, 0, 0);
+          for (int q = 0; q < 4; ++q)
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(Li[(16 * b + 4 * q + lg) * LD + 16 * a + li], X[b][q], acc, 0, 0, 0);
 #pragma unroll
-          for (int q = 0; q < 4; ++q) {
-            int i = 16 * a + 4 * q + lg, j = 16 * c + li;
-            if (i < M && j <= i) {
-              double g = acc[q];
-              if (i == j) g += 1.0 / cv[i * (i + 1) / 2 + i];
-              gcv[i * (i + 1) / 2 + j] = g;
-            }
+        for (int q = 0; q < 4; ++q) {
+          int i = 16 * a + 4 * q + lg, j = 16 * c + li;
+          if (i < M && j <= i) {
+            double g = acc[q];
+            if (i == j) g += 1.0 / cv[i * (i + 1) / 2 + i];
+            gcv[i * (i + 1) / 2 + j] = g;
           }
         }
       }
@@ -528,51 +530,42 @@ __device__ void bwd_mfma_body(const EngineView& ev, const int r, const int k, co
   }
   if (!want_zt) return;
 
-  // ---- C = Vt Vt^T Gt and VV = Vt Vt^T, panel by panel, both kept in registers until Vt is dead
-  d4 VV[NT][NT], Cm[NT][NT];
-#pragma unroll
-  for (int c = 0; c < NT; ++c) {
+  // ---- panel c of C = Vt Vt^T Gt and of VV = Vt Vt^T, kept in registers until Vt is dead in every wave
+  d4 VV[NT], Cm[NT];
+  {
     d4 P[NT], Bm[NT];
 #pragma unroll
     for (int b = 0; b < NT; ++b)
 #pragma unroll
       for (int q = 0; q < 4; ++q) P[b][q] = Gl[(16 * b + 4 * q + lg) * LD + 16 * c + li];
     tri_chain<NT, 1>(Bm, Vl, LD, P, li, lg);
-    tri_chain<NT, 0>(Cm[c], Vl, LD, Bm, li, lg);
+    tri_chain<NT, 0>(Cm, Vl, LD, Bm, li, lg);
 #pragma unroll
     for (int b = 0; b < NT; ++b)
 #pragma unroll
       for (int q = 0; q < 4; ++q) P[b][q] = Vl[(16 * c + li) * LD + 16 * b + 4 * q + lg];   // Vt^T panel
-    tri_chain<NT, 0>(VV[c], Vl, LD, P, li, lg);
+    tri_chain<NT, 0>(VV, Vl, LD, P, li, lg);
   }
   __syncthreads();
 #pragma unroll
-  for (int c = 0; c < NT; ++c)
+  for (int a = 0; a < NT; ++a)
 #pragma unroll
-    for (int a = 0; a < NT; ++a)
-#pragma unroll
-      for (int q = 0; q < 4; ++q) Cs[(16 * a + 4 * q + lg) * LD + 16 * c + li] = Cm[c][a][q];
+    for (int q = 0; q < 4; ++q) Cs[(16 * a + 4 * q + lg) * LD + 16 * c + li] = Cm[a][q];
   __syncthreads();
-  // ---- At (in place over Gt): each element is read and written by exactly one lane
+  // ---- At (in place over Gt): each element is read and written by exactly one lane; the transposed reads of Gt
+  //      itself do not occur (only C is read transposed), so no wave sees a half-updated panel
 #pragma unroll
-  for (int c = 0; c < NT; ++c)
+  for (int a = 0; a < NT; ++a)
 #pragma unroll
-    for (int a = 0; a < NT; ++a)
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        int i = 16 * a + 4 * q + lg, j = 16 * c + li;
-        double v = -0.5 * (gt[i] * ul[j] + ul[i] * gt[j]) + 0.5 * ul[i] * ul[j] + Gl[i * LD + j] +
-                   0.5 * (VV[c][a][q] - (i == j ? 1.0 : 0.0)) - Cs[i * LD + j] - Cs[j * LD + i];
-        Gl[i * LD + j] = v;
-      }
+    for (int q = 0; q < 4; ++q) {
+      int i = 16 * a + 4 * q + lg, j = 16 * c + li;
+      double v = -0.5 * (gt[i] * ul[j] + ul[i] * gt[j]) + 0.5 * ul[i] * ul[j] + Gl[i * LD + j] +
+                 0.5 * (VV[a][q] - (i == j ? 1.0 : 0.0)) - Cs[i * LD + j] - Cs[j * LD + i];
+      Gl[i * LD + j] = v;
+    }
   __syncthreads();
-  // ---- A = Linv^T At Linv, contracted on the fly with dKzz/dZ and dKzz/dtheta
-  d4 gzrow[NT];
-#pragma unroll
-  for (int a = 0; a < NT; ++a) gzrow[a] = (d4){0.0, 0.0, 0.0, 0.0};
-  double t0 = 0.0, t1 = 0.0;
-#pragma unroll
-  for (int c = 0; c < NT; ++c) {
+  // ---- panel c of A = Linv^T At Linv, contracted on the fly with dKzz/dZ and dKzz/dtheta
+  {
     d4 P[NT], Dm[NT], Am[NT];
 #pragma unroll
     for (int b = 0; b < NT; ++b)
@@ -582,68 +575,82 @@ __device__ void bwd_mfma_body(const EngineView& ev, const int r, const int k, co
     for (int a = 0; a < NT; ++a) {
       d4 acc = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-      for (int b = c; b < NT; ++b)   // Linv lower triangular
+      for (int b = 0; b < NT; ++b)
+        if (b >= c) {   // Linv lower triangular
 #pragma unroll
-        for (int q = 0; q < 4; ++q)
-          acc = __builtin_amdgcn_mfma_f64_16x16x4f64(Gl[(16 * a + li) * LD + 16 * b + 4 * q + lg], P[b][q], acc, 0, 0, 0);
+          for (int q = 0; q < 4; ++q)
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(Gl[(16 * a + li) * LD + 16 * b + 4 * q + lg], P[b][q], acc, 0, 0, 0);
+        }
       Dm[a] = acc;
     }
     tri_chain<NT, 1>(Am, Li, LD, Dm, li, lg);
     const double zc = zl[16 * c + li];
+    double t0 = 0.0, t1 = 0.0;
 #pragma unroll
     for (int a = 0; a < NT; ++a)
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         int i = 16 * a + 4 * q + lg, j = 16 * c + li;
+        double gz = 0.0;
         if (i < M && j < M) {
           double kt, bz, b0, b1;
           kern_eval<KT>(zl[i] - zc, p, kt, bz, b0, b1);
           double ak = Am[a][q] * kt;
-          gzrow[a][q] -= ak * bz;
+          gz = -(ak * bz);
           t0 = fma(ak, b0, t0);
           t1 = fma(ak, b1, t1);
         }
+        gz = row16_sum(gz);
+        if (li == 0) redz[c * MP + i] = gz;
       }
-  }
-  t0 = wave_sum(t0) * p.c0;
-  t1 = wave_sum(t1) * p.c1;
-  __syncthreads();
-  // direct spike part a_j cz P1_j lives on lanes j < M; park it in gs for the row owners
-  if (lane < M) gs[lane] = a_l * p.cz * p1sum;
-  __syncthreads();
-#pragma unroll
-  for (int a = 0; a < NT; ++a)
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      double g = row16_sum(gzrow[a][q]) * 2.0 * p.cz;
-      int i = 16 * a + 4 * q + lg;
-      if ((mask & 8u) && li == 0 && i < M) pt.g_Z[(long long)r * M + i] = g + ev.gZq[vbase + i] + gs[i];
+    t0 = wave_sum(t0);
+    t1 = wave_sum(t1);
+    if (lane == 0) {
+      redt[2 * c + 0] = t0;
+      redt[2 * c + 1] = t1;
     }
-  if (lane == 0) {
-    ev.gthitem[item * 2 + 0] = t0 + ev.gthq[item * 2 + 0] + p.c0 * tp0;
-    ev.gthitem[item * 2 + 1] = t1 + ev.gthq[item * 2 + 1] + p.c1 * tp1;
+  }
+  __syncthreads();
+  if ((mask & 8u) && tid < M) {
+    double g = 0.0;
+#pragma unroll
+    for (int w = 0; w < NT; ++w) g += redz[w * MP + tid];     // fixed panel order
+    // direct spike part a_j cz P1_j is already on this thread
+    pt.g_Z[(long long)r * M + tid] = g * 2.0 * p.cz + ev.gZq[vbase + tid] + a_l * p.cz * p1sum;
+  }
+  if (tid == 0) {
+    double t0 = 0.0, t1 = 0.0;
+#pragma unroll
+    for (int w = 0; w < NT; ++w) {
+      t0 += redt[2 * w + 0];
+      t1 += redt[2 * w + 1];
+    }
+    ev.gthitem[item * 2 + 0] = t0 * p.c0 + ev.gthq[item * 2 + 0] + p.c0 * tp0;
+    ev.gthitem[item * 2 + 1] = t1 * p.c1 + ev.gthq[item * 2 + 1] + p.c1 * tp1;
   }
 }
 
 // ----------------------------------------------------------------------------- k_prep_mfma
 // ut = Linv m, a = Linv^T ut, Vt = Linv L_S and the KL term per (trial, latent), on the f64 MFMA.
-// One wavefront per item; Linv and L_S are staged in LDS with coalesced loads; the vector m rides
-// along as an extra 16-column panel (column 0) so that ut and a come out of the same tri_chain.
+// NT wavefronts per item: wave c produces the 16-column panel c of Vt; wave 0 also carries the vector m as an
+// extra panel (column 0) so that ut and a come out of the same tri_chain.  Linv and L_S are staged in LDS with
+// coalesced loads by the whole block.
 template <int NT>
-__global__ __launch_bounds__(64) void k_prep_mfma(EngineView ev, LatentPtrTable ptab) {
+__global__ __launch_bounds__(64 * NT) void k_prep_mfma(EngineView ev, LatentPtrTable ptab) {
   extern __shared__ double sm[];
-  constexpr int MP = 16 * NT, LD = MP + 2;
-  const int item = blockIdx.x, lane = threadIdx.x, li = lane & 15, lg = lane >> 4;
+  constexpr int MP = 16 * NT, LD = MP + 2, NTH = 64 * NT;
+  const int item = blockIdx.x, tid = threadIdx.x, lane = tid & 63, c = tid >> 6, li = lane & 15, lg = lane >> 4;
   const int r = item / ev.K, k = item % ev.K;
   const LatentMeta m = ev.meta[k];
   const LatentPtrs pt = ptab.p[k];
   const int M = m.M;
   double* Li = sm;               // MP*LD
   double* Ls = Li + MP * LD;     // MP*LD
+  double* red = Ls + MP * LD;    // NT
   const long long base = m.offMM + (long long)r * M * M;
   const long long vbase = m.offM + (long long)r * M;
   const double* cv = pt.cholvec + (long long)r * m.P;
-  for (int e = lane; e < MP * MP; e += 64) {
+  for (int e = tid; e < MP * MP; e += NTH) {
     int i = e / MP, j = e % MP;
     bool in = (i < M) && (j < M);
     Li[i * LD + j] = in ? ev.Linv[base + i * M + j] : 0.0;
@@ -651,10 +658,9 @@ __global__ __launch_bounds__(64) void k_prep_mfma(EngineView ev, LatentPtrTable 
   }
   __syncthreads();
 
-  // panels of L_S (NT of them) -> Vt ; |Vt|_F^2
-  double fro = 0.0;
-#pragma unroll
-  for (int c = 0; c < NT; ++c) {
+  // panel c of L_S -> Vt ; |Vt|_F^2
+  double part = 0.0;
+  {
     d4 P[NT], V[NT];
 #pragma unroll
     for (int b = 0; b < NT; ++b)
@@ -667,36 +673,43 @@ __global__ __launch_bounds__(64) void k_prep_mfma(EngineView ev, LatentPtrTable 
       for (int q = 0; q < 4; ++q) {
         int i = 16 * a + 4 * q + lg, j = 16 * c + li;
         if (i < M && j < M) ev.Vt[base + i * M + j] = V[a][q];
-        fro = fma(V[a][q], V[a][q], fro);
+        part = fma(V[a][q], V[a][q], part);
       }
   }
-  // the mean as column 0 of an extra panel: ut = Linv m, a = Linv^T ut
-  d4 Pm[NT], U[NT], A[NT];
+  if (c == 0) {
+    // the mean as column 0 of an extra panel: ut = Linv m, a = Linv^T ut
+    d4 Pm[NT], U[NT], A[NT];
 #pragma unroll
-  for (int b = 0; b < NT; ++b)
+    for (int b = 0; b < NT; ++b)
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      int i = 16 * b + 4 * q + lg;
-      Pm[b][q] = (li == 0 && i < M) ? pt.mean[(long long)r * M + i] : 0.0;
-    }
-  tri_chain<NT, 0>(U, Li, LD, Pm, li, lg);
-  tri_chain<NT, 1>(A, Li, LD, U, li, lg);
-  double quad = 0.0;
-#pragma unroll
-  for (int a = 0; a < NT; ++a)
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      int i = 16 * a + 4 * q + lg;
-      if (li == 0 && i < M) {
-        ev.ut[vbase + i] = U[a][q];
-        ev.a[vbase + i] = A[a][q];
-        quad = fma(U[a][q], U[a][q], quad);
+      for (int q = 0; q < 4; ++q) {
+        int i = 16 * b + 4 * q + lg;
+        Pm[b][q] = (li == 0 && i < M) ? pt.mean[(long long)r * M + i] : 0.0;
       }
-    }
-  double ld = 0.0;
-  if (lane < M) ld = -2.0 * log(Li[lane * LD + lane]) - 2.0 * log(fabs(Ls[lane * LD + lane]));
-  const double tot = wave_sum(fro + quad + ld);
-  if (lane == 0) ev.klpart[item] = 0.5 * (tot - (double)M);
+    tri_chain<NT, 0>(U, Li, LD, Pm, li, lg);
+    tri_chain<NT, 1>(A, Li, LD, U, li, lg);
+#pragma unroll
+    for (int a = 0; a < NT; ++a)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        int i = 16 * a + 4 * q + lg;
+        if (li == 0 && i < M) {
+          ev.ut[vbase + i] = U[a][q];
+          ev.a[vbase + i] = A[a][q];
+          part = fma(U[a][q], U[a][q], part);
+        }
+      }
+    if (lane < M) part += -2.0 * log(Li[lane * LD + lane]) - 2.0 * log(fabs(Ls[lane * LD + lane]));
+  }
+  part = wave_sum(part);
+  if (lane == 0) red[c] = part;
+  __syncthreads();
+  if (tid == 0) {
+    double tot = 0.0;
+#pragma unroll
+    for (int w = 0; w < NT; ++w) tot += red[w];     // fixed panel order
+    ev.klpart[item] = 0.5 * (tot - (double)M);
+  }
 }
 
 // ------------------------------------------------------------------------- k_quad_ell_mfma

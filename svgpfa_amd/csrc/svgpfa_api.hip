@@ -131,7 +131,7 @@ __global__ __launch_bounds__(64) void k_prep_entry(EngineView ev, PtrTable pt) {
   k_prep_body<PACK>(ev, pt.p, sm);
 }
 template <int NT, int KT>
-__global__ __launch_bounds__(64) void k_bwd_mfma(EngineView ev, PtrTable pt, unsigned mask) {
+__global__ __launch_bounds__(64 * NT) void k_bwd_mfma(EngineView ev, PtrTable pt, unsigned mask) {
   extern __shared__ double sm[];
   int r, k;
   block_item<KT>(ev, r, k);
@@ -163,9 +163,13 @@ __global__ __launch_bounds__(64) void k_bwd_mfma(EngineView ev, PtrTable pt, uns
     if ((e)->v.ntype[0] > 0) { constexpr int KT_ = SV_RBF; __VA_ARGS__; }      \
     if ((e)->v.ntype[1] > 0) { constexpr int KT_ = SV_PERIODIC; __VA_ARGS__; } \
   } while (0)
+static size_t lds_prep_mfma(int NT) {
+  size_t MP = 16 * NT, LD = MP + 2;
+  return (2 * MP * LD + NT) * 8;
+}
 static size_t lds_bwd_mfma(int NT) {
   size_t MP = 16 * NT, LD = MP + 2;
-  return (3 * MP * LD + 4 * MP) * 8;
+  return (3 * MP * LD + 4 * MP + NT * MP + 2 * NT) * 8;
 }
 
 // Snapshot Z_k / theta_k of all latents into engine-owned HBM in ONE launch (reference semantics:
@@ -301,6 +305,8 @@ int svgpfa_create(const svgpfa_dims* d, int device, svgpfa_engine** out) {
   }
   rc = 0;
   DISPATCH_NT(e->NT, FOR_KT(e, if (!rc) rc = allow_lds(e, (k_bwd_mfma<NT_, KT_>), lds_bwd_mfma(NT_))));
+  if (rc) return rc;
+  DISPATCH_NT(e->NT, rc = allow_lds(e, (k_prep_mfma<NT_>), lds_prep_mfma(NT_)));
   if (rc) return rc;
   DISPATCH_NT(e->NT, rc = allow_lds(e, (k_bwd_mfma<NT_, SV_ANYTYPE>), lds_bwd_mfma(NT_));
               if (!rc) rc = allow_lds(e, (k_times_fwd_mfma<NT_, SV_ANYTYPE>), lds_times_mfma(NT_));
@@ -492,6 +498,9 @@ static void launch_build(svgpfa_engine* e, int write_aux, const SnapTable* snap)
   } else if (e->Mmax <= 32) {
     hipLaunchKernelGGL(k_build_reg<32>, dim3(v.K * ((v.R + 1) / 2)), dim3(64), 0, e->stream, v, write_aux, snap ? 1 : 0,
                        snap ? *snap : none);
+  } else if (e->Mmax <= 64) {   // one item per wave, 64 rows: 256 VGPRs of matrix data, still no LDS staging of Kzz
+    hipLaunchKernelGGL(k_build_reg<64>, dim3(v.K * v.R), dim3(64), 0, e->stream, v, write_aux, snap ? 1 : 0,
+                       snap ? *snap : none);
   } else {
     if (snap) {
       int gx = std::max(1, std::min(64, (v.R * e->Mmax + 255) / 256));
@@ -591,14 +600,10 @@ static int launch_times(svgpfa_engine* e, const double* times, const long long* 
   return SVGPFA_OK;
 }
 
-static size_t lds_prep_mfma(int NT) {
-  size_t MP = 16 * NT, LD = MP + 2;
-  return 2 * MP * LD * 8;
-}
 static void launch_prep(svgpfa_engine* e, const PtrTable& pt) {
   EngineView& v = e->v;
-  if (e->NT <= 2) {   // larger M: keep the scalar kernel (register budget of 3-4 tile panels)
-    DISPATCH_NT(e->NT, hipLaunchKernelGGL(k_prep_mfma<NT_>, dim3(v.R * v.K), dim3(64), lds_prep_mfma(NT_), e->stream, v, pt));
+  if (e->NT <= 4) {   // one wavefront per 16-column panel
+    DISPATCH_NT(e->NT, hipLaunchKernelGGL(k_prep_mfma<NT_>, dim3(v.R * v.K), dim3(64 * NT_), lds_prep_mfma(NT_), e->stream, v, pt));
     return;
   }
   if (e->pack == 2)
@@ -707,7 +712,7 @@ int svgpfa_elbo(svgpfa_engine* e, const double* const* mean, const double* const
     HIPCHK(e, hipStreamWaitEvent(sp, e->ev_spk[1], 0));
   }
   if (side) HIPCHK(e, hipStreamWaitEvent(sm, e->ev_spk[0], 0));
-  DISPATCH_NT(e->NT, FOR_TYPES(e, mitems, sm, sp, hipLaunchKernelGGL((k_bwd_mfma<NT_, KT_>), dim3(v.R * NKT_), dim3(64),
+  DISPATCH_NT(e->NT, FOR_TYPES(e, mitems, sm, sp, hipLaunchKernelGGL((k_bwd_mfma<NT_, KT_>), dim3(v.R * NKT_), dim3(64 * NT_),
                                                                      lds_bwd_mfma(NT_), ST_, v, pt, mask)));
   if (ov) {
     HIPCHK(e, hipEventRecord(e->ev_b1, sp));
@@ -777,7 +782,7 @@ int svgpfa_predict(svgpfa_engine* e, const double* const* mean, const double* co
 static int get_mm(svgpfa_engine* e, int k, const double* src, double* out) {
   if (!e || !out || k < 0 || k >= e->v.K) return SVGPFA_ERR_INVALID;
   if (!e->have_kernels) FAIL(e, SVGPFA_ERR_STATE, "svgpfa_build_kernels has not been called");
-  if (!e->aux_valid && e->Mmax <= 32) {   // Kzz / L are materialised on demand from the current snapshot
+  if (!e->aux_valid && e->Mmax <= 64) {   // Kzz / L are materialised on demand from the current snapshot
     launch_build(e, 1, nullptr);
     HIPCHK(e, hipGetLastError());
     e->aux_valid = true;
