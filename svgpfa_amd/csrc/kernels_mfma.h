@@ -722,10 +722,12 @@ __global__ __launch_bounds__(64 * NT) void k_prep_mfma(EngineView ev, LatentPtrT
 // recomputes the transposed tile instead of transposing through LDS.  log2(e) is folded into the LDS copy
 // of [C | C^2/2] and d, so that E = w 2^h.  The LOOPED operand matrix of the whole trial sits in LDS
 // (rows padded to LDK = 4 KS + 2 doubles: conflict-free fragment reads); the wave's own 16 rows of the
-// other matrix sit in a small per-wave LDS slice.  grid = R * parts blocks of 256 threads.
+// other matrix sit in a small per-wave LDS slice.  When the looped matrix exceeds the LDS budget (large N K or
+// Q K) it is streamed through LDS in chunks of lc tiles.  grid = R * parts blocks of 256 threads.
 template <int KS, int ROLE>
 __device__ __forceinline__ void quad_ell_mfma_body(const EngineView& ev, const double* C, const double* d,
-                                                   int want_sums, int write_ell, int parts, int blk, double* sm) {
+                                                   int want_sums, int write_ell, int parts, int lc, int blk,
+                                                   double* sm) {
   constexpr int KKP = 4 * KS, LDK = KKP + 2, KKT = (KKP + 15) / 16;
   const double L2E = 1.4426950408889634074, LN2 = 0.69314718055994530942;
   const int K = ev.K, N = ev.N, Q = ev.Q, K2 = 2 * K;
@@ -733,23 +735,25 @@ __device__ __forceinline__ void quad_ell_mfma_body(const EngineView& ev, const d
   const int LT = (ROLE == 0) ? QT : NTl;      // tiles of the looped dimension
   const int OT = (ROLE == 0) ? NTl : QT;      // tiles of the wave-owned dimension
   const int Lp = LT * 16;
+  const int LC = (lc < LT) ? lc : LT;         // looped tiles resident in LDS at a time (LC < LT: large N K or Q K)
+  const int Lrows = LC * 16;
   const int r = blk / parts, part = blk % parts;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 15, lg = lane >> 4;
-  double* LM = sm;                          // (Lp + 1) * LDK  looped matrix: ROLE 0 [mu | var], ROLE 1 log2e [C | C^2/2]
-  double* lv = LM + (Lp + 1) * LDK;         // Lp   looped vector: ROLE 0 w_q, ROLE 1 log2e d_n
+  double* LM = sm;                          // (Lrows + 1) * LDK  looped matrix: ROLE 0 [mu | var], ROLE 1 log2e [C | C^2/2]
+  double* lv = LM + (Lrows + 1) * LDK;      // Lp   looped vector: ROLE 0 w_q, ROLE 1 log2e d_n
   double* OW = lv + Lp;                     // 4 * 16 * LDK  per-wave rows of the other matrix
   double* red = OW + 4 * 16 * LDK;          // 8
+  const int lrows_tot = (ROLE == 0) ? Q : N;
 
-  // ---- fill the looped matrix: zero the padding, then batched independent loads (8 in flight per thread)
-  //      over the contiguous sources mu/var [Q x K] (ROLE 0) or C [N x K] (ROLE 1)
-  for (int e = tid; e < (Lp + 1) * LDK; e += 256) LM[e] = 0.0;
-  for (int i = tid; i < Lp; i += 256)
-    lv[i] = (ROLE == 0) ? ((i < Q) ? ev.wq[(long long)r * Q + i] : 0.0) : ((i < N) ? d[i] * L2E : 0.0);
-  __syncthreads();
-  {
-    const int tot = ((ROLE == 0) ? Q : N) * K;
-    const double* s0 = (ROLE == 0) ? ev.muq + (long long)r * Q * K : C;
-    const double* s1 = (ROLE == 0) ? ev.varq + (long long)r * Q * K : C;
+  // fill rows [row0, row0 + Lrows) of the looped matrix: zero the padding, then batched independent loads
+  // (8 in flight per thread) over the contiguous sources mu/var [Q x K] (ROLE 0) or C [N x K] (ROLE 1)
+  auto fill_lm = [&](int row0) {
+    for (int e = tid; e < (Lrows + 1) * LDK; e += 256) LM[e] = 0.0;
+    __syncthreads();
+    const int nrow = (lrows_tot - row0 < Lrows) ? (lrows_tot - row0) : Lrows;
+    const int tot = nrow * K;
+    const double* s0 = ((ROLE == 0) ? ev.muq + (long long)r * Q * K : C) + (long long)row0 * K;
+    const double* s1 = ((ROLE == 0) ? ev.varq + (long long)r * Q * K : C) + (long long)row0 * K;
     for (int b0 = 0; b0 < tot; b0 += 256 * 8) {
       double v0[8], v1[8];
 #pragma unroll
@@ -774,17 +778,24 @@ __device__ __forceinline__ void quad_ell_mfma_body(const EngineView& ev, const d
         }
       }
     }
-  }
-  __syncthreads();
+    __syncthreads();
+  };
+
+  for (int i = tid; i < Lp; i += 256)
+    lv[i] = (ROLE == 0) ? ((i < Q) ? ev.wq[(long long)r * Q + i] : 0.0) : ((i < N) ? d[i] * L2E : 0.0);
+  if (LC == LT) fill_lm(0);     // common case: the whole looped matrix stays resident
+  else __syncthreads();
 
   double esum = 0.0;
   double* ow = OW + wave * 16 * LDK;
-  for (int ot = part * 4 + wave; ot < OT; ot += parts * 4) {
+  for (int ot0 = part * 4; ot0 < OT; ot0 += parts * 4) {     // block-uniform rounds; wave `wave` owns tile ot0 + wave
+    const int ot = ot0 + wave;
+    const bool active = ot < OT;
     // own 16 rows -> per-wave LDS slice (wave-local: no block barrier needed); the source rows are
     // contiguous (16 K doubles): batched loads again
     for (int e = lane; e < 16 * LDK; e += 64) ow[e] = 0.0;
     lds_wave_fence();
-    {
+    if (active) {
       const int orows = (ROLE == 0) ? N : Q;
       const int nrow = (orows - ot * 16 < 16) ? (orows - ot * 16) : 16;
       const int tot = nrow * K;
@@ -815,8 +826,8 @@ __device__ __forceinline__ void quad_ell_mfma_body(const EngineView& ev, const d
     }
     lds_wave_fence();
     const int oi = ot * 16 + li;              // own index of this lane's column
-    const bool ook = oi < ((ROLE == 0) ? N : Q);
-    const double ov = (ROLE == 0) ? ((oi < N) ? d[oi] * L2E : 0.0) : ((oi < Q) ? ev.wq[(long long)r * Q + oi] : 0.0);
+    const bool ook = active && oi < ((ROLE == 0) ? N : Q);
+    const double ov = !ook ? 0.0 : ((ROLE == 0) ? d[oi] * L2E : ev.wq[(long long)r * Q + oi]);
     double bfrag[KS];                         // own rows as the B operand of the h product
 #pragma unroll
     for (int c = 0; c < KS; ++c) bfrag[c] = ow[li * LDK + 4 * c + lg];
@@ -824,35 +835,42 @@ __device__ __forceinline__ void quad_ell_mfma_body(const EngineView& ev, const d
 #pragma unroll
     for (int t = 0; t < KKT; ++t) acc[t] = (d4){0.0, 0.0, 0.0, 0.0};
     double colsum = 0.0;
-    for (int lt = 0; lt < LT; ++lt) {
-      d4 h = {0.0, 0.0, 0.0, 0.0};
+    for (int lt0 = 0; lt0 < LT; lt0 += LC) {
+      if (LC < LT) fill_lm(lt0 * 16);         // block-uniform: every wave takes part, active or not
+      const int lt1 = (lt0 + LC < LT) ? lt0 + LC : LT;
+      if (active)
+        for (int lt = lt0; lt < lt1; ++lt) {
+          const int lr = (lt - lt0) * 16;     // row of this tile inside the resident chunk
+          d4 h = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-      for (int c = 0; c < KS; ++c)
-        h = __builtin_amdgcn_mfma_f64_16x16x4f64(LM[(lt * 16 + li) * LDK + 4 * c + lg], bfrag[c], h, 0, 0, 0);
-      double afrag[KKT][4];                   // looped rows, transposed, for the sum product (independent of E)
-      if (want_sums) {
+          for (int c = 0; c < KS; ++c)
+            h = __builtin_amdgcn_mfma_f64_16x16x4f64(LM[(lr + li) * LDK + 4 * c + lg], bfrag[c], h, 0, 0, 0);
+          double afrag[KKT][4];               // looped rows, transposed, for the sum product (independent of E)
+          if (want_sums) {
 #pragma unroll
-        for (int t = 0; t < KKT; ++t)
+            for (int t = 0; t < KKT; ++t)
 #pragma unroll
-          for (int c = 0; c < 4; ++c) afrag[t][c] = LM[(lt * 16 + 4 * c + lg) * LDK + 16 * t + li];
-      }
-      d4 E;
+              for (int c = 0; c < 4; ++c) afrag[t][c] = LM[(lr + 4 * c + lg) * LDK + 16 * t + li];
+          }
+          d4 E;
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const int l = lt * 16 + lg + 4 * q;   // looped index of this element's row
-        // ROLE 0: E = w_q 2^(h + d_n) ; ROLE 1: E^T = w_q 2^(h^T + d_n)
-        const double x = (ROLE == 0) ? lv[l] * sv_exp2(h[q] + ov) : ov * sv_exp2(h[q] + lv[l]);
-        const bool lok = l < ((ROLE == 0) ? Q : N);
-        E[q] = (ook && lok) ? x : 0.0;
-        colsum += E[q];
-      }
-      if (want_sums) {
+          for (int q = 0; q < 4; ++q) {
+            const int l = lt * 16 + lg + 4 * q;   // looped index of this element's row
+            // ROLE 0: E = w_q 2^(h + d_n) ; ROLE 1: E^T = w_q 2^(h^T + d_n)
+            const double x = (ROLE == 0) ? lv[l] * sv_exp2(h[q] + ov) : ov * sv_exp2(h[q] + lv[l]);
+            const bool lok = l < lrows_tot;
+            E[q] = (ook && lok) ? x : 0.0;
+            colsum += E[q];
+          }
+          if (want_sums) {
 #pragma unroll
-        for (int t = 0; t < KKT; ++t)
+            for (int t = 0; t < KKT; ++t)
 #pragma unroll
-          for (int c = 0; c < 4; ++c)
-            acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(afrag[t][c], E[c], acc[t], 0, 0, 0);
-      }
+              for (int c = 0; c < 4; ++c)
+                acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(afrag[t][c], E[c], acc[t], 0, 0, 0);
+          }
+        }
+      if (LC < LT) __syncthreads();           // all waves done with this chunk before it is overwritten
     }
     esum += colsum;
     if (want_sums && ook) {
@@ -892,15 +910,16 @@ __device__ __forceinline__ void quad_ell_mfma_body(const EngineView& ev, const d
 // small shards, where each launch is latency- rather than throughput-bound.
 template <int KS, int ROLE>
 __global__ __launch_bounds__(256) void k_quad_ell_mfma(EngineView ev, const double* C, const double* d,
-                                                       int want_sums, int write_ell, int parts) {
+                                                       int want_sums, int write_ell, int parts, int lc0, int lc1) {
   extern __shared__ double sm[];
   if (ROLE == 2) {
     const int nb = ev.R * parts;
     if ((int)blockIdx.x < nb)
-      quad_ell_mfma_body<KS, 0>(ev, C, d, want_sums, 1, parts, blockIdx.x, sm);
+      quad_ell_mfma_body<KS, 0>(ev, C, d, want_sums, 1, parts, lc0, blockIdx.x, sm);
     else
-      quad_ell_mfma_body<KS, 1>(ev, C, d, 1, 0, parts, blockIdx.x - nb, sm);
+      quad_ell_mfma_body<KS, 1>(ev, C, d, 1, 0, parts, lc1, blockIdx.x - nb, sm);
   } else {
-    quad_ell_mfma_body<KS, (ROLE == 2 ? 0 : ROLE)>(ev, C, d, want_sums, write_ell, parts, blockIdx.x, sm);
+    quad_ell_mfma_body<KS, (ROLE == 2 ? 0 : ROLE)>(ev, C, d, want_sums, write_ell, parts, ROLE == 0 ? lc0 : lc1,
+                                                    blockIdx.x, sm);
   }
 }

@@ -27,7 +27,8 @@ struct svgpfa_engine {
   hipStream_t stream = nullptr;
   int device = 0;
   int Mmax = 0, KT = 0, NT = 1, pack = 1;
-  int ell_parts = 0, KKT = 1;  // ell_parts > 0: MFMA GEMM form of the quadrature term (fits LDS)
+  int ell_parts = 0, KKT = 1;  // ell_parts > 0: MFMA GEMM form of the quadrature term
+  int ell_lc[2] = {0, 0};      // looped tiles resident in LDS per role (fewer than all: streamed in chunks)
   long long totM = 0, totMM = 0;  // R*sum M, R*sum M^2
   bool have_quad = false, have_spikes = false, have_kernels = false, have_stats = false;
   bool aux_valid = false;   // Kzz / L buffers hold the matrices of the current kernel snapshot (getters only)
@@ -105,11 +106,19 @@ static size_t lds_qbwd_mfma(int NT) {
     case 3: { constexpr int NT_ = 3; __VA_ARGS__; } break;   \
     default: { constexpr int NT_ = 4; __VA_ARGS__; } break;  \
   }
-static size_t lds_qell_mfma(const svgpfa_engine* e, int role) {
+// LDS of k_quad_ell_mfma with lc looped tiles resident; qell_chunk = the largest lc within the budget (0: none fits)
+static size_t lds_qell_mfma_lc(const svgpfa_engine* e, int role, int lc) {
   size_t K2 = 2 * e->v.K, KKP = (K2 + 3) & ~(size_t)3, LDK = KKP + 2;
   size_t Lp = (((role == 0 ? e->v.Q : e->v.N) + 15) / 16) * 16;
-  return ((Lp + 1) * LDK + Lp + 4 * 16 * LDK + 8) * 8;
+  return (((size_t)lc * 16 + 1) * LDK + Lp + 4 * 16 * LDK + 8) * 8;
 }
+static int qell_chunk(const svgpfa_engine* e, int role) {
+  const int LT = ((role == 0 ? e->v.Q : e->v.N) + 15) / 16;
+  int lc = LT;
+  while (lc > 0 && lds_qell_mfma_lc(e, role, lc) > 64 * 1024) --lc;
+  return lc;
+}
+static size_t lds_qell_mfma(const svgpfa_engine* e, int role) { return lds_qell_mfma_lc(e, role, e->ell_lc[role]); }
 #define DISPATCH_KS(ks, ...)                                                                            \
   switch (ks) {                                                                                         \
     case 1: { constexpr int KS_ = 1; __VA_ARGS__; } break;   case 2: { constexpr int KS_ = 2; __VA_ARGS__; } break;   \
@@ -255,7 +264,9 @@ int svgpfa_create(const svgpfa_dims* d, int device, svgpfa_engine** out) {
   DALLOC(e, v.gthq, (size_t)v.R * v.K * 2);
   size_t nblk = (size_t)v.R * v.nqt;
   e->KKT = (2 * v.K + 3) / 4;   // KS: k-steps of the h product
-  e->ell_parts = (std::max(lds_qell_mfma(e, 0), lds_qell_mfma(e, 1)) <= 64 * 1024) ? 4 : 0;
+  e->ell_lc[0] = qell_chunk(e, 0);
+  e->ell_lc[1] = qell_chunk(e, 1);
+  e->ell_parts = (e->ell_lc[0] > 0 && e->ell_lc[1] > 0 && e->KKT <= 16) ? 4 : 0;
   v.ncd = e->ell_parts ? v.R : (int)nblk;
   v.nell = e->ell_parts ? v.R * e->ell_parts : (int)nblk;
   DALLOC(e, v.gCpart, (size_t)v.ncd * v.N * 2 * v.K); DALLOC(e, v.gdpart, (size_t)v.ncd * v.N);
@@ -564,13 +575,13 @@ static int launch_quad_ell(svgpfa_engine* e, const double* C, const double* d, i
     if (want_lat && (long long)v.R * v.K <= e->merge_items) {   // small shard: both roles in one launch
       const size_t l2 = std::max(lds_qell_mfma(e, 0), lds_qell_mfma(e, 1));
       DISPATCH_KS(e->KKT, hipLaunchKernelGGL((k_quad_ell_mfma<KS_, 2>), dim3(2 * gm.x), bm, l2, e->stream, v, C, d, want_cd,
-                                             1, e->ell_parts));
+                                             1, e->ell_parts, e->ell_lc[0], e->ell_lc[1]));
     } else {
       DISPATCH_KS(e->KKT,
                   hipLaunchKernelGGL((k_quad_ell_mfma<KS_, 0>), gm, bm, lds_qell_mfma(e, 0), e->stream, v, C, d, want_cd, 1,
-                                     e->ell_parts);
+                                     e->ell_parts, e->ell_lc[0], e->ell_lc[1]);
                   if (want_lat) hipLaunchKernelGGL((k_quad_ell_mfma<KS_, 1>), gm, bm, lds_qell_mfma(e, 1), e->stream, v, C,
-                                                   d, 1, 0, e->ell_parts));
+                                                   d, 1, 0, e->ell_parts, e->ell_lc[0], e->ell_lc[1]));
     }
     HIPCHK(e, hipGetLastError());
     return SVGPFA_OK;
