@@ -5,6 +5,11 @@ first; the embedding step freezes the latent statistics and optimises the ELL on
 TerminationInfo returned in the same tuple.  The reference's own SVEM_PyTorch also drives the engine-backed
 model unchanged; this mirror exists because the reference's source cannot travel to the GPU box.
 
+With trials sharded over ranks (torch.distributed initialised, world size > 1, model attached through
+svgpfa_amd.distributed.attach) every rank runs this same loop on its own trials: the per-trial groups (E-step,
+inducing-point locations) and the replicated groups (embedding, kernel parameters) are then optimised by
+svgpfa_amd.stats.shardedLBFGS.ShardedLBFGS, which exchanges inner products only.
+
 Left out on purpose: the lock-file streaming for the legacy GUI."""
 import copy
 import io
@@ -108,13 +113,14 @@ class SVEM_PyTorch:
     # ---- the four conditional maximisations (svEM.py:218-264)
     def _eStep(self, model, optim_params):
         x = model.getSVPosteriorOnIndPointsParams()
-        return self._lbfgs_step(x, model.eval, optim_params)
+        return self._lbfgs_step(x, model.eval, optim_params, per_trial=True)
 
     def _mStepEmbedding(self, model, optim_params):
         x = model.getSVEmbeddingParams()
         stats = model.computeSVPosteriorOnLatentsStats()
         return self._lbfgs_step(
-            x, lambda: model.evalELLSumAcrossTrialsAndNeurons(svPosteriorOnLatentsStats=stats), optim_params)
+            x, lambda: model.evalELLSumAcrossTrialsAndNeurons(svPosteriorOnLatentsStats=stats), optim_params,
+            per_trial=False)
 
     def _mStepKernels(self, model, optim_params):
         x = model.getKernelsParams()
@@ -124,7 +130,7 @@ class SVEM_PyTorch:
             model.buildKernelsMatrices()
             return model.eval()
         try:
-            return self._lbfgs_step(x, evalFunc, optim_params)
+            return self._lbfgs_step(x, evalFunc, optim_params, per_trial=False)
         except Exception:                                  # svEM.py:246-253: roll the kernel params back
             for t, p in zip(x, previous):
                 t.requires_grad_(False)
@@ -137,11 +143,17 @@ class SVEM_PyTorch:
         def evalFunc():
             model.buildKernelsMatrices()
             return model.eval()
-        return self._lbfgs_step(x, evalFunc, optim_params)
+        return self._lbfgs_step(x, evalFunc, optim_params, per_trial=True)
 
     @staticmethod
-    def _lbfgs_step(x, evalFunc, optim_params):
-        optimizer = torch.optim.LBFGS(x, **optim_params)
+    def _lbfgs_step(x, evalFunc, optim_params, per_trial):
+        """per_trial: the group lives on the owner of each trial (means, cholVecs, Z); otherwise it is replicated."""
+        import torch.distributed as dist
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+            from svgpfa_amd.stats.shardedLBFGS import ShardedLBFGS
+            optimizer = ShardedLBFGS(x if per_trial else [], [] if per_trial else x, **optim_params)
+        else:
+            optimizer = torch.optim.LBFGS(x, **optim_params)
         for t in x:
             t.requires_grad_(True)
         try:
