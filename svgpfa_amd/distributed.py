@@ -13,7 +13,12 @@ import torch.distributed as dist
 def allreduce_shared(shared, group=None):
     """In-place sum of the shared vector over ranks; no-op without an initialised process group."""
     if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
-        dist.all_reduce(shared, op=dist.ReduceOp.SUM, group=group)
+        if shared.is_cuda and dist.get_backend(group) == "gloo":     # CPU rehearsal of the exchange (tests)
+            host = shared.cpu()
+            dist.all_reduce(host, op=dist.ReduceOp.SUM, group=group)
+            shared.copy_(host)
+        else:
+            dist.all_reduce(shared, op=dist.ReduceOp.SUM, group=group)
     return shared
 
 

@@ -105,6 +105,8 @@ class ShardedLBFGS:
         if self._world == 1 or not parts:
             return sums, maxes
         buf = torch.cat(parts)
+        if buf.is_cuda and dist.get_backend(self._group) == "gloo":   # CPU rehearsal of the exchange (tests)
+            buf = buf.cpu()
         out = [torch.empty_like(buf) for _ in range(self._world)]
         dist.all_gather(out, buf, group=self._group)
         self.collectives += 1
