@@ -19,6 +19,7 @@ it is a drop-in for it; tests/test_sharded_lbfgs.py checks both the one-rank equ
 """
 import math
 
+import numpy as np
 import torch
 import torch.distributed as dist
 
@@ -132,7 +133,7 @@ class ShardedLBFGS:
             return orig_loss
 
         d, t = st.get("d"), st.get("t")
-        S, Y = st.get("S", []), st.get("Y", [])
+        Sb, Yb, m = st.get("Sb"), st.get("Yb"), st.get("m", 0)      # history rows 0..m-1 (oldest first)
         SY, YY = st.get("SY"), st.get("YY")
         H = st.get("H", 1.0)
         prev_g, prev_loss = st.get("prev_g"), st.get("prev_loss")
@@ -145,63 +146,61 @@ class ShardedLBFGS:
                 (gg, gabs), _ = self._reduce(part, None)
                 gg, gabs = float(gg), float(gabs)
                 d = g.neg()
-                S, Y = [], []
-                SY = YY = torch.zeros(0, 0, dtype=torch.double)
+                m = 0
+                SY = YY = np.zeros((0, 0))
                 H = 1.0
                 gtd = -gg
             else:
                 y = g - prev_g
                 s = d * t
-                m = len(S)
                 gw, yw, sw = g * w, y * w, s * w
                 head = torch.stack([yw.dot(s), yw.dot(y), gw.dot(g), sw.dot(g), yw.dot(g)])
                 if m:
-                    Sm, Ym = torch.stack(S), torch.stack(Y)
+                    Sm, Ym = Sb[:m], Yb[:m]
                     part = torch.cat([head, Sm @ yw, Ym @ sw, Ym @ yw, Sm @ gw, Ym @ gw])
                 else:
                     part = head
                 tot, _ = self._reduce(part, None)
-                tot = tot.double().cpu()
+                tot = tot.double().cpu().numpy()                      # the one host sync of the iteration
                 ys, yy, gg, sg, yg = (float(v) for v in tot[:5])
                 S_y, s_Y, Y_y, S_g, Y_g = (tot[5 + i * m:5 + (i + 1) * m] for i in range(5))
                 if ys > 1e-10:
                     if m == self.history_size:       # drop the oldest pair
-                        S.pop(0)
-                        Y.pop(0)
+                        Sb[:m - 1] = Sb[1:m].clone()
+                        Yb[:m - 1] = Yb[1:m].clone()
                         SY, YY = SY[1:, 1:], YY[1:, 1:]
                         S_y, s_Y, Y_y, S_g, Y_g = S_y[1:], s_Y[1:], Y_y[1:], S_g[1:], Y_g[1:]
                         m -= 1
-                    S.append(s)
-                    Y.append(y)
-                    nSY = torch.zeros(m + 1, m + 1, dtype=torch.double)
-                    nYY = torch.zeros(m + 1, m + 1, dtype=torch.double)
+                    if Sb is None or m == Sb.shape[0]:               # grow the history buffers geometrically
+                        cap = min(self.history_size, max(8, 2 * m))
+                        nS, nY = g.new_empty(cap, g.numel()), g.new_empty(cap, g.numel())
+                        if m:
+                            nS[:m], nY[:m] = Sb[:m], Yb[:m]
+                        Sb, Yb = nS, nY
+                    Sb[m], Yb[m] = s, y
+                    nSY, nYY = np.zeros((m + 1, m + 1)), np.zeros((m + 1, m + 1))
                     nSY[:m, :m], nYY[:m, :m] = SY, YY
                     nSY[:m, m], nSY[m, :m], nSY[m, m] = S_y, s_Y, ys       # SY[i, j] = s_i . y_j
                     nYY[:m, m], nYY[m, :m], nYY[m, m] = Y_y, Y_y, yy
                     SY, YY = nSY, nYY
-                    S_g = torch.cat([S_g, torch.tensor([sg], dtype=torch.double)])
-                    Y_g = torch.cat([Y_g, torch.tensor([yg], dtype=torch.double)])
+                    S_g, Y_g = np.append(S_g, sg), np.append(Y_g, yg)
                     H = ys / yy
                     m += 1
                 # two-loop recursion on coefficients: q = -g - sum_j al_j y_j ; r = H q + sum_j (al_j - be_j) s_j
-                al = [0.0] * m
-                be = [0.0] * m
+                al, be = np.zeros(m), np.zeros(m)
+                dg = np.diag(SY).copy() if m else np.zeros(0)
                 for i in range(m - 1, -1, -1):
-                    sq = -float(S_g[i]) - sum(al[j] * float(SY[i, j]) for j in range(i + 1, m))
-                    al[i] = sq / float(SY[i, i])
+                    al[i] = (-S_g[i] - al[i + 1:].dot(SY[i, i + 1:])) / dg[i]
+                yq = -Y_g - YY.dot(al) if m else np.zeros(0)
                 for i in range(m):
-                    yr = H * (-float(Y_g[i]) - sum(al[j] * float(YY[i, j]) for j in range(m))) \
-                        + sum((al[j] - be[j]) * float(SY[j, i]) for j in range(i))
-                    be[i] = yr / float(SY[i, i])
+                    be[i] = (H * yq[i] + (al[:i] - be[:i]).dot(SY[:i, i])) / dg[i]
                 d = g.mul(-H)
                 gtd = -H * gg
                 if m:
-                    ca = torch.tensor(al, dtype=g.dtype, device=g.device)
-                    cs = torch.tensor([a - b for a, b in zip(al, be)], dtype=g.dtype, device=g.device)
-                    d.add_(torch.stack(Y).t() @ ca, alpha=-H)
-                    d.add_(torch.stack(S).t() @ cs)
-                    gtd += -H * sum(al[j] * float(Y_g[j]) for j in range(m)) \
-                        + sum((al[j] - be[j]) * float(S_g[j]) for j in range(m))
+                    coef = torch.from_numpy(np.concatenate([-H * al, al - be])).to(device=g.device, dtype=g.dtype)
+                    d.addmv_(Yb[:m].t(), coef[:m])
+                    d.addmv_(Sb[:m].t(), coef[m:])
+                    gtd += float(-H * al.dot(Y_g) + (al - be).dot(S_g))
             prev_g = g.clone()
             prev_loss = loss
             t = min(1.0, 1.0 / gabs) * self.lr if st["n_iter"] == 1 else self.lr
@@ -212,12 +211,14 @@ class ShardedLBFGS:
             if self.line_search_fn == "strong_wolfe":
                 x0 = self._clone()
 
-                def phi(step):
+                def phi(step):                 # -> (loss, flat gradient, g . d) at x0 + step d; ONE host sync
                     self._add(step, d)
-                    f = float(closure())
+                    f = closure()
                     gn = self._flat_grad()
                     self._restore(x0)
-                    return f, gn
+                    part, _ = self._reduce(((gn * w).dot(d)).reshape(1), None)
+                    both = torch.stack([f.detach().reshape(()).to(part.device, part.dtype), part[0]]).cpu()
+                    return float(both[0]), gn, float(both[1])
                 loss, g, t, ls_evals = self._strong_wolfe(phi, t, d, loss, g, gtd)
                 self._add(t, d)
                 _, mx = self._reduce(None, torch.stack([g.abs().max(), d.abs().max()]))
@@ -246,21 +247,16 @@ class ShardedLBFGS:
             if abs(loss - prev_loss) < tc:
                 break
 
-        st.update(d=d, t=t, S=S, Y=Y, SY=SY, YY=YY, H=H, prev_g=prev_g, prev_loss=prev_loss)
+        st.update(d=d, t=t, Sb=Sb, Yb=Yb, m=m, SY=SY, YY=YY, H=H, prev_g=prev_g, prev_loss=prev_loss)
         return orig_loss
 
-    def _gtd(self, g, d):
-        tot, _ = self._reduce(((g * self._w).dot(d)).reshape(1), None)
-        return float(tot[0])
-
     def _strong_wolfe(self, phi, t, d, f, g, gtd, c1=1e-4, c2=0.9, max_ls=25):
-        """Bracketing + zoom line search for the strong Wolfe conditions; phi(t) -> (loss, flat grad) at x + t d."""
+        """Bracketing + zoom line search for the strong Wolfe conditions; phi(t) -> (loss, flat grad, grad . d)."""
         tc = self.tolerance_change
         _, mx = self._reduce(None, d.abs().max().reshape(1))
         d_norm = float(mx[0])
-        f_new, g_new = phi(t)
+        f_new, g_new, gtd_new = phi(t)
         n_eval = 1
-        gtd_new = self._gtd(g_new, d)
         t_prev, f_prev, g_prev, gtd_prev = 0.0, f, g, gtd
         done = False
         it = 0
@@ -277,9 +273,8 @@ class ShardedLBFGS:
             t_next = _cubic_min(t_prev, f_prev, gtd_prev, t, f_new, gtd_new, bounds=(lo_step, hi_step))
             t_prev, f_prev, g_prev, gtd_prev = t, f_new, g_new, gtd_new
             t = t_next
-            f_new, g_new = phi(t)
+            f_new, g_new, gtd_new = phi(t)
             n_eval += 1
-            gtd_new = self._gtd(g_new, d)
             it += 1
         if br is None:                      # ran out of bracketing iterations
             br = [[0.0, f, g, gtd], [t, f_new, g_new, gtd_new]]
@@ -300,9 +295,8 @@ class ShardedLBFGS:
                     insufficient = True
             else:
                 insufficient = False
-            f_new, g_new = phi(t)
+            f_new, g_new, gtd_new = phi(t)
             n_eval += 1
-            gtd_new = self._gtd(g_new, d)
             it += 1
             if f_new > f + c1 * t * gtd or f_new >= br[lo][1]:
                 br[hi] = [t, f_new, g_new, gtd_new]
