@@ -182,6 +182,37 @@ def test_launch_strategies_agree(monkeypatch):
             assert torch.equal(a, b)
 
 
+def _drop_spikes(prob, keep_trial):
+    """Remove every spike of the trials for which keep_trial(r) is False (CSR arrays rebuilt)."""
+    off = prob["spike_offsets"]
+    keep = np.concatenate([np.full(off[r + 1] - off[r], bool(keep_trial(r))) for r in range(prob["R"])])
+    out = dict(prob)
+    cnt = np.array([(off[r + 1] - off[r]) if keep_trial(r) else 0 for r in range(prob["R"])], dtype=np.int64)
+    out["spike_offsets"] = np.concatenate([[0], np.cumsum(cnt)]).astype(np.int64)
+    out["spike_times"] = prob["spike_times"][keep]
+    out["spike_neuron"] = prob["spike_neuron"][keep]
+    return out
+
+
+@pytest.mark.parametrize("which", ["one_empty_trial", "no_spikes_at_all"])
+def test_empty_trials(which):
+    """Edge cases of the spike CSR: a trial without spikes, and a data set without any spike (ELL = quadrature term only)."""
+    from oracle import svgpfa_oracle as orc
+    prob = synthetic.make_problem(R=3, N=6, K=2, M=[7, 5], kernels="mix", seed=17, n_quad=30, rate=5.0, jitter=1.0)
+    prob = _drop_spikes(prob, (lambda r: r != 1) if which == "one_empty_trial" else (lambda r: False))
+    eng, P = _engine(prob)
+    out = _eval(eng, P, 15)
+    ref = orc.elbo_and_grads(orc.from_numpy_problem(prob), 15)
+    assert _close(out["elbo"], float(ref["elbo"]), TOL_S)
+    assert rel_err(out["g_C"], ref["g_C"].numpy()) < TOL_A
+    assert rel_err(out["g_d"], ref["g_d"].numpy()) < TOL_A
+    for k in range(prob["K"]):
+        assert rel_err(out["g_mean"][k], ref["g_mean"][k].numpy()[:, :, 0]) < TOL_A
+        assert rel_err(out["g_cholVecs"][k], ref["g_cholVecs"][k].numpy()[:, :, 0]) < TOL_A
+        assert rel_err(out["g_Z"][k], ref["g_Z"][k].numpy()[:, :, 0]) < TOL_A
+        assert rel_err(out["g_theta"][k], ref["g_theta"][k].numpy()) < TOL_A
+
+
 def test_half_size_spike_chunks(monkeypatch):
     """Optional 4-spikes-per-lane granularity of the spike pass (SVGPFA_SMALL_SPIKE_WAVES): different chunking,
     same sums to rounding (tolerance 1e-11 relative on the ELBO, 1e-9 on gradients)."""
