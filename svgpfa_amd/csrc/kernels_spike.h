@@ -234,20 +234,23 @@ __global__ void k_mseg(EngineView ev) {
   ev.Mseg[id] = s;
 }
 
+#define SV_FIN_OUT 16   // outputs per block of k_finalize
+#define SV_FIN_GRP 16   // trial groups per block (256 threads): more, smaller blocks fill the chip better than 32 x 8
 // ------------------------------------------------------------------------------ k_finalize
 // Fixed-order reductions of the per-trial partials into the `shared` output vector
 // [ELBO, ELL, KL, dC (N*K), dd (N), dtheta].  Block roles by blockIdx:
-//   [0, nbC)            dC : 32 outputs x 8 trial groups per block; each thread sums its trials'
-//                            quadrature and spike partials, then the 8 groups are added in order
+//   [0, nbC)            dC : SV_FIN_OUT outputs x SV_FIN_GRP trial groups per block; each thread sums its trials'
+//                            quadrature and spike partials, then the groups are added in order
 //                            through LDS
 //   [nbC, nbC+nbD)      dd, [.., +nbT) dtheta : same scheme
 //   last block          the three scalars
 __global__ __launch_bounds__(256) void k_finalize(EngineView ev, const double* C, const double* d, unsigned mask,
                                                   double* shared) {
-  __shared__ double red[8 * 32];
-  const int tid = threadIdx.x, o = tid & 31, pg = tid >> 5;
+  __shared__ double red[SV_FIN_GRP * SV_FIN_OUT];
+  const int tid = threadIdx.x, o = tid % SV_FIN_OUT, pg = tid / SV_FIN_OUT;
   const int NK = ev.N * ev.K, N = ev.N, K = ev.K, R = ev.R;
-  const int nbC = (NK + 31) / 32, nbD = (N + 31) / 32, nbT = (ev.nth_total + 31) / 32;
+  const int nbC = (NK + SV_FIN_OUT - 1) / SV_FIN_OUT, nbD = (N + SV_FIN_OUT - 1) / SV_FIN_OUT,
+            nbT = (ev.nth_total + SV_FIN_OUT - 1) / SV_FIN_OUT;
   int blk = blockIdx.x;
   if (blk == nbC + nbD + nbT) {
     double e = 0.0, kl = 0.0;
@@ -269,14 +272,14 @@ __global__ __launch_bounds__(256) void k_finalize(EngineView ev, const double* C
   double s = 0.0;
   int out = -1;
   if (blk < nbC) {
-    const int id = blk * 32 + o;
+    const int id = blk * SV_FIN_OUT + o;
     if (id < NK) {
       out = 3 + id;
       if (mask & 2u) {
         const int n = id / K, k = id % K;
         const double cnk = C[id];
-        for (int r = pg; r < R; r += 8) s += ev.gCspk[(long long)r * NK + id];
-        for (int b = pg; b < ev.ncd; b += 8) {      // dC = -(E^T mu + C . E^T var)
+        for (int r = pg; r < R; r += SV_FIN_GRP) s += ev.gCspk[(long long)r * NK + id];
+        for (int b = pg; b < ev.ncd; b += SV_FIN_GRP) {      // dC = -(E^T mu + C . E^T var)
           const long long o = ((long long)b * N + n) * 2 * K + k;
           s -= ev.gCpart[o] + cnk * ev.gCpart[o + K];
         }
@@ -288,32 +291,32 @@ __global__ __launch_bounds__(256) void k_finalize(EngineView ev, const double* C
       }
     }
   } else if (blk < nbC + nbD) {
-    const int n = (blk - nbC) * 32 + o;
+    const int n = (blk - nbC) * SV_FIN_OUT + o;
     if (n < N) {
       out = 3 + NK + n;
       if (mask & 2u) {
-        for (int b = pg; b < ev.ncd; b += 8) s += ev.gdpart[(long long)b * N + n];
+        for (int b = pg; b < ev.ncd; b += SV_FIN_GRP) s += ev.gdpart[(long long)b * N + n];
         if (pg == 0) s += ev.spk_cnt[n];
       }
     }
   } else {
-    const int ti = (blk - nbC - nbD) * 32 + o;
+    const int ti = (blk - nbC - nbD) * SV_FIN_OUT + o;
     if (ti < ev.nth_total) {
       out = 3 + NK + N + ti;
       if (mask & 4u) {
         int k = 0;
         while (k + 1 < K && ev.meta[k + 1].thoff <= ti) ++k;
         const int t = ti - ev.meta[k].thoff;
-        for (int r = pg; r < R; r += 8) s += ev.gthitem[((long long)r * K + k) * 2 + t];
+        for (int r = pg; r < R; r += SV_FIN_GRP) s += ev.gthitem[((long long)r * K + k) * 2 + t];
       }
     }
   }
-  red[pg * 32 + o] = s;
+  red[pg * SV_FIN_OUT + o] = s;
   __syncthreads();
   if (pg == 0 && out >= 0) {
     double t = red[o];
 #pragma unroll
-    for (int g = 1; g < 8; ++g) t += red[g * 32 + o];
+    for (int g = 1; g < SV_FIN_GRP; ++g) t += red[g * SV_FIN_OUT + o];
     shared[out] = t;
   }
 }

@@ -266,7 +266,10 @@ int svgpfa_create(const svgpfa_dims* d, int device, svgpfa_engine** out) {
   e->KKT = (2 * v.K + 3) / 4;   // KS: k-steps of the h product
   e->ell_lc[0] = qell_chunk(e, 0);
   e->ell_lc[1] = qell_chunk(e, 1);
-  e->ell_parts = (e->ell_lc[0] > 0 && e->ell_lc[1] > 0 && e->KKT <= 16) ? 4 : 0;
+  // blocks per trial of the ELL kernels: every block re-stages the trial's looped operand in LDS, so fewer blocks
+  // per trial are cheaper as long as the grid still fills the chip (measured on cfg3: 1 -> 151 us, 4 -> 168 us)
+  e->ell_parts = (e->ell_lc[0] > 0 && e->ell_lc[1] > 0 && e->KKT <= 16) ? std::min(4, std::max(1, (383 + v.R) / v.R)) : 0;
+  if (e->ell_parts && getenv("SVGPFA_ELL_PARTS")) e->ell_parts = std::max(1, atoi(getenv("SVGPFA_ELL_PARTS")));
   v.ncd = e->ell_parts ? v.R : (int)nblk;
   v.nell = e->ell_parts ? v.R * e->ell_parts : (int)nblk;
   DALLOC(e, v.gCpart, (size_t)v.ncd * v.N * 2 * v.K); DALLOC(e, v.gdpart, (size_t)v.ncd * v.N);
@@ -729,7 +732,8 @@ int svgpfa_elbo(svgpfa_engine* e, const double* const* mean, const double* const
     HIPCHK(e, hipEventRecord(e->ev_b1, sp));
     HIPCHK(e, hipStreamWaitEvent(sm, e->ev_b1, 0));
   }
-  int nfin = (v.N * v.K + 31) / 32 + (v.N + 31) / 32 + (v.nth_total + 31) / 32 + 1;
+  int nfin = (v.N * v.K + SV_FIN_OUT - 1) / SV_FIN_OUT + (v.N + SV_FIN_OUT - 1) / SV_FIN_OUT +
+             (v.nth_total + SV_FIN_OUT - 1) / SV_FIN_OUT + 1;
   hipLaunchKernelGGL(k_finalize, dim3(nfin), dim3(256), 0, e->stream, v, C, d, mask, shared);
   HIPCHK(e, hipGetLastError());
   return SVGPFA_OK;
