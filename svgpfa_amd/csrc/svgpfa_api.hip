@@ -51,7 +51,10 @@ struct svgpfa_engine {
   long long small_spike_waves = 0;       // below this many (chunk, latent) waves at SPL = 8, use SPL = 4 (measured slower on
                                          // cfg3 shards: per-wave epilogue dominates; kept as an option, SVGPFA_SMALL_SPIKE_WAVES)
   long long overlap_thresh = 8192;
-  long long merge_items = 2048, merge_spike_blocks = 8192;   // merged-type launches below these grid sizes
+  // Per-item kernels (times / ELL roles / quad_bwd / bwd) are launched ONCE over all latents with the covariance type
+  // resolved per block (measured faster at every size: fewer launches, shorter grid tails; cfg3 +3 %).  The spike
+  // pass keeps one launch per type above merge_spike_blocks (the merged kernel carries the periodic type's VGPR count).
+  long long merge_items = 1LL << 40, merge_spike_blocks = 8192;
   hipEvent_t ev_prep = nullptr, ev_t1 = nullptr, ev_ell = nullptr, ev_spk[2] = {nullptr, nullptr}, ev_b1 = nullptr;
 };
 
@@ -655,7 +658,7 @@ int svgpfa_elbo(svgpfa_engine* e, const double* const* mean, const double* const
   // small shards: every launch is latency-bound and under-fills the chip, so the spike pass runs beside the
   // quadrature chain on one side stream (two cross-stream edges: prep -> spike, spike -> bwd)
   const bool side = !ov && v.nchunks > 0 &&
-                    (e->overlap_mode == 3 || (e->overlap_mode == 4 && (long long)v.R * v.K <= e->merge_items));
+                    (e->overlap_mode == 3 || (e->overlap_mode == 4 && (long long)v.R * v.K <= 2048));
   hipStream_t sk[2] = {ov ? e->s_spk[0] : (side ? e->s_side : sm), ov ? e->s_spk[1] : (side ? e->s_side : sm)};
   if (side) {
     HIPCHK(e, hipEventRecord(e->ev_prep, sm));
