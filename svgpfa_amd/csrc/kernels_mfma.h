@@ -179,6 +179,7 @@ __global__ __launch_bounds__(256) void k_times_fwd_mfma(EngineView ev, const dou
 // ------------------------------------------------------------------------- k_quad_bwd_mfma
 // Adjoints of the quadrature term wrt ut (gt), Vt Vt^T (Gt) and -- FULL -- the direct dependence
 // on Z / theta through kappa(t_q, Z).  grid = R*K blocks of 256 threads.
+// (forcing 3 waves/SIMD with amdgpu_waves_per_eu spills 76 VGPRs and is 36 % slower: the FULL variant stays at 2)
 template <int NT, int KT, bool FULL>
 __device__ void quad_bwd_mfma_body(const EngineView& ev, const int r, const int k, double* sm) {
   constexpr int MP = 16 * NT, LD = MP + 2, NTRI = NT * (NT + 1) / 2;
