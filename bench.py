@@ -172,6 +172,11 @@ def main():
         if use_dist:
             dist.all_reduce(shared)   # RCCL sum of [ELBO, ELL, KL, dC, dd, dtheta]
 
+    # one-off initialisation outside the W + K protocol: first launches load the code objects and create the RCCL
+    # communicator channels lazily; W warm-up steps then run at steady state even when W is small
+    for _ in range(3):
+        step()
+    eng.sync()
     for _ in range(args.warmup):
         step()
     eng.sync()
