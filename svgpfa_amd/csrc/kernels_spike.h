@@ -207,11 +207,16 @@ __global__ __launch_bounds__(64) void k_spike(EngineView ev, const double* __res
   __shared__ double red[NVM * 8 * 65 + 3 * 64];             // LDS bounds the waves per CU: keep it to what the type needs
   const int item = blockIdx.x;
   if (KT == 2) {
-    const int ch = item / ev.K, k = item % ev.K;
-    if (ev.meta[k].ktype == SV_RBF)
-      spike_body<SV_RBF, FULL, SPL>(ev, C, ch, k, red);
-    else
-      spike_body<SV_PERIODIC, FULL, SPL>(ev, C, ch, k, red);
+    // longest jobs first: all periodic (chunk, latent) items, then the RBF ones, so that the tail of the grid is
+    // filled with the shorter work items (a small shard is only 2-3 occupancy rounds long)
+    const int nper = ev.ntype[SV_PERIODIC], nrbf = ev.ntype[SV_RBF];
+    const int nb_per = ev.nchunks * nper;
+    if (item < nb_per) {
+      spike_body<SV_PERIODIC, FULL, SPL>(ev, C, item / nper, ev.klist[SV_PERIODIC][item % nper], red);
+    } else {
+      const int it = item - nb_per;
+      spike_body<SV_RBF, FULL, SPL>(ev, C, it / nrbf, ev.klist[SV_RBF][it % nrbf], red);
+    }
   } else {
     const int nk = ev.ntype[KT == 2 ? 0 : KT];
     const int ch = item / nk, k = ev.klist[KT == 2 ? 0 : KT][item % nk];
