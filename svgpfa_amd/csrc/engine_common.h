@@ -62,7 +62,7 @@ struct SpikeChunk {
 // Everything a kernel needs, passed by value (fits well inside the kernarg segment).
 struct EngineView {
   int R, N, K, Q, S;
-  int sumM, nchunks, nqt, qtile, nth_total;
+  int sumM, nchunks, nth_total;
   int ncd, nell;              // rows of dC / dd partials ([ncd][N][2K], [ncd][N]) and number of ELL partials
   int ntype[2];               // number of RBF / periodic latents
   int klist[2][SV_MAX_K];     // their indices: kernels are launched once per covariance type

@@ -26,7 +26,7 @@ struct svgpfa_engine {
   std::vector<void*> allocs;
   hipStream_t stream = nullptr;
   int device = 0;
-  int Mmax = 0, KT = 0, NT = 1, pack = 1;
+  int Mmax = 0, NT = 1;
   int ell_parts = 0, KKT = 1;  // ell_parts > 0: MFMA GEMM form of the quadrature term
   int ell_lc[2] = {0, 0};      // looped tiles resident in LDS per role (fewer than all: streamed in chunks)
   long long totM = 0, totMM = 0;  // R*sum M, R*sum M^2
@@ -37,25 +37,18 @@ struct svgpfa_engine {
   size_t ev_used = 0;
   std::string err;
   int* status_host = nullptr;  // pinned
-  // Concurrency for SMALL shards (strong scaling): when a shard's grids are below ~2 GPU rounds the
-  // pipeline is a chain of per-kernel latency floors, so the spike pass (2 streams, one per covariance
-  // type) and the periodic-type MFMA kernels (1 stream) run beside the main chain.  At full size both
-  // sides fill the chip and time-slice, which measured SLOWER, hence the size threshold.
-  // SVGPFA_OVERLAP = 0 never (default: measured no gain on MI355X / ROCm 7.2) | 1 always | 2 automatic
-  hipStream_t s_spk[2] = {nullptr, nullptr}, s_per = nullptr;
-  int overlap_mode = 0;        // 0 (default) one stream | 1 multi-stream per type | 2 = 1 below overlap_thresh | 3 spike pass on a
-                               // side stream | 4 = 3 on small shards only.  Measured on MI355X: every concurrent variant is
-                               // SLOWER than one stream (cfg3 8-way shard 0.41 vs 0.27 ms), so they stay opt-in (SVGPFA_OVERLAP)
+  // Launch strategy.  The per-item kernels (times / ELL roles / quad_bwd / bwd) are launched ONCE over all latents with
+  // the covariance type resolved per block (measured faster than one launch per type at every size: fewer launches,
+  // shorter grid tails; cfg3 +3 %).  The spike pass keeps one launch per type above merge_spike_blocks (the merged
+  // kernel carries the periodic type's VGPR count) and is merged, longest items first, below it.
+  long long merge_spike_blocks = 8192;          // SVGPFA_MERGE_SPIKE_BLOCKS
+  // SVGPFA_OVERLAP=1: spike pass on a side stream beside the quadrature chain.  Measured on MI355X / ROCm 7.2: SLOWER
+  // than one stream at every size (cfg3 1.81 vs 1.51 ms, 8-way shard 0.41 vs 0.27 ms), so it is opt-in only.
+  int side_stream = 0;
   hipStream_t s_side = nullptr;
-  int spl = SV_SPL;            // spikes per lane of the spike pass: 8, or 4 when the shard has few chunks (set_spikes)
-  long long small_spike_waves = 0;       // below this many (chunk, latent) waves at SPL = 8, use SPL = 4 (measured slower on
-                                         // cfg3 shards: per-wave epilogue dominates; kept as an option, SVGPFA_SMALL_SPIKE_WAVES)
-  long long overlap_thresh = 8192;
-  // Per-item kernels (times / ELL roles / quad_bwd / bwd) are launched ONCE over all latents with the covariance type
-  // resolved per block (measured faster at every size: fewer launches, shorter grid tails; cfg3 +3 %).  The spike
-  // pass keeps one launch per type above merge_spike_blocks (the merged kernel carries the periodic type's VGPR count).
-  long long merge_items = 1LL << 40, merge_spike_blocks = 8192;
-  hipEvent_t ev_prep = nullptr, ev_t1 = nullptr, ev_ell = nullptr, ev_spk[2] = {nullptr, nullptr}, ev_b1 = nullptr;
+  hipEvent_t ev_prep = nullptr, ev_spk = nullptr;
+  int spl = SV_SPL;                             // spikes per lane of the spike pass: 8, or 4 below small_spike_waves
+  long long small_spike_waves = 0;              // SVGPFA_SMALL_SPIKE_WAVES (half-size chunks measured slower: off)
 };
 
 #define HIPCHK(e, call)                                                                  \
@@ -92,8 +85,6 @@ static int dalloc(svgpfa_engine* e, T** p, size_t n) {
     if (_r) return _r;                       \
   } while (0)
 
-static size_t lds_build(int M, int pack) { return ((size_t)2 * M * (M + 1) + 64) * 8 * pack; }
-static size_t lds_prep(int M, int pack) { return ((size_t)M * (M + 1) + 128) * 8 * pack; }
 static size_t lds_times_mfma(int NT) {
   size_t MP = 16 * NT, LD = MP + 2;
   return (2 * MP * LD + 2 * MP) * 8;
@@ -133,47 +124,26 @@ static size_t lds_qell_mfma(const svgpfa_engine* e, int role) { return lds_qell_
     case 13: { constexpr int KS_ = 13; __VA_ARGS__; } break; case 14: { constexpr int KS_ = 14; __VA_ARGS__; } break; \
     case 15: { constexpr int KS_ = 15; __VA_ARGS__; } break; default: { constexpr int KS_ = 16; __VA_ARGS__; } break; \
   }
-static size_t lds_qell(const svgpfa_engine* e) {
-  return ((size_t)2 * e->v.qtile * e->KT + e->v.qtile + (size_t)e->v.N * e->KT + e->v.N + 4) * 8;
-}
-
-template <int PACK>
-__global__ __launch_bounds__(64) void k_prep_entry(EngineView ev, PtrTable pt) {
-  extern __shared__ double sm[];
-  k_prep_body<PACK>(ev, pt.p, sm);
-}
-template <int NT, int KT>
+template <int NT>
 __global__ __launch_bounds__(64 * NT) void k_bwd_mfma(EngineView ev, PtrTable pt, unsigned mask) {
   extern __shared__ double sm[];
-  int r, k;
-  block_item<KT>(ev, r, k);
-  if (KT == SV_RBF || (KT == SV_ANYTYPE && ev.meta[k].ktype == SV_RBF))
+  const int r = blockIdx.x / ev.K, k = blockIdx.x % ev.K;
+  if (ev.meta[k].ktype == SV_RBF)
     bwd_mfma_body<NT, SV_RBF>(ev, r, k, pt.p[k], mask, sm);
   else
     bwd_mfma_body<NT, SV_PERIODIC>(ev, r, k, pt.p[k], mask, sm);
 }
-// launch STMT once per covariance type that has latents; KT_ is the compile-time type
-// Launch over covariance types.  merged = true: ONE launch with KT_ = SV_ANYTYPE over all latents (NKT_ = K);
+// Spike pass over covariance types.  merged = true: ONE launch with KT_ = SV_ANYTYPE over all latents (NKT_ = K);
 // merged = false: one launch per type that has latents (NKT_ = that type's latent count).
-#define FOR_TYPES(e, merged, ST0, ST1, ...)                                                                  \
-  do {                                                                                                       \
-    if (merged) {                                                                                            \
-      constexpr int KT_ = SV_ANYTYPE; const int NKT_ = (e)->v.K; hipStream_t ST_ = (ST0); __VA_ARGS__;        \
-    } else {                                                                                                 \
-      if ((e)->v.ntype[0] > 0) { constexpr int KT_ = SV_RBF; const int NKT_ = (e)->v.ntype[0]; hipStream_t ST_ = (ST0); __VA_ARGS__; }      \
-      if ((e)->v.ntype[1] > 0) { constexpr int KT_ = SV_PERIODIC; const int NKT_ = (e)->v.ntype[1]; hipStream_t ST_ = (ST1); __VA_ARGS__; } \
-    }                                                                                                        \
-  } while (0)
-// same, with an explicit stream per covariance type (ST_ inside the statement)
-#define FOR_KT_ST(e, ST0, ST1, ...)                                                              \
-  do {                                                                                           \
-    if ((e)->v.ntype[0] > 0) { constexpr int KT_ = SV_RBF; hipStream_t ST_ = (ST0); __VA_ARGS__; }      \
-    if ((e)->v.ntype[1] > 0) { constexpr int KT_ = SV_PERIODIC; hipStream_t ST_ = (ST1); __VA_ARGS__; } \
-  } while (0)
-#define FOR_KT(e, ...)                                                        \
-  do {                                                                        \
-    if ((e)->v.ntype[0] > 0) { constexpr int KT_ = SV_RBF; __VA_ARGS__; }      \
-    if ((e)->v.ntype[1] > 0) { constexpr int KT_ = SV_PERIODIC; __VA_ARGS__; } \
+#define FOR_TYPES(e, merged, ST, ...)                                                                         \
+  do {                                                                                                        \
+    hipStream_t ST_ = (ST);                                                                                   \
+    if (merged) {                                                                                             \
+      constexpr int KT_ = SV_ANYTYPE; const int NKT_ = (e)->v.K; __VA_ARGS__;                                  \
+    } else {                                                                                                  \
+      if ((e)->v.ntype[0] > 0) { constexpr int KT_ = SV_RBF; const int NKT_ = (e)->v.ntype[0]; __VA_ARGS__; }       \
+      if ((e)->v.ntype[1] > 0) { constexpr int KT_ = SV_PERIODIC; const int NKT_ = (e)->v.ntype[1]; __VA_ARGS__; }  \
+    }                                                                                                         \
   } while (0)
 static size_t lds_prep_mfma(int NT) {
   size_t MP = 16 * NT, LD = MP + 2;
@@ -182,17 +152,6 @@ static size_t lds_prep_mfma(int NT) {
 static size_t lds_bwd_mfma(int NT) {
   size_t MP = 16 * NT, LD = MP + 2;
   return (3 * MP * LD + 4 * MP + NT * MP + 2 * NT) * 8;
-}
-
-// Snapshot Z_k / theta_k of all latents into engine-owned HBM in ONE launch (reference semantics:
-// later evaluations keep using the matrices of the last buildKernelsMatrices() call).
-__global__ void k_snapshot(EngineView ev, SnapTable st) {
-  const int k = blockIdx.y;
-  const LatentMeta m = ev.meta[k];
-  const long long n = (long long)ev.R * m.M;
-  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
-    ev.Zs[m.offM + i] = st.Z[k][i];
-  if (blockIdx.x == 0 && threadIdx.x < m.nth) ev.theta[2 * k + threadIdx.x] = st.theta[k][threadIdx.x];
 }
 
 template <typename F>
@@ -248,9 +207,6 @@ int svgpfa_create(const svgpfa_dims* d, int device, svgpfa_engine** out) {
   }
   e->totM = offM; e->totMM = offMM;
   v.sumM = colM; v.nth_total = thoff;
-  v.qtile = std::min(v.Q, 256);
-  v.nqt = (v.Q + v.qtile - 1) / v.qtile;
-  e->KT = 4 * ((v.K + 3) / 4);
   e->NT = (e->Mmax + 15) / 16;
 
   LatentMeta* dmeta; DALLOC(e, dmeta, v.K);
@@ -265,16 +221,17 @@ int svgpfa_create(const svgpfa_dims* d, int device, svgpfa_engine** out) {
   DALLOC(e, v.muq, rqk); DALLOC(e, v.varq, rqk); DALLOC(e, v.gmuq, rqk); DALLOC(e, v.gvarq, rqk);
   DALLOC(e, v.gaq, e->totM); DALLOC(e, v.GW, e->totMM); DALLOC(e, v.gZq, e->totM);
   DALLOC(e, v.gthq, (size_t)v.R * v.K * 2);
-  size_t nblk = (size_t)v.R * v.nqt;
   e->KKT = (2 * v.K + 3) / 4;   // KS: k-steps of the h product
   e->ell_lc[0] = qell_chunk(e, 0);
   e->ell_lc[1] = qell_chunk(e, 1);
   // blocks per trial of the ELL kernels: every block re-stages the trial's looped operand in LDS, so fewer blocks
   // per trial are cheaper as long as the grid still fills the chip (measured on cfg3: 1 -> 151 us, 4 -> 168 us)
-  e->ell_parts = (e->ell_lc[0] > 0 && e->ell_lc[1] > 0 && e->KKT <= 16) ? std::min(4, std::max(1, (383 + v.R) / v.R)) : 0;
-  if (e->ell_parts && getenv("SVGPFA_ELL_PARTS")) e->ell_parts = std::max(1, atoi(getenv("SVGPFA_ELL_PARTS")));
-  v.ncd = e->ell_parts ? v.R : (int)nblk;
-  v.nell = e->ell_parts ? v.R * e->ell_parts : (int)nblk;
+  if (e->ell_lc[0] <= 0 || e->ell_lc[1] <= 0)
+    FAIL(e, SVGPFA_ERR_UNSUPPORTED, "n_neurons / n_quad too large for the LDS-resident ELL kernels");
+  e->ell_parts = std::min(4, std::max(1, (383 + v.R) / v.R));
+  if (getenv("SVGPFA_ELL_PARTS")) e->ell_parts = std::max(1, atoi(getenv("SVGPFA_ELL_PARTS")));
+  v.ncd = v.R;
+  v.nell = v.R * e->ell_parts;
   DALLOC(e, v.gCpart, (size_t)v.ncd * v.N * 2 * v.K); DALLOC(e, v.gdpart, (size_t)v.ncd * v.N);
   DALLOC(e, v.ellq, (size_t)v.nell);
   DALLOC(e, v.ells, (size_t)v.R * v.K); DALLOC(e, v.gthitem, (size_t)v.R * v.K * 2);
@@ -286,70 +243,27 @@ int svgpfa_create(const svgpfa_dims* d, int device, svgpfa_engine** out) {
   HIPCHK(e, hipMemset(v.gZq, 0, sizeof(double) * e->totM));
   HIPCHK(e, hipMemset(v.gthq, 0, sizeof(double) * v.R * v.K * 2));
   HIPCHK(e, hipHostMalloc((void**)&e->status_host, sizeof(int)));
-  {
-    // the spike pass is bulk throughput work: lowest priority, so that the short dependent MFMA chain
-    // (whose kernels are single-round latency floors on small shards) gets wave slots first
-    int lo = 0, hi = 0;
-    HIPCHK(e, hipDeviceGetStreamPriorityRange(&lo, &hi));
-    HIPCHK(e, hipStreamCreateWithPriority(&e->s_spk[0], hipStreamNonBlocking, lo));
-    HIPCHK(e, hipStreamCreateWithPriority(&e->s_spk[1], hipStreamNonBlocking, lo));
-    HIPCHK(e, hipStreamCreateWithPriority(&e->s_per, hipStreamNonBlocking, hi));
-    HIPCHK(e, hipStreamCreateWithFlags(&e->s_side, hipStreamNonBlocking));
-  }
+  HIPCHK(e, hipStreamCreateWithFlags(&e->s_side, hipStreamNonBlocking));
   {
     const char* ov = getenv("SVGPFA_OVERLAP");
-    if (ov && ov[0] >= '0' && ov[0] <= '4') e->overlap_mode = ov[0] - '0';
-    const char* th = getenv("SVGPFA_OVERLAP_THRESH");
-    if (th) e->overlap_thresh = atoll(th);
-    const char* mi = getenv("SVGPFA_MERGE_ITEMS");
-    if (mi) e->merge_items = atoll(mi);
+    if (ov) e->side_stream = atoi(ov) != 0;
     const char* ms = getenv("SVGPFA_MERGE_SPIKE_BLOCKS");
     if (ms) e->merge_spike_blocks = atoll(ms);
     const char* sw = getenv("SVGPFA_SMALL_SPIKE_WAVES");
     if (sw) e->small_spike_waves = atoll(sw);
   }
-  for (hipEvent_t* ev : {&e->ev_prep, &e->ev_t1, &e->ev_ell, &e->ev_spk[0], &e->ev_spk[1], &e->ev_b1})
+  for (hipEvent_t* ev : {&e->ev_prep, &e->ev_spk})
     HIPCHK(e, hipEventCreateWithFlags(ev, hipEventDisableTiming));
 
-  int rc;
-  e->pack = 1;   // two items per wavefront (pack = 2) measured no faster: these kernels are latency-bound per item
-  if (e->pack == 2) {
-    if ((rc = allow_lds(e, k_build<2>, lds_build(e->Mmax, 2)))) return rc;
-    if ((rc = allow_lds(e, k_prep_entry<2>, lds_prep(e->Mmax, 2)))) return rc;
-  } else {
-    if ((rc = allow_lds(e, k_build<1>, lds_build(e->Mmax, 1)))) return rc;
-    if ((rc = allow_lds(e, k_prep_entry<1>, lds_prep(e->Mmax, 1)))) return rc;
-  }
-  rc = 0;
-  DISPATCH_NT(e->NT, FOR_KT(e, if (!rc) rc = allow_lds(e, (k_bwd_mfma<NT_, KT_>), lds_bwd_mfma(NT_))));
-  if (rc) return rc;
-  DISPATCH_NT(e->NT, rc = allow_lds(e, (k_prep_mfma<NT_>), lds_prep_mfma(NT_)));
-  if (rc) return rc;
-  DISPATCH_NT(e->NT, rc = allow_lds(e, (k_bwd_mfma<NT_, SV_ANYTYPE>), lds_bwd_mfma(NT_));
+  int rc = 0;
+  DISPATCH_NT(e->NT, rc = allow_lds(e, (k_prep_mfma<NT_>), lds_prep_mfma(NT_));
+              if (!rc) rc = allow_lds(e, (k_bwd_mfma<NT_>), lds_bwd_mfma(NT_));
               if (!rc) rc = allow_lds(e, (k_times_fwd_mfma<NT_, SV_ANYTYPE>), lds_times_mfma(NT_));
               if (!rc) rc = allow_lds(e, (k_quad_bwd_mfma<NT_, SV_ANYTYPE, true>), lds_qbwd_mfma(NT_));
               if (!rc) rc = allow_lds(e, (k_quad_bwd_mfma<NT_, SV_ANYTYPE, false>), lds_qbwd_mfma(NT_)));
   if (rc) return rc;
-  DISPATCH_NT(e->NT, FOR_KT(e, if (!rc) rc = allow_lds(e, (k_times_fwd_mfma<NT_, KT_>), lds_times_mfma(NT_))));
-  if (rc) return rc;
-  DISPATCH_NT(e->NT, FOR_KT(e, if (!rc) rc = allow_lds(e, (k_quad_bwd_mfma<NT_, KT_, true>), lds_qbwd_mfma(NT_))));
-  if (rc) return rc;
-  DISPATCH_NT(e->NT, FOR_KT(e, if (!rc) rc = allow_lds(e, (k_quad_bwd_mfma<NT_, KT_, false>), lds_qbwd_mfma(NT_))));
-  if (rc) return rc;
-  if (e->ell_parts) {
-    rc = 0;
-    DISPATCH_KS(e->KKT, rc = allow_lds(e, (k_quad_ell_mfma<KS_, 0>), lds_qell_mfma(e, 0));
-                if (!rc) rc = allow_lds(e, (k_quad_ell_mfma<KS_, 1>), lds_qell_mfma(e, 1));
-                if (!rc) rc = allow_lds(e, (k_quad_ell_mfma<KS_, 2>), std::max(lds_qell_mfma(e, 0), lds_qell_mfma(e, 1))));
-    if (rc) return rc;
-  }
-  size_t lq = lds_qell(e);
-  switch (e->KT) {
-#define CASE_KT(X) case X: rc = allow_lds(e, k_quad_ell<X>, lq); break;
-    CASE_KT(4) CASE_KT(8) CASE_KT(12) CASE_KT(16) CASE_KT(20) CASE_KT(24) CASE_KT(28) CASE_KT(32)
-#undef CASE_KT
-    default: FAIL(e, SVGPFA_ERR_UNSUPPORTED, "n_latents > 32");
-  }
+  DISPATCH_KS(e->KKT, rc = allow_lds(e, (k_quad_ell_mfma<KS_, 0>), lds_qell_mfma(e, 0));
+              if (!rc) rc = allow_lds(e, (k_quad_ell_mfma<KS_, 2>), std::max(lds_qell_mfma(e, 0), lds_qell_mfma(e, 1))));
   if (rc) return rc;
   return SVGPFA_OK;
 }
@@ -360,9 +274,9 @@ void svgpfa_destroy(svgpfa_engine* e) {
   (void)hipDeviceSynchronize();
   for (void* p : e->allocs) (void)hipFree(p);
   if (e->status_host) (void)hipHostFree(e->status_host);
-  for (hipStream_t st : {e->s_spk[0], e->s_spk[1], e->s_per, e->s_side})
+  for (hipStream_t st : {e->s_side})
     if (st) (void)hipStreamDestroy(st);
-  for (hipEvent_t ev : {e->ev_prep, e->ev_t1, e->ev_ell, e->ev_spk[0], e->ev_spk[1], e->ev_b1})
+  for (hipEvent_t ev : {e->ev_prep, e->ev_spk})
     if (ev) (void)hipEventDestroy(ev);
   for (auto& pr : e->ev_pool) {
     (void)hipEventDestroy(pr.first);
@@ -503,7 +417,7 @@ int svgpfa_set_spikes(svgpfa_engine* e, const int64_t* off, const double* times,
   return SVGPFA_OK;
 }
 
-// write_aux: also store Kzz and L (getter path).  M <= 32: register-resident kernel, several items per wave.
+// write_aux: also store Kzz and L (getter path).  Register-resident kernel, 4 / 2 / 1 items per wave.
 // snap != nullptr: read Z / theta from the caller's tensors and snapshot them in the same launch.
 static void launch_build(svgpfa_engine* e, int write_aux, const SnapTable* snap) {
   EngineView& v = e->v;
@@ -515,15 +429,9 @@ static void launch_build(svgpfa_engine* e, int write_aux, const SnapTable* snap)
   } else if (e->Mmax <= 32) {
     hipLaunchKernelGGL(k_build_reg<32>, dim3(v.K * ((v.R + 1) / 2)), dim3(64), 0, e->stream, v, write_aux, snap ? 1 : 0,
                        snap ? *snap : none);
-  } else if (e->Mmax <= 64) {   // one item per wave, 64 rows: 256 VGPRs of matrix data, still no LDS staging of Kzz
+  } else {   // M <= 64 (checked at creation): one item per wave, 64 rows, 256 VGPRs of matrix data
     hipLaunchKernelGGL(k_build_reg<64>, dim3(v.K * v.R), dim3(64), 0, e->stream, v, write_aux, snap ? 1 : 0,
                        snap ? *snap : none);
-  } else {
-    if (snap) {
-      int gx = std::max(1, std::min(64, (v.R * e->Mmax + 255) / 256));
-      hipLaunchKernelGGL(k_snapshot, dim3(gx, v.K), dim3(256), 0, e->stream, v, *snap);
-    }
-    hipLaunchKernelGGL(k_build<1>, dim3(v.K * v.R), dim3(64), lds_build(e->Mmax, 1), e->stream, v);
   }
 }
 
@@ -575,58 +483,33 @@ static int fill_ptrs(svgpfa_engine* e, PtrTable& pt, const double* const* mean, 
 
 static int launch_quad_ell(svgpfa_engine* e, const double* C, const double* d, int want_cd, int want_lat) {
   EngineView& v = e->v;
-  if (e->ell_parts) {
-    // role 0 (dC, dd and the ELL value) always runs: its column sums give sum E; role 1 only for latent adjoints
-    dim3 gm(v.R * e->ell_parts), bm(256);
-    if (want_lat && (long long)v.R * v.K <= e->merge_items) {   // small shard: both roles in one launch
-      const size_t l2 = std::max(lds_qell_mfma(e, 0), lds_qell_mfma(e, 1));
-      DISPATCH_KS(e->KKT, hipLaunchKernelGGL((k_quad_ell_mfma<KS_, 2>), dim3(2 * gm.x), bm, l2, e->stream, v, C, d, want_cd,
-                                             1, e->ell_parts, e->ell_lc[0], e->ell_lc[1]));
-    } else {
-      DISPATCH_KS(e->KKT,
-                  hipLaunchKernelGGL((k_quad_ell_mfma<KS_, 0>), gm, bm, lds_qell_mfma(e, 0), e->stream, v, C, d, want_cd, 1,
-                                     e->ell_parts, e->ell_lc[0], e->ell_lc[1]);
-                  if (want_lat) hipLaunchKernelGGL((k_quad_ell_mfma<KS_, 1>), gm, bm, lds_qell_mfma(e, 1), e->stream, v, C,
-                                                   d, 1, 0, e->ell_parts, e->ell_lc[0], e->ell_lc[1]));
-    }
-    HIPCHK(e, hipGetLastError());
-    return SVGPFA_OK;
-  }
-  size_t lq = lds_qell(e);
-  dim3 g(v.R * v.nqt), b(256);
-  switch (e->KT) {
-#define CASE_KT(X) case X: hipLaunchKernelGGL(k_quad_ell<X>, g, b, lq, e->stream, v, C, d, want_cd, want_lat); break;
-    CASE_KT(4) CASE_KT(8) CASE_KT(12) CASE_KT(16) CASE_KT(20) CASE_KT(24) CASE_KT(28) CASE_KT(32)
-#undef CASE_KT
+  // role 0 (dC, dd and the ELL value) always runs: its column sums give sum E; role 1 (latent adjoints) rides in the
+  // same launch when some latent-side gradient is wanted
+  dim3 gm(v.R * e->ell_parts), bm(256);
+  if (want_lat) {
+    const size_t l2 = std::max(lds_qell_mfma(e, 0), lds_qell_mfma(e, 1));
+    DISPATCH_KS(e->KKT, hipLaunchKernelGGL((k_quad_ell_mfma<KS_, 2>), dim3(2 * gm.x), bm, l2, e->stream, v, C, d, want_cd,
+                                           1, e->ell_parts, e->ell_lc[0], e->ell_lc[1]));
+  } else {
+    DISPATCH_KS(e->KKT, hipLaunchKernelGGL((k_quad_ell_mfma<KS_, 0>), gm, bm, lds_qell_mfma(e, 0), e->stream, v, C, d,
+                                           want_cd, 1, e->ell_parts, e->ell_lc[0], e->ell_lc[1]));
   }
   HIPCHK(e, hipGetLastError());
   return SVGPFA_OK;
 }
 
 static int launch_times(svgpfa_engine* e, const double* times, const long long* toff, int nper, double* mu,
-                        double* var, long long os_t, long long os_k, int want_var, hipStream_t st0 = nullptr,
-                        hipStream_t st1 = nullptr) {
+                        double* var, long long os_t, long long os_k, int want_var) {
   EngineView& v = e->v;
-  if (!st0) st0 = e->stream;
-  if (!st1) st1 = e->stream;
-  const bool merged = (long long)v.R * v.K <= e->merge_items;
-  DISPATCH_NT(e->NT, FOR_TYPES(e, merged, st0, st1, hipLaunchKernelGGL((k_times_fwd_mfma<NT_, KT_>), dim3(v.R * NKT_),
-                                                                     dim3(256), lds_times_mfma(NT_), ST_, v, times, toff,
-                                                                     nper, mu, var, os_t, os_k, want_var)));
+  DISPATCH_NT(e->NT, hipLaunchKernelGGL((k_times_fwd_mfma<NT_, SV_ANYTYPE>), dim3(v.R * v.K), dim3(256),
+                                        lds_times_mfma(NT_), e->stream, v, times, toff, nper, mu, var, os_t, os_k, want_var));
   HIPCHK(e, hipGetLastError());
   return SVGPFA_OK;
 }
 
-static void launch_prep(svgpfa_engine* e, const PtrTable& pt) {
+static void launch_prep(svgpfa_engine* e, const PtrTable& pt) {   // one wavefront per 16-column panel
   EngineView& v = e->v;
-  if (e->NT <= 4) {   // one wavefront per 16-column panel
-    DISPATCH_NT(e->NT, hipLaunchKernelGGL(k_prep_mfma<NT_>, dim3(v.R * v.K), dim3(64 * NT_), lds_prep_mfma(NT_), e->stream, v, pt));
-    return;
-  }
-  if (e->pack == 2)
-    hipLaunchKernelGGL(k_prep_entry<2>, dim3(v.K * ((v.R + 1) / 2)), dim3(64), lds_prep(e->Mmax, 2), e->stream, v, pt);
-  else
-    hipLaunchKernelGGL(k_prep_entry<1>, dim3(v.K * v.R), dim3(64), lds_prep(e->Mmax, 1), e->stream, v, pt);
+  DISPATCH_NT(e->NT, hipLaunchKernelGGL(k_prep_mfma<NT_>, dim3(v.R * v.K), dim3(64 * NT_), lds_prep_mfma(NT_), e->stream, v, pt));
 }
 
 static int check_ready(svgpfa_engine* e) {
@@ -645,35 +528,20 @@ int svgpfa_elbo(svgpfa_engine* e, const double* const* mean, const double* const
   EngineView& v = e->v;
   PtrTable pt;
   if ((rc = fill_ptrs(e, pt, mean, cholvec, g_mean, g_cholvec, g_Z, mask))) return rc;
-  const int RK = v.R * v.K;
   const bool want_lat = (mask & (1u | 4u | 8u)) != 0;
   const bool full = (mask & (2u | 4u | 8u)) != 0;
 
   launch_prep(e, pt);
-  const long long spk_blocks = (long long)v.nchunks * std::max(v.ntype[0], v.ntype[1]);
-  const bool ov = e->overlap_mode == 1 || (e->overlap_mode == 2 && spk_blocks <= e->overlap_thresh);
-  const bool mitems = !ov && (long long)v.R * v.K <= e->merge_items;   // merged-type launches on small shards
   hipStream_t sm = e->stream;
-  hipStream_t sp = ov ? e->s_per : sm;                      // periodic-type MFMA kernels
-  // small shards: every launch is latency-bound and under-fills the chip, so the spike pass runs beside the
-  // quadrature chain on one side stream (two cross-stream edges: prep -> spike, spike -> bwd)
-  const bool side = !ov && v.nchunks > 0 &&
-                    (e->overlap_mode == 3 || (e->overlap_mode == 4 && (long long)v.R * v.K <= 2048));
-  hipStream_t sk[2] = {ov ? e->s_spk[0] : (side ? e->s_side : sm), ov ? e->s_spk[1] : (side ? e->s_side : sm)};
+  const bool side = e->side_stream && v.nchunks > 0;     // opt-in: spike pass beside the quadrature chain
+  hipStream_t sk = side ? e->s_side : sm;
   if (side) {
     HIPCHK(e, hipEventRecord(e->ev_prep, sm));
-    HIPCHK(e, hipStreamWaitEvent(e->s_side, e->ev_prep, 0));
-  }
-  if (ov) {
-    HIPCHK(e, hipEventRecord(e->ev_prep, sm));
-    HIPCHK(e, hipStreamWaitEvent(sp, e->ev_prep, 0));
-    HIPCHK(e, hipStreamWaitEvent(sk[0], e->ev_prep, 0));
-    HIPCHK(e, hipStreamWaitEvent(sk[1], e->ev_prep, 0));
+    HIPCHK(e, hipStreamWaitEvent(sk, e->ev_prep, 0));
   }
   // ---- spike pass (fp64 VALU bound): needs only a = Kzz^-1 m from k_prep
   if (v.nchunks > 0) {
     std::pair<hipEvent_t, hipEvent_t>* evp = nullptr;
-    const int tfirst = v.ntype[0] > 0 ? 0 : 1, tlast = v.ntype[1] > 0 ? 1 : 0;
     if (e->timing) {
       if (e->ev_used == e->ev_pool.size()) {
         std::pair<hipEvent_t, hipEvent_t> pr;
@@ -682,59 +550,38 @@ int svgpfa_elbo(svgpfa_engine* e, const double* const* mean, const double* const
         e->ev_pool.push_back(pr);
       }
       evp = &e->ev_pool[e->ev_used++];
-      HIPCHK(e, hipEventRecord(evp->first, sk[tfirst]));
+      HIPCHK(e, hipEventRecord(evp->first, sk));
     }
-    const bool mspk = !ov && (long long)v.nchunks * v.K * e->spl / 8 <= e->merge_spike_blocks;
+    const bool mspk = (long long)v.nchunks * v.K * e->spl / 8 <= e->merge_spike_blocks;
     if (e->spl == 4) {
       if (full) {
-        FOR_TYPES(e, mspk, sk[0], sk[1], hipLaunchKernelGGL((k_spike<KT_, true, 4>), dim3(v.nchunks * NKT_), dim3(64), 0, ST_, v, C));
+        FOR_TYPES(e, mspk, sk, hipLaunchKernelGGL((k_spike<KT_, true, 4>), dim3(v.nchunks * NKT_), dim3(64), 0, ST_, v, C));
       } else {
-        FOR_TYPES(e, mspk, sk[0], sk[1], hipLaunchKernelGGL((k_spike<KT_, false, 4>), dim3(v.nchunks * NKT_), dim3(64), 0, ST_, v, C));
+        FOR_TYPES(e, mspk, sk, hipLaunchKernelGGL((k_spike<KT_, false, 4>), dim3(v.nchunks * NKT_), dim3(64), 0, ST_, v, C));
       }
     } else if (full) {
-      FOR_TYPES(e, mspk, sk[0], sk[1], hipLaunchKernelGGL((k_spike<KT_, true, 8>), dim3(v.nchunks * NKT_), dim3(64), 0, ST_, v, C));
+      FOR_TYPES(e, mspk, sk, hipLaunchKernelGGL((k_spike<KT_, true, 8>), dim3(v.nchunks * NKT_), dim3(64), 0, ST_, v, C));
     } else {
-      FOR_TYPES(e, mspk, sk[0], sk[1], hipLaunchKernelGGL((k_spike<KT_, false, 8>), dim3(v.nchunks * NKT_), dim3(64), 0, ST_, v, C));
+      FOR_TYPES(e, mspk, sk, hipLaunchKernelGGL((k_spike<KT_, false, 8>), dim3(v.nchunks * NKT_), dim3(64), 0, ST_, v, C));
     }
-    if (evp) HIPCHK(e, hipEventRecord(evp->second, sk[tlast]));
-    if (ov) {
-      HIPCHK(e, hipEventRecord(e->ev_spk[0], sk[0]));
-      HIPCHK(e, hipEventRecord(e->ev_spk[1], sk[1]));
-    }
-    if (side) HIPCHK(e, hipEventRecord(e->ev_spk[0], e->s_side));
+    if (evp) HIPCHK(e, hipEventRecord(evp->second, sk));
+    if (side) HIPCHK(e, hipEventRecord(e->ev_spk, sk));
   }
   // ---- quadrature chain (f64 MFMA): posterior stats -> ELL term -> adjoints
-  if ((rc = launch_times(e, v.tq, nullptr, v.Q, v.muq, v.varq, (long long)v.K, 1LL, 1, sm, sp))) return rc;
-  if (ov) {
-    HIPCHK(e, hipEventRecord(e->ev_t1, sp));
-    HIPCHK(e, hipStreamWaitEvent(sm, e->ev_t1, 0));
-  }
+  if ((rc = launch_times(e, v.tq, nullptr, v.Q, v.muq, v.varq, (long long)v.K, 1LL, 1))) return rc;
   if ((rc = launch_quad_ell(e, C, d, (mask & 2u) ? 1 : 0, want_lat ? 1 : 0))) return rc;
-  if (ov) {
-    HIPCHK(e, hipEventRecord(e->ev_ell, sm));
-    HIPCHK(e, hipStreamWaitEvent(sp, e->ev_ell, 0));
-  }
   if (want_lat) {
     if (mask & (4u | 8u)) {
-      DISPATCH_NT(e->NT, FOR_TYPES(e, mitems, sm, sp, hipLaunchKernelGGL((k_quad_bwd_mfma<NT_, KT_, true>), dim3(v.R * NKT_),
-                                                                         dim3(256), lds_qbwd_mfma(NT_), ST_, v)));
+      DISPATCH_NT(e->NT, hipLaunchKernelGGL((k_quad_bwd_mfma<NT_, SV_ANYTYPE, true>), dim3(v.R * v.K), dim3(256),
+                                            lds_qbwd_mfma(NT_), sm, v));
     } else {
-      DISPATCH_NT(e->NT, FOR_TYPES(e, mitems, sm, sp, hipLaunchKernelGGL((k_quad_bwd_mfma<NT_, KT_, false>), dim3(v.R * NKT_),
-                                                                         dim3(256), lds_qbwd_mfma(NT_), ST_, v)));
+      DISPATCH_NT(e->NT, hipLaunchKernelGGL((k_quad_bwd_mfma<NT_, SV_ANYTYPE, false>), dim3(v.R * v.K), dim3(256),
+                                            lds_qbwd_mfma(NT_), sm, v));
     }
   }
-  // ---- join the spike pass per type, per-item backward, then the fixed-order reductions
-  if (ov && v.nchunks > 0) {
-    HIPCHK(e, hipStreamWaitEvent(sm, e->ev_spk[0], 0));
-    HIPCHK(e, hipStreamWaitEvent(sp, e->ev_spk[1], 0));
-  }
-  if (side) HIPCHK(e, hipStreamWaitEvent(sm, e->ev_spk[0], 0));
-  DISPATCH_NT(e->NT, FOR_TYPES(e, mitems, sm, sp, hipLaunchKernelGGL((k_bwd_mfma<NT_, KT_>), dim3(v.R * NKT_), dim3(64 * NT_),
-                                                                     lds_bwd_mfma(NT_), ST_, v, pt, mask)));
-  if (ov) {
-    HIPCHK(e, hipEventRecord(e->ev_b1, sp));
-    HIPCHK(e, hipStreamWaitEvent(sm, e->ev_b1, 0));
-  }
+  // ---- join the spike pass, per-item backward, then the fixed-order reductions
+  if (side) HIPCHK(e, hipStreamWaitEvent(sm, e->ev_spk, 0));
+  DISPATCH_NT(e->NT, hipLaunchKernelGGL((k_bwd_mfma<NT_>), dim3(v.R * v.K), dim3(64 * NT_), lds_bwd_mfma(NT_), sm, v, pt, mask));
   int nfin = (v.N * v.K + SV_FIN_OUT - 1) / SV_FIN_OUT + (v.N + SV_FIN_OUT - 1) / SV_FIN_OUT +
              (v.nth_total + SV_FIN_OUT - 1) / SV_FIN_OUT + 1;
   hipLaunchKernelGGL(k_finalize, dim3(nfin), dim3(256), 0, e->stream, v, C, d, mask, shared);
@@ -750,7 +597,6 @@ int svgpfa_latent_stats(svgpfa_engine* e, const double* const* mean, const doubl
   EngineView& v = e->v;
   PtrTable pt;
   if ((rc = fill_ptrs(e, pt, mean, cholvec, nullptr, nullptr, nullptr, 0))) return rc;
-  const int RK = v.R * v.K;
   launch_prep(e, pt);
   if ((rc = launch_times(e, v.tq, nullptr, v.Q, v.muq, v.varq, (long long)v.K, 1LL, 1))) return rc;
   if ((rc = launch_times(e, v.spk_t, v.spk_off, 0, v.muspk, v.varspk, 1LL, (long long)v.S, 1))) return rc;
@@ -789,7 +635,6 @@ int svgpfa_predict(svgpfa_engine* e, const double* const* mean, const double* co
   PtrTable pt;
   int rc;
   if ((rc = fill_ptrs(e, pt, mean, cholvec, nullptr, nullptr, nullptr, 0))) return rc;
-  const int RK = v.R * v.K;
   launch_prep(e, pt);
   if ((rc = launch_times(e, times, nullptr, (int)T, mu, var ? var : mu, (long long)v.K, 1LL, var ? 1 : 0))) return rc;
   HIPCHK(e, hipGetLastError());

@@ -161,14 +161,13 @@ def test_not_positive_definite_raises():
 
 
 def test_launch_strategies_agree(monkeypatch):
-    """Per-covariance-type launches (full-size strategy), merged-type launches (small-shard strategy), the
-    multi-stream variants and the default (auto) must give the same numbers (fixed-order reductions: bit-identical)."""
+    """One spike launch per covariance type (full-size strategy), the merged spike launch (small-shard strategy) and
+    the opt-in side-stream variant must give the same numbers (fixed-order reductions: bit-identical)."""
     prob = synthetic.make_problem(R=5, N=12, K=4, M=[10, 12, 9, 16], kernels="mix", seed=13, n_quad=60, rate=25.0, jitter=1.0)
     outs = []
-    for env in ({"SVGPFA_MERGE_ITEMS": "0", "SVGPFA_MERGE_SPIKE_BLOCKS": "0", "SVGPFA_OVERLAP": "0"},
-                {"SVGPFA_MERGE_ITEMS": "1000000", "SVGPFA_MERGE_SPIKE_BLOCKS": "1000000", "SVGPFA_OVERLAP": "0"},
-                {"SVGPFA_OVERLAP": "1"}, {"SVGPFA_OVERLAP": "3"}, {}):
-        for k in ("SVGPFA_MERGE_ITEMS", "SVGPFA_MERGE_SPIKE_BLOCKS", "SVGPFA_OVERLAP"):
+    for env in ({"SVGPFA_MERGE_SPIKE_BLOCKS": "0"}, {"SVGPFA_MERGE_SPIKE_BLOCKS": "1000000"},
+                {"SVGPFA_OVERLAP": "1"}, {"SVGPFA_OVERLAP": "1", "SVGPFA_MERGE_SPIKE_BLOCKS": "0"}, {}):
+        for k in ("SVGPFA_MERGE_SPIKE_BLOCKS", "SVGPFA_OVERLAP"):
             monkeypatch.delenv(k, raising=False)
         for k, v in env.items():
             monkeypatch.setenv(k, v)
