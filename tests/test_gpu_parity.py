@@ -241,6 +241,26 @@ def test_repeatable_bitwise():
         assert torch.equal(a, b)
 
 
+def test_cfg3_shapes_against_oracle():
+    """North-star shapes (200 neurons, 10 latents RBF+periodic, 32 inducing points, Q = 200, ~4000 spikes per trial) on a
+    few trials the oracle can evaluate: value and every gradient group."""
+    from oracle import svgpfa_oracle as orc
+    prob = synthetic.make_config("cfg3", n_trials=4)
+    eng, P = _engine(prob)
+    out = _eval(eng, P, 15)
+    ref = orc.elbo_and_grads(orc.from_numpy_problem(prob), 15)
+    assert _close(out["elbo"], float(ref["elbo"]), TOL_S)
+    assert _close(out["ell"], float(ref["ell"]), TOL_S)
+    assert _close(out["kl"], float(ref["kl"]), TOL_S)
+    assert rel_err(out["g_C"], ref["g_C"].numpy()) < TOL_A
+    assert rel_err(out["g_d"], ref["g_d"].numpy()) < TOL_A
+    for k in range(prob["K"]):
+        assert rel_err(out["g_mean"][k], ref["g_mean"][k].numpy()[:, :, 0]) < TOL_A
+        assert rel_err(out["g_cholVecs"][k], ref["g_cholVecs"][k].numpy()[:, :, 0]) < TOL_A
+        assert rel_err(out["g_Z"][k], ref["g_Z"][k].numpy()[:, :, 0]) < TOL_A
+        assert rel_err(out["g_theta"][k], ref["g_theta"][k].numpy()) < TOL_A
+
+
 def test_cfg3_properties():
     """North-star size (500x200x10x32, RBF+periodic): size-independent properties.
     (1) trial additivity: the ELBO of the full problem equals the sum over two trial shards;
