@@ -92,6 +92,12 @@ __device__ void times_fwd_body(const EngineView& ev, const int r, const int k, c
   load_factors<NT>(ev, m, r, Li, Vl, ul, zl, want_var != 0);
   __syncthreads();
 
+  // periodic: sin / cos of the inducing points' phases in LDS, so that a (node, inducing point) pair costs two FMAs by
+  // angle addition instead of a sincos; read at the use site (jo is an opaque lg: keeps them out of long-lived VGPRs)
+  double* szl = zl + MP;
+  double* czl = szl + MP;
+  if (KT == SV_PERIODIC && tid < MP) sv_sincos_quarter(zl[tid] * p.q4, szl[tid], czl[tid]);
+  if (KT == SV_PERIODIC) __syncthreads();
   double uj[NT][4], zj[NT][4];
 #pragma unroll
   for (int a = 0; a < NT; ++a)
@@ -113,10 +119,22 @@ __device__ void times_fwd_body(const EngineView& ev, const int r, const int k, c
       if (tile + 4 < ntiles) tq_next = times[t0 + ((nn < nt) ? nn : 0)];
     }
     d4 X0[NT];
+    double stq = 0.0, ctq = 0.0;
+    if (KT == SV_PERIODIC) sv_sincos_quarter(tq * p.q4, stq, ctq);
+    int jo = lg;
+    asm volatile("" : "+v"(jo));
 #pragma unroll
     for (int a = 0; a < NT; ++a)
 #pragma unroll
-      for (int q = 0; q < 4; ++q) X0[a][q] = p.s2 * kern_val<KT>(tq - zj[a][q], p);
+      for (int q = 0; q < 4; ++q) {
+        if (KT == SV_RBF) {
+          X0[a][q] = p.s2 * kern_val<SV_RBF>(tq - zj[a][q], p);
+        } else {
+          const int j = 16 * a + 4 * q + jo;
+          const double cs = fma(stq, szl[j], ctq * czl[j]);            // cos(2 pi (t - z) / p)
+          X0[a][q] = p.s2 * sv_exp2_neg(fmin(fma(cs, p.h2, -p.h2), 0.0));
+        }
+      }
     d4 Kw[NT];
     tri_chain<NT, 0>(Kw, Li, LD, X0, li, lg);
     double pm = 0.0, n2 = 0.0, tt = 0.0;

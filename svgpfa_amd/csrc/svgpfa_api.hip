@@ -87,7 +87,7 @@ static int dalloc(svgpfa_engine* e, T** p, size_t n) {
 
 static size_t lds_times_mfma(int NT) {
   size_t MP = 16 * NT, LD = MP + 2;
-  return (2 * MP * LD + 2 * MP) * 8;
+  return (2 * MP * LD + 4 * MP) * 8;
 }
 static size_t lds_qbwd_mfma(int NT) {
   size_t MP = 16 * NT, LD = MP + 2;
