@@ -222,6 +222,35 @@ __device__ void quad_bwd_mfma_body(const EngineView& ev, const int r, const int 
   load_factors<NT>(ev, m, r, Li, Vl, ul, zl, FULL);
   __syncthreads();
   if (KT == SV_PERIODIC && tid < MP) sv_sincos_quarter(zl[tid] * p.q4, szl[tid], czl[tid]);
+  if (FULL) {
+    // The adjoint of kappa(t, Z) at a node is gk = Linv^T [gm ut + 2 gv (Vt Vt^T - I) kt] = gm a + 2 gv D kt with the
+    // per-item matrix D = Linv^T (Vt Vt^T - I): one dense M x M x 16 product per tile instead of three triangular ones
+    // (T = Vt^T kt, Vt T, Linv^T .).  D is built once per item, one 16-column panel per wavefront, and replaces Vt in LDS.
+    d4 Dp[NT];
+    const int c = wave;
+    if (c < NT) {
+      d4 P[NT], VV[NT];
+#pragma unroll
+      for (int b = 0; b < NT; ++b)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) P[b][q] = Vl[(16 * c + li) * LD + 16 * b + 4 * q + lg];   // Vt^T panel
+      tri_chain<NT, 0>(VV, Vl, LD, P, li, lg);
+#pragma unroll
+      for (int a = 0; a < NT; ++a)
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+          if (16 * a + 4 * q + lg == 16 * c + li) VV[a][q] -= 1.0;
+      tri_chain<NT, 1>(Dp, Li, LD, VV, li, lg);
+    }
+    if (tid < MP) ul[tid] = (tid < M) ? ev.a[vbase + tid] : 0.0;     // a = Linv^T ut takes the place of ut
+    __syncthreads();                                                   // every wave is done reading Vt
+    if (c < NT) {
+#pragma unroll
+      for (int a = 0; a < NT; ++a)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) Vl[(16 * a + 4 * q + lg) * LD + 16 * c + li] = Dp[a][q];
+    }
+  }
   __syncthreads();
   d4 gu[NT], dz[NT], GW[NTRI];
 #pragma unroll
@@ -283,14 +312,21 @@ __device__ void quad_bwd_mfma_body(const EngineView& ev, const int r, const int 
 #pragma unroll
       for (int q = 0; q < 4; ++q) gu[a][q] = fma(gm, Kw[a][q], gu[a][q]);
     if (FULL) {
-      d4 T[NT], Y[NT], Gk[NT];
-      tri_chain<NT, 1>(T, Vl, LD, Kw, li, lg);
-      tri_chain<NT, 0>(Y, Vl, LD, T, li, lg);
+      d4 Gk[NT];
+#pragma unroll
+      for (int a = 0; a < NT; ++a) {
+        d4 acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int b = 0; b < NT; ++b)
+#pragma unroll
+          for (int q = 0; q < 4; ++q)
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(Vl[(16 * a + li) * LD + 16 * b + 4 * q + lg], Kw[b][q], acc, 0, 0, 0);
+        Gk[a] = acc;                                            // D kt
+      }
 #pragma unroll
       for (int a = 0; a < NT; ++a)
 #pragma unroll
-        for (int q = 0; q < 4; ++q) Y[a][q] = gm * ul[16 * a + 4 * q + jo] + 2.0 * gvv * (Y[a][q] - Kw[a][q]);
-      tri_chain<NT, 1>(Gk, Li, LD, Y, li, lg);
+        for (int q = 0; q < 4; ++q) Gk[a][q] = fma(2.0 * gvv, Gk[a][q], gm * ul[16 * a + 4 * q + jo]);
       asm volatile("" : "+v"(jo));
 #pragma unroll
       for (int a = 0; a < NT; ++a)
@@ -397,7 +433,7 @@ __device__ void quad_bwd_mfma_body(const EngineView& ev, const int r, const int 
 }
 
 template <int NT, int KT, bool FULL>
-__global__ __launch_bounds__(256) void k_quad_bwd_mfma(EngineView ev) {
+__global__ __launch_bounds__(256, (NT <= 2 ? 2 : 1)) void k_quad_bwd_mfma(EngineView ev) {   // M <= 32: keep 2 waves / SIMD
   extern __shared__ double sm[];
   int r, k;
   block_item<KT>(ev, r, k);
