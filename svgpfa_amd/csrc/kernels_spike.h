@@ -36,10 +36,147 @@ __device__ __forceinline__ void seg_emit(int key, double v, int& ck, double& cv,
   cv = __shfl(v, 63, 64);
 }
 
+// Periodic kernel, value + all gradients.  With theta_s = 2 pi t_s / p and phi_j = 2 pi z_j / p every sum over spikes the
+// pass needs is linear in sin / cos of theta_s, so the per-pair work is one exponential and seven FMAs:
+//   y_sj = hh (cos(theta_s - phi_j) - 1) = ct_s (hh cos phi_j) + st_s (hh sin phi_j) - hh        ck = c_s 2^y
+//   P0 = sum ck,  QA = sum ck st,  QB = sum ck ct,  QC = sum ck st t,  QD = sum ck ct t   and then per inducing point
+//   sum ck sin(theta - phi)   = cos phi QA - sin phi QB            (-> direct dZ)
+//   sum ck cos(theta - phi)   = cos phi QB + sin phi QA            (-> dtheta_lengthscale through sum ck y)
+//   sum ck sin(theta - phi) t = cos phi QC - sin phi QD            (-> dtheta_period, minus z_j times the first)
+// (no sin(theta - phi) per pair, no separate sum of ck y).  Five reduction vectors, reduced four inducing points at a time.
+template <int SPL>
+__device__ void spike_body_periodic_full(const EngineView& ev, const double* __restrict__ C, int ch, int k, double* red) {
+  constexpr int NV = 5, JG = 4;   // 20 rows: 13 KB of LDS per wave, so that three waves per SIMD fit
+  const int lane = threadIdx.x;
+  const SpikeChunk c = ev.chunks[ch];
+  const LatentMeta m = ev.meta[k];
+  const int M = m.M, K = ev.K, r = c.trial;
+  const KPar p = make_kpar(m, ev.theta + 2 * k);
+  const double* __restrict__ z = ev.Zs + m.offM + (long long)r * M;
+  const double* __restrict__ a = ev.a + m.offM + (long long)r * M;
+  const double L2E = 1.4426950408889634074;
+  const double sc = 4.0 * p.ip, hh = 0.5 * p.h * L2E;      // phase in quarter turns: (pi/2) (t 4/p)
+  const double w2 = -1.0 / (2.0 * hh), w3 = 1.0 / sc;
+
+  double cw[SPL], mu[SPL], st[SPL], ct[SPL], stt[SPL], ctt[SPL];
+  int nid[SPL];
+#pragma unroll
+  for (int i = 0; i < SPL; ++i) {
+    int idx = i * 64 + lane;
+    bool ok = idx < c.count;
+    long long gs = c.start + (ok ? idx : 0);
+    const double tsc = ev.spk_t[gs] * sc;
+    nid[i] = ok ? ev.spk_n[gs] : -1;
+    cw[i] = ok ? C[(long long)nid[i] * K + k] : 0.0;
+    mu[i] = 0.0;
+    sv_sincos_quarter(tsc, st[i], ct[i]);
+    stt[i] = st[i] * tsc;
+    ctt[i] = ct[i] * tsc;
+  }
+  double* zsc = red + NV * JG * 65;   // per inducing point: scaled z | sin phi | cos phi | hh sin phi | hh cos phi
+  double* rs = zsc + 5 * 64;          // NV * JG reduced sums of the current group
+  if (lane < M) {
+    const double zq = z[lane] * sc;
+    double sz, cz;
+    sv_sincos_quarter(zq, sz, cz);
+    zsc[lane] = zq;
+    zsc[64 + lane] = sz;
+    zsc[128 + lane] = cz;
+    zsc[192 + lane] = hh * sz;
+    zsc[256 + lane] = hh * cz;
+  }
+  __syncthreads();
+  double t0acc = 0.0, t1acc = 0.0;
+
+  for (int jb = 0; jb < M; jb += JG) {
+#pragma unroll
+    for (int jj = 0; jj < JG; ++jj) {
+      const int j = jb + jj;
+      double p0 = 0.0, qa = 0.0, qb = 0.0, qc = 0.0, qd = 0.0;
+      if (j < M) {
+        const double aj = a[j], hs = zsc[192 + j], hc = zsc[256 + j];
+#pragma unroll
+        for (int i = 0; i < SPL; ++i) {
+          const double y = fma(ct[i], hc, fma(st[i], hs, -hh));
+          const double kt = sv_exp2_neg(y);          // y <= ~1e-16: the kernel only needs |y - rint(y)| <= 1/2
+          const double ck = cw[i] * kt;
+          p0 += ck;
+          qa = fma(ck, st[i], qa);
+          qb = fma(ck, ct[i], qb);
+          qc = fma(ck, stt[i], qc);
+          qd = fma(ck, ctt[i], qd);
+          mu[i] = fma(kt, aj, mu[i]);
+        }
+      }
+      red[(0 * JG + jj) * 65 + lane] = p0;
+      red[(1 * JG + jj) * 65 + lane] = qa;
+      red[(2 * JG + jj) * 65 + lane] = qb;
+      red[(3 * JG + jj) * 65 + lane] = qc;
+      red[(4 * JG + jj) * 65 + lane] = qd;
+    }
+    __syncthreads();
+    // transposed reduction: lane (v, quarter) sums 16 of the 64 lane-partials of row v, then the quarters are added
+#pragma unroll
+    for (int v0 = 0; v0 < NV * JG; v0 += 16) {
+      const int v = v0 + (lane & 15), qd4 = lane >> 4;
+      double s = 0.0;
+      if (v < NV * JG) {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) s += red[v * 65 + qd4 * 16 + e];
+      }
+      s += __shfl_xor(s, 16, 64);
+      s += __shfl_xor(s, 32, 64);
+      if (lane < 16 && v < NV * JG) rs[v] = s;
+    }
+    __syncthreads();
+    if (lane < JG && jb + lane < M) {
+      const int j = jb + lane;
+      const double P0 = rs[lane], QA = rs[JG + lane], QB = rs[2 * JG + lane], QC = rs[3 * JG + lane],
+                   QD = rs[4 * JG + lane];
+      const double sz = zsc[64 + j], cz = zsc[128 + j];
+      const double p1 = fma(cz, QA, -(sz * QB));              // sum ck sin(theta - phi_j)
+      const double pcs = fma(cz, QB, sz * QA);                // sum ck cos(theta - phi_j)
+      const double p3 = fma(cz, QC, -(sz * QD));              // sum ck sin(theta - phi_j) t (scaled)
+      const long long o = (long long)ch * ev.sumM + m.colM + j;
+      ev.P0[o] = P0;
+      ev.P1[o] = p1;
+      t0acc = fma(a[j], hh * (pcs - P0), t0acc);              // sum ck y
+      t1acc = fma(a[j], p3 - zsc[j] * p1, t1acc);             // sum ck sin(.) (t - z_j)   (scaled units)
+    }
+    __syncthreads();
+  }
+
+  const double t0 = wave_sum(t0acc) * w2;
+  const double t1 = wave_sum(t1acc) * w3;
+  if (lane == 0) {
+    ev.Tpart[((long long)ch * K + k) * 2 + 0] = t0;
+    ev.Tpart[((long long)ch * K + k) * 2 + 1] = t1;
+  }
+  // spike part of dC[n, k]: per-neuron sums of mu_s
+  if (c.split) {
+    double tot = 0.0;
+#pragma unroll
+    for (int i = 0; i < SPL; ++i) tot += (nid[i] >= 0) ? mu[i] : 0.0;
+    tot = wave_sum(tot);
+    if (lane == 0) ev.splitPart[(long long)ch * K + k] = p.s2 * tot;
+  } else {
+    double* out = ev.gCspk + (long long)r * ev.N * K + k;
+    int ck = -1;
+    double cv = 0.0;
+#pragma unroll
+    for (int i = 0; i < SPL; ++i) seg_emit(nid[i], p.s2 * mu[i], ck, cv, out, K, lane);
+    if (ck >= 0 && lane == 0) out[(long long)ck * K] = cv;
+  }
+}
+
 template <int KT, bool FULL, int SPL>
 __device__ void spike_body(const EngineView& ev, const double* __restrict__ C, int ch, int k,
                            double* red) {
-  // NV partial-sum vectors per inducing point: P0 | P0 P1 P2 (RBF) | P0 P1 P2 P3 (periodic)
+  if constexpr (KT == SV_PERIODIC && FULL) {
+    spike_body_periodic_full<SPL>(ev, C, ch, k, red);
+    return;
+  }
+  // NV partial-sum vectors per inducing point: P0 | P0 P1 P2 (RBF) | P0 P1 P2 P3 (periodic, value-only path unused)
   constexpr int NV = FULL ? (KT == SV_RBF ? 3 : 4) : 1;
   const int lane = threadIdx.x;
   const SpikeChunk c = ev.chunks[ch];
@@ -202,9 +339,12 @@ __device__ void spike_body(const EngineView& ev, const double* __restrict__ C, i
 
 // KT = SV_RBF / SV_PERIODIC: one launch per covariance type; KT = 2 (any): type resolved per block (small shards).
 template <int KT, bool FULL, int SPL>
-__global__ __launch_bounds__(64) void k_spike(EngineView ev, const double* __restrict__ C) {
-  constexpr int NVM = FULL ? (KT == SV_RBF ? 3 : 4) : 1;     // reduction vectors (the larger count for the merged kernel)
-  __shared__ double red[NVM * 8 * 65 + 3 * 64];             // LDS bounds the waves per CU: keep it to what the type needs
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 8))) void k_spike(EngineView ev,
+                                                                                         const double* __restrict__ C) {
+  // LDS bounds the waves per CU: RBF full 3 x 8 rows + 3 x 64 (14.0 KB), periodic full 5 x 6 rows + 5 x 64 + 30 (18.4 KB,
+  // VGPR-limited to 2 waves / SIMD anyway), value-only 8 rows
+  constexpr int LDS_RBF = 3 * 8 * 65 + 3 * 64, LDS_PER = 5 * 4 * 65 + 5 * 64 + 32;
+  __shared__ double red[FULL ? (KT == SV_RBF ? LDS_RBF : LDS_PER) : 8 * 65 + 3 * 64];
   const int item = blockIdx.x;
   if (KT == 2) {
     // longest jobs first: all periodic (chunk, latent) items, then the RBF ones, so that the tail of the grid is
