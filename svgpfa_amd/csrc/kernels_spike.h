@@ -16,6 +16,10 @@
 #include "engine_common.h"
 #include "sv_math.h"
 
+#ifndef SV_SPIKE_JG
+#define SV_SPIKE_JG 8     // inducing points per LDS reduction group of the RBF / value-only spike pass
+#endif
+
 // One group of 64 consecutive, neuron-sorted spikes: inclusive segmented scan of v over equal
 // keys, continuing the carry (ck, cv) of the previous group; completed segments are stored
 // (each (neuron) has exactly one writer).  key < 0 marks padding lanes (always at the end).
@@ -58,16 +62,15 @@ __device__ void spike_body_periodic_full(const EngineView& ev, const double* __r
   const double sc = 4.0 * p.ip, hh = 0.5 * p.h * L2E;      // phase in quarter turns: (pi/2) (t 4/p)
   const double w2 = -1.0 / (2.0 * hh), w3 = 1.0 / sc;
 
+  // (the neuron ids are re-read in the epilogue instead of living in VGPRs through the pair loop: 168 VGPRs = 3 waves / SIMD)
   double cw[SPL], mu[SPL], st[SPL], ct[SPL], stt[SPL], ctt[SPL];
-  int nid[SPL];
 #pragma unroll
   for (int i = 0; i < SPL; ++i) {
     int idx = i * 64 + lane;
     bool ok = idx < c.count;
     long long gs = c.start + (ok ? idx : 0);
     const double tsc = ev.spk_t[gs] * sc;
-    nid[i] = ok ? ev.spk_n[gs] : -1;
-    cw[i] = ok ? C[(long long)nid[i] * K + k] : 0.0;
+    cw[i] = ok ? C[(long long)ev.spk_n[gs] * K + k] : 0.0;
     mu[i] = 0.0;
     sv_sincos_quarter(tsc, st[i], ct[i]);
     stt[i] = st[i] * tsc;
@@ -153,6 +156,12 @@ __device__ void spike_body_periodic_full(const EngineView& ev, const double* __r
     ev.Tpart[((long long)ch * K + k) * 2 + 1] = t1;
   }
   // spike part of dC[n, k]: per-neuron sums of mu_s
+  int nid[SPL];
+#pragma unroll
+  for (int i = 0; i < SPL; ++i) {
+    const int idx = i * 64 + lane;
+    nid[i] = (idx < c.count) ? ev.spk_n[c.start + idx] : -1;
+  }
   if (c.split) {
     double tot = 0.0;
 #pragma unroll
@@ -176,8 +185,9 @@ __device__ void spike_body(const EngineView& ev, const double* __restrict__ C, i
     spike_body_periodic_full<SPL>(ev, C, ch, k, red);
     return;
   }
-  // NV partial-sum vectors per inducing point: P0 | P0 P1 P2 (RBF) | P0 P1 P2 P3 (periodic, value-only path unused)
-  constexpr int NV = FULL ? (KT == SV_RBF ? 3 : 4) : 1;
+  // This body: RBF (value-only or full) and periodic value-only.  NV partial-sum vectors per inducing point: P0 | P0 P1 P2
+  constexpr int NV = FULL ? 3 : 1;
+  constexpr int JG = SV_SPIKE_JG;     // inducing points per reduction group
   const int lane = threadIdx.x;
   const SpikeChunk c = ev.chunks[ch];
   const LatentMeta m = ev.meta[k];
@@ -219,7 +229,7 @@ __device__ void spike_body(const EngineView& ev, const double* __restrict__ C, i
     mu[i] = 0.0;
     if (KT == SV_PERIODIC) sv_sincos_quarter(ts[i], st[i], ct[i]);
   }
-  double* zsc = red + NV * 8 * 65;   // 3 * 64 doubles behind the reduction area: scaled z, sin / cos of its phase
+  double* zsc = red + NV * JG * 65;   // 3 * 64 doubles behind the reduction area: scaled z, sin / cos of its phase
   if (lane < M) {
     const double zq = z[lane] * sc;
     zsc[lane] = zq;
@@ -233,11 +243,11 @@ __device__ void spike_body(const EngineView& ev, const double* __restrict__ C, i
   __syncthreads();
   double t0acc = 0.0, t1acc = 0.0;
 
-  for (int jb = 0; jb < M; jb += 8) {
+  for (int jb = 0; jb < M; jb += JG) {
 #pragma unroll
-    for (int jj = 0; jj < 8; ++jj) {
+    for (int jj = 0; jj < JG; ++jj) {
       const int j = jb + jj;
-      double p0 = 0.0, p1 = 0.0, p2 = 0.0, p3 = 0.0;
+      double p0 = 0.0, p1 = 0.0, p2 = 0.0;
       if (j < M) {
         const double zs = zsc[j], aj = a[j];
         double sz = 0.0, cz = 0.0;
@@ -247,27 +257,20 @@ __device__ void spike_body(const EngineView& ev, const double* __restrict__ C, i
         }
 #pragma unroll
         for (int i = 0; i < SPL; ++i) {
-          double y, sn = 0.0, u = 0.0;
+          double y, u = 0.0;
           if (KT == SV_RBF) {
             u = ts[i] - zs;
             y = -(u * u);
           } else {
             const double cs = fma(st[i], sz, ct[i] * cz);     // cos(2 pi (t - z) / p)
-            sn = fma(st[i], cz, -(ct[i] * sz));               // sin(2 pi (t - z) / p)
             y = fma(cs, hh, -hh);
           }
           const double kt = sv_exp2_neg(y);
-          if (FULL) {
+          if (FULL) {                                         // RBF only (periodic: spike_body_periodic_full)
             const double ck = cw[i] * kt;
             p0 += ck;
             p2 = fma(ck, y, p2);
-            if (KT == SV_RBF) {
-              p1 = fma(ck, u, p1);
-            } else {
-              const double cks = ck * sn;
-              p1 += cks;
-              p3 = fma(cks, ts[i], p3);    // sum c ktil sn (t - z) = p3 - z p1, finished after the reduction
-            }
+            p1 = fma(ck, u, p1);
             mu[i] = fma(kt, aj, mu[i]);
           } else {
             p0 = fma(cw[i], kt, p0);
@@ -276,37 +279,32 @@ __device__ void spike_body(const EngineView& ev, const double* __restrict__ C, i
       }
       red[jj * 65 + lane] = p0;
       if (FULL) {
-        red[(8 + jj) * 65 + lane] = p1;
-        red[(16 + jj) * 65 + lane] = p2;
-        if (KT == SV_PERIODIC) red[(24 + jj) * 65 + lane] = p3;
+        red[(JG + jj) * 65 + lane] = p1;
+        red[(2 * JG + jj) * 65 + lane] = p2;
       }
     }
     __syncthreads();
     // transposed reduction: lane (v, quarter) sums 16 of the 64 lane-partials of vector v
-    double p1keep = 0.0;   // lane 8 + jj holds P1_j in round 0 and the periodic P3_j in round 1
 #pragma unroll
-    for (int v0 = 0; v0 < NV * 8; v0 += 16) {
+    for (int v0 = 0; v0 < NV * JG; v0 += 16) {
       const int v = v0 + (lane & 15), qd = lane >> 4;
       double s = 0.0;
-      if (v < NV * 8) {
+      if (v < NV * JG) {
 #pragma unroll
         for (int e = 0; e < 16; ++e) s += red[v * 65 + qd * 16 + e];
       }
       s += __shfl_xor(s, 16, 64);
       s += __shfl_xor(s, 32, 64);
-      const int j = jb + (v & 7);
-      if (lane < 16 && v < NV * 8 && j < M) {
+      const int j = jb + (v % JG);
+      if (lane < 16 && v < NV * JG && j < M) {
         const long long o = (long long)ch * ev.sumM + m.colM + j;
-        const int type = v >> 3;
+        const int type = v / JG;
         if (type == 0)
           ev.P0[o] = s;
-        else if (type == 1) {
+        else if (type == 1)
           ev.P1[o] = s * w1;
-          p1keep = s;
-        } else if (type == 2)
+        else
           t0acc = fma(a[j], s, t0acc);
-        else   // sum_s c ktil sn (t - z_j) = P3_j - z_j P1_j   (scaled units)
-          t1acc = fma(a[j], s - zsc[j] * p1keep, t1acc);
       }
     }
     __syncthreads();
@@ -343,8 +341,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 8))) void
                                                                                          const double* __restrict__ C) {
   // LDS bounds the waves per CU: RBF full 3 x 8 rows + 3 x 64 (14.0 KB), periodic full 5 x 6 rows + 5 x 64 + 30 (18.4 KB,
   // VGPR-limited to 2 waves / SIMD anyway), value-only 8 rows
-  constexpr int LDS_RBF = 3 * 8 * 65 + 3 * 64, LDS_PER = 5 * 4 * 65 + 5 * 64 + 32;
-  __shared__ double red[FULL ? (KT == SV_RBF ? LDS_RBF : LDS_PER) : 8 * 65 + 3 * 64];
+  constexpr int LDS_RBF = 3 * SV_SPIKE_JG * 65 + 3 * 64, LDS_PER = 5 * 4 * 65 + 5 * 64 + 32;
+  __shared__ double red[FULL ? (KT == SV_RBF ? LDS_RBF : LDS_PER) : SV_SPIKE_JG * 65 + 3 * 64];
   const int item = blockIdx.x;
   if (KT == 2) {
     // longest jobs first: all periodic (chunk, latent) items, then the RBF ones, so that the tail of the grid is
