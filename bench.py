@@ -138,6 +138,9 @@ def main():
     ap.add_argument("--variant", default="all", choices=["all", "estep"])
     ap.add_argument("--cpu-sample-trials", type=int, default=200)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--estep-cache", action="store_true",
+                    help="E-step variant only: let value-only evaluations reuse the spike sums while C, Z, theta are "
+                         "unchanged (svgpfa_set_embedding_token), as the closure of a real E-step does")
     args = ap.parse_args()
 
     import torch
@@ -164,6 +167,9 @@ def main():
     mask = 15 if args.variant == "all" else 1
     shared = torch.empty(eng.shared_len, dtype=torch.float64, device=dev)
     grads = eng.alloc_grads(mask)
+
+    if args.estep_cache and args.variant == "estep":
+        eng.set_embedding_token(1)
 
     def step():
         if args.variant == "all":
@@ -218,7 +224,8 @@ def main():
             "config": {"workload": f"{args.config}: {full['R']} trials x {full['N']} neurons x {full['K']} latents x "
                                    f"{full['Ms'][0]} inducing, {int(full['spike_offsets'][-1])} spikes, Q={full['Q']}",
                        "variant": "ALL (rebuild kernels + ELBO + 4 gradient groups)" if args.variant == "all"
-                       else "E-step (ELBO + variational gradients)",
+                       else ("E-step (ELBO + variational gradients)"
+                                         + (", spike sums reused across evaluations" if args.estep_cache else "")),
                        "parallelism": f"trials sharded {world}-way by spike count, 1 RCCL all-reduce/step" if world > 1 else "single GPU"},
             "elbo": elbo,
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",

@@ -145,6 +145,17 @@ int svgpfa_get_kzz_chol(svgpfa_engine* e, int32_t k, double* out);
 int svgpfa_get_ktz_quad(svgpfa_engine* e, int32_t k, double* out);
 int svgpfa_get_ktz_spikes(svgpfa_engine* e, int32_t k, double* out);
 
+/* Reuse of the spike sums across value-only evaluations.  The reference's E-step closure (stats/svEM.py:218-223)
+ * does not rebuild the spike-time kernel matrices: they depend on the spikes, Z, theta only
+ * (kernelsMatricesStore.py:208-221).  Here the corresponding quantity is P0_j = sum_s C[n_s, k] kappa(t_s, z_j),
+ * which depends on (spikes, Z, theta, C) and NOT on the variational parameters.  `token` identifies the CONTENT of C:
+ * when an evaluation that needs no embedding / kernel / inducing-point gradients (grad_mask without bits 2, 4, 8)
+ * sees the same non-zero token as the last value-only evaluation that ran the spike pass, and no full-gradient
+ * evaluation, svgpfa_build_kernels or svgpfa_set_spikes has happened since, the spike pass is skipped and P0 is
+ * reused (results are bit-identical to the un-cached evaluation).  token = 0 (default)
+ * disables the reuse.  The caller must change the token whenever it changes C. */
+int svgpfa_set_embedding_token(svgpfa_engine* e, uint64_t token);
+
 /* Timing hook for bench.py.  While enabled, every svgpfa_elbo call brackets its dominant kernel
  * (the spike-time pass) with a hipEvent pair on the engine's stream; nothing is waited for at
  * record time.  svgpfa_spike_kernel_ms synchronises the stream, adds up the elapsed device time

@@ -49,6 +49,7 @@ SIGNATURES = {
     "svgpfa_get_kzz_chol": (ctypes.c_int, [_vp, _i32, _vp]),
     "svgpfa_get_ktz_quad": (ctypes.c_int, [_vp, _i32, _vp]),
     "svgpfa_get_ktz_spikes": (ctypes.c_int, [_vp, _i32, _vp]),
+    "svgpfa_set_embedding_token": (ctypes.c_int, [_vp, ctypes.c_uint64]),
     "svgpfa_enable_timing": (ctypes.c_int, [_vp, ctypes.c_int]),
     "svgpfa_spike_kernel_ms": (ctypes.c_int, [_vp, ctypes.POINTER(_f64), ctypes.POINTER(_i32)]),
 }

@@ -33,6 +33,7 @@ struct svgpfa_engine {
   bool have_quad = false, have_spikes = false, have_kernels = false, have_stats = false;
   bool aux_valid = false;   // Kzz / L buffers hold the matrices of the current kernel snapshot (getters only)
   bool timing = false;
+  uint64_t emb_token = 0, p0_token = 0;   // svgpfa_set_embedding_token: content id of C now / when P0 was computed
   std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool;  // event pairs, reused
   size_t ev_used = 0;
   std::string err;
@@ -414,6 +415,7 @@ int svgpfa_set_spikes(svgpfa_engine* e, const int64_t* off, const double* times,
   HIPCHK(e, hipMemset(v.Tpart, 0, sizeof(double) * std::max<size_t>(1, (size_t)v.nchunks * v.K * 2)));
   e->have_spikes = true;
   e->have_stats = false;
+  e->p0_token = 0;
   return SVGPFA_OK;
 }
 
@@ -447,6 +449,7 @@ int svgpfa_build_kernels(svgpfa_engine* e, const double* const* Z, const double*
   }
   launch_build(e, 0, &st);
   e->aux_valid = false;
+  e->p0_token = 0;
   HIPCHK(e, hipGetLastError());
   e->have_kernels = true;
   e->have_stats = false;
@@ -539,8 +542,13 @@ int svgpfa_elbo(svgpfa_engine* e, const double* const* mean, const double* const
     HIPCHK(e, hipEventRecord(e->ev_prep, sm));
     HIPCHK(e, hipStreamWaitEvent(sk, e->ev_prep, 0));
   }
-  // ---- spike pass (fp64 VALU bound): needs only a = Kzz^-1 m from k_prep
-  if (v.nchunks > 0) {
+  // ---- spike pass (fp64 VALU bound): needs only a = Kzz^-1 m from k_prep.  A value-only evaluation reuses P0 when
+  //      the caller vouches (token) that C is unchanged since the pass that produced it
+  const bool reuse_p0 = !full && e->emb_token != 0 && e->p0_token == e->emb_token;
+  if (v.nchunks > 0 && !reuse_p0) {
+    // only a value-only pass leaves reusable sums: the full pass accumulates P0 with different roundings, and
+    // cached and un-cached evaluations are to stay bit-identical
+    e->p0_token = full ? 0 : e->emb_token;
     std::pair<hipEvent_t, hipEvent_t>* evp = nullptr;
     if (e->timing) {
       if (e->ev_used == e->ev_pool.size()) {
@@ -677,6 +685,12 @@ int svgpfa_get_ktz_spikes(svgpfa_engine* e, int32_t k, double* out) {
   hipLaunchKernelGGL(k_ktz, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, e->stream, v, (int)k, v.spk_t,
                      v.spk_off, 0, ntot, out);
   HIPCHK(e, hipGetLastError());
+  return SVGPFA_OK;
+}
+
+int svgpfa_set_embedding_token(svgpfa_engine* e, uint64_t token) {
+  if (!e) return SVGPFA_ERR_INVALID;
+  e->emb_token = token;
   return SVGPFA_OK;
 }
 

@@ -154,6 +154,10 @@ class Engine:
                                          self._table(g_Z, [self.R * m for m in self.Ms])))
         return shared, g_mean, g_chol, g_Z
 
+    def set_embedding_token(self, token):
+        """Content id of C for the reuse of the spike sums across value-only evaluations (include/svgpfa.h); 0 disables."""
+        self._check(self.lib.svgpfa_set_embedding_token(self._h, int(token) & 0xFFFFFFFFFFFFFFFF))
+
     def split_shared(self, shared):
         """Views into the shared vector: (elbo, ell, kl, gC N x K, gd N, [gtheta_k])."""
         NK = self.N * self.K

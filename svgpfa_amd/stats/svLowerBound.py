@@ -46,6 +46,9 @@ class _ELBOFunction(torch.autograd.Function):
         if any(need[3 * K + 2:4 * K + 2]):
             mask |= _lib.GRAD_INDPOINTS
         eng = model._engine
+        # content id of C: torch bumps _version on every in-place update (optimiser steps), a new tensor has a new address
+        C = model._C
+        eng.set_embedding_token((hash((C.data_ptr(), C._version)) & 0x7FFFFFFFFFFFFFFF) | 1)
         shared, gm, gc, gz = eng.elbo(model._mean, model._cholVecs, model._C, model._d, mask)
         model._sync()
         if model._reduce is not None:      # trials sharded over ranks: ONE all-reduce of the shared vector

@@ -50,7 +50,8 @@ def _rank_main(rank, world, port, q):
     C, d = model.getSVEmbeddingParams()
     theta = model.getKernelsParams()
     if rank == 0:
-        q.put((hist, msg, C.cpu(), d.cpu(), [t.cpu() for t in theta]))
+        # plain numpy (pickled by value): tensors would travel as shared-memory handles that die with this process
+        q.put((hist, msg, C.cpu().numpy(), d.cpu().numpy(), [t.cpu().numpy() for t in theta]))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -80,7 +81,7 @@ def test_two_rank_em_matches_single_process():
         assert abs(a - b) <= 1e-6 * abs(b), (hist, href)
     assert hist[-1] > hist[0]
     Cr, dr = model.getSVEmbeddingParams()
-    assert torch.allclose(C, Cr.cpu(), rtol=1e-4, atol=1e-6)
-    assert torch.allclose(d, dr.cpu(), rtol=1e-4, atol=1e-6)
+    assert torch.allclose(torch.from_numpy(C), Cr.cpu(), rtol=1e-4, atol=1e-6)
+    assert torch.allclose(torch.from_numpy(d), dr.cpu(), rtol=1e-4, atol=1e-6)
     for a, b in zip(theta, model.getKernelsParams()):
-        assert torch.allclose(a, b.cpu(), rtol=1e-4, atol=1e-6)
+        assert torch.allclose(torch.from_numpy(a), b.cpu(), rtol=1e-4, atol=1e-6)

@@ -229,6 +229,49 @@ def test_half_size_spike_chunks(monkeypatch):
         assert rel_err(b.cpu().numpy(), a.cpu().numpy()) < 1e-9
 
 
+def test_spike_sum_reuse_token():
+    """Value-only evaluations (E-step closure) reuse the spike sums P0 while the caller's token says C is unchanged
+    (include/svgpfa.h: svgpfa_set_embedding_token); results must equal the un-cached evaluation bit for bit, and a
+    new token / build_kernels / a gradient mask that needs the full pass must bring the pass back."""
+    prob = synthetic.make_problem(R=4, N=9, K=3, M=[8, 11, 6], kernels="mix", seed=23, n_quad=40, rate=15.0, jitter=1.0)
+    eng, P = _engine(prob)
+    ref_eng, _ = _engine(prob)
+
+    def both(mask, token):
+        eng.set_embedding_token(token)
+        a = eng.elbo(P["mean"], P["cholVecs"], P["C"], P["d"], mask)
+        b = ref_eng.elbo(P["mean"], P["cholVecs"], P["C"], P["d"], mask)
+        eng.sync(), ref_eng.sync()
+        assert torch.equal(a[0], b[0])
+        if mask & 1:
+            for x, y in zip(a[1] + a[2], b[1] + b[2]):
+                assert torch.equal(x, y)
+        return float(a[0][0])
+
+    e0 = both(1, 7)                       # runs the pass, remembers token 7
+    for k in range(prob["K"]):            # an optimiser step on the variational parameters
+        P["mean"][k].add_(0.05)
+        P["cholVecs"][k].mul_(1.01)
+    e1 = both(1, 7)                       # reuse
+    assert e1 != e0
+    both(0, 7)                            # value only, reuse
+    both(15, 7)                           # full pass (all gradients): invalidates the cached sums
+    both(1, 7)                            # recomputed, then reusable again
+    both(1, 7)
+    P["C"].mul_(1.1)                      # embedding changed -> caller changes the token
+    both(1, 8)
+    eng.build_kernels(P["Z"], P["theta"])
+    ref_eng.build_kernels(P["Z"], P["theta"])
+    both(1, 8)                            # kernels rebuilt -> pass runs again although the token is the same
+    # and the reuse is real: a stale token after changing C gives the OLD spike sums (documented caller contract)
+    P["C"].mul_(0.5)
+    eng.set_embedding_token(8)
+    stale = eng.elbo(P["mean"], P["cholVecs"], P["C"], P["d"], 0)[0]
+    fresh = ref_eng.elbo(P["mean"], P["cholVecs"], P["C"], P["d"], 0)[0]
+    eng.sync(), ref_eng.sync()
+    assert not torch.equal(stale, fresh)
+
+
 def test_repeatable_bitwise():
     """Fixed-order reductions: two evaluations of the same inputs are bit-identical."""
     prob = synthetic.make_problem(R=6, N=20, K=3, M=12, kernels="mix", seed=11, n_quad=100, rate=40.0, jitter=1.0)

@@ -115,9 +115,9 @@ def _rank_main(rank, world, port, q):
         hist.append(float(v))
     st = opt.state[opt._params[0]]
     gathered = [None] * world
-    dist.all_gather_object(gathered, x.detach())
-    if rank == 0:
-        q.put((hist, st["func_evals"], st["n_iter"], z.detach(), gathered, opt.collectives))
+    dist.all_gather_object(gathered, x.detach().numpy())
+    if rank == 0:   # plain numpy (pickled by value): tensors would travel as shared-memory handles that die with this process
+        q.put((hist, st["func_evals"], st["n_iter"], z.detach().numpy(), gathered, opt.collectives))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -148,8 +148,8 @@ def test_two_rank_gloo_matches_single_process():
     assert (nfe, nit) == (fref, nref)
     for a, b in zip(hist, href):
         assert abs(a - b) <= 1e-7 * max(1.0, abs(b)), (hist, href)
-    assert torch.allclose(z, zr.detach(), rtol=1e-5, atol=1e-7)
+    assert torch.allclose(torch.from_numpy(z), zr.detach(), rtol=1e-5, atol=1e-7)
     for a, b in zip(xs_out, xr):
-        assert torch.allclose(a, b.detach(), rtol=1e-5, atol=1e-7)
+        assert torch.allclose(torch.from_numpy(a), b.detach(), rtol=1e-5, atol=1e-7)
     # one all-gather per iteration + a few per line-search evaluation: far fewer than 2 x history inner products
     assert ncoll <= 4 * nfe + 3 * nit + 4
