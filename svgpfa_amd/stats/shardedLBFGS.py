@@ -124,7 +124,7 @@ class ShardedLBFGS:
         w = self._w
 
         orig_loss = closure()
-        loss = float(orig_loss)
+        loss = float(orig_loss.detach()) if torch.is_tensor(orig_loss) else float(orig_loss)
         evals = 1
         st["func_evals"] += 1
         g = self._flat_grad()

@@ -134,13 +134,16 @@ def _optim_params(em_max_iter):
     return op
 
 
-def test_em_small_matches_reference_history():
-    """The reference's SVEM_PyTorch.maximize (ECM, 2 iterations) vs the same loop over the HIP model."""
+@pytest.mark.parametrize("optimizer", ["sharded", "torch"])
+def test_em_small_matches_reference_history(optimizer):
+    """The reference's SVEM_PyTorch.maximize (ECM, 2 iterations) vs the same loop over the HIP model, with the default
+    Gram-form L-BFGS and with torch.optim.LBFGS (the reference's optimiser)."""
     from svgpfa_amd.stats.svEM import SVEM_PyTorch, ErrorTerminationInfo
     prob, ref = load_golden("em_small")
     model = _model(prob)
     out = io.StringIO()
-    hist, elapsed, info, _ = SVEM_PyTorch().maximize(model=model, optim_params=_optim_params(2), method="ECM", out=out)
+    hist, elapsed, info, _ = SVEM_PyTorch(optimizer=optimizer).maximize(model=model, optim_params=_optim_params(2),
+                                                                        method="ECM", out=out)
     assert not isinstance(info, ErrorTerminationInfo), info.message
     assert len(hist) == 3 and len(elapsed) == 3
     want = ref["lowerBoundHist"]
@@ -152,13 +155,14 @@ def test_em_small_matches_reference_history():
     assert rel_err(model.getSVEmbeddingParams()[0].cpu().numpy(), ref["final_C"]) < 1e-4
 
 
-def test_config1_bundled_data_two_em_iterations():
+@pytest.mark.parametrize("optimizer", ["sharded", "torch"])
+def test_config1_bundled_data_two_em_iterations(optimizer):
     """BASELINE config 1: bundled simulated data, ini 545, em_max_iter = 2."""
     from svgpfa_amd.stats.svEM import SVEM_PyTorch, ErrorTerminationInfo
     prob, ref = load_golden("cfg1_bundled")
     model = _model(prob)
-    hist, _, info, _ = SVEM_PyTorch().maximize(model=model, optim_params=_optim_params(2), method="ECM",
-                                               out=io.StringIO())
+    hist, _, info, _ = SVEM_PyTorch(optimizer=optimizer).maximize(model=model, optim_params=_optim_params(2),
+                                                                  method="ECM", out=io.StringIO())
     assert not isinstance(info, ErrorTerminationInfo), info.message
     want = ref["lowerBoundHist"]          # [277018.8745717274, 1003993.0510170484, 1007863.0982122809]
     assert abs(hist[0] - 277018.8745717274) < 1e-10 * 277018.8745717274
