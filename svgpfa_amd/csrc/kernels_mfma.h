@@ -164,31 +164,15 @@ __device__ void times_fwd_body(const EngineView& ev, const int r, const int k, c
   }
 }
 
-// Block -> (trial, latent).  KT = SV_RBF / SV_PERIODIC: one launch per covariance type over that type's
-// latents (best occupancy at full size).  KT = SV_ANYTYPE: one launch over all latents, type resolved per
-// block (fewer single-round kernels on small shards).
-#define SV_ANYTYPE 2
-template <int KT>
-__device__ __forceinline__ void block_item(const EngineView& ev, int& r, int& k) {
-  if (KT == SV_ANYTYPE) {
-    r = blockIdx.x / ev.K;
-    k = blockIdx.x % ev.K;
-  } else {
-    const int nk = ev.ntype[KT];
-    r = blockIdx.x / nk;
-    k = ev.klist[KT][blockIdx.x % nk];
-  }
-}
-
-template <int NT, int KT>
+// One launch over all (trial, latent) items; the covariance type is resolved per block (wave-uniform branch).
+template <int NT>
 __global__ __launch_bounds__(256) void k_times_fwd_mfma(EngineView ev, const double* times,
                                                         const long long* toff, int nper, double* mu_out,
                                                         double* var_out, long long os_t, long long os_k,
                                                         int want_var) {
   extern __shared__ double sm[];
-  int r, k;
-  block_item<KT>(ev, r, k);
-  if (KT == SV_RBF || (KT == SV_ANYTYPE && ev.meta[k].ktype == SV_RBF))
+  const int r = blockIdx.x / ev.K, k = blockIdx.x % ev.K;
+  if (ev.meta[k].ktype == SV_RBF)
     times_fwd_body<NT, SV_RBF>(ev, r, k, times, toff, nper, mu_out, var_out, os_t, os_k, want_var, sm);
   else
     times_fwd_body<NT, SV_PERIODIC>(ev, r, k, times, toff, nper, mu_out, var_out, os_t, os_k, want_var, sm);
@@ -432,12 +416,11 @@ __device__ void quad_bwd_mfma_body(const EngineView& ev, const int r, const int 
   }
 }
 
-template <int NT, int KT, bool FULL>
+template <int NT, bool FULL>
 __global__ __launch_bounds__(256, (NT <= 2 ? 2 : 1)) void k_quad_bwd_mfma(EngineView ev) {   // M <= 32: keep 2 waves / SIMD
   extern __shared__ double sm[];
-  int r, k;
-  block_item<KT>(ev, r, k);
-  if (KT == SV_RBF || (KT == SV_ANYTYPE && ev.meta[k].ktype == SV_RBF))
+  const int r = blockIdx.x / ev.K, k = blockIdx.x % ev.K;
+  if (ev.meta[k].ktype == SV_RBF)
     quad_bwd_mfma_body<NT, SV_RBF, FULL>(ev, r, k, sm);
   else
     quad_bwd_mfma_body<NT, SV_PERIODIC, FULL>(ev, r, k, sm);

@@ -259,9 +259,9 @@ int svgpfa_create(const svgpfa_dims* d, int device, svgpfa_engine** out) {
   int rc = 0;
   DISPATCH_NT(e->NT, rc = allow_lds(e, (k_prep_mfma<NT_>), lds_prep_mfma(NT_));
               if (!rc) rc = allow_lds(e, (k_bwd_mfma<NT_>), lds_bwd_mfma(NT_));
-              if (!rc) rc = allow_lds(e, (k_times_fwd_mfma<NT_, SV_ANYTYPE>), lds_times_mfma(NT_));
-              if (!rc) rc = allow_lds(e, (k_quad_bwd_mfma<NT_, SV_ANYTYPE, true>), lds_qbwd_mfma(NT_));
-              if (!rc) rc = allow_lds(e, (k_quad_bwd_mfma<NT_, SV_ANYTYPE, false>), lds_qbwd_mfma(NT_)));
+              if (!rc) rc = allow_lds(e, (k_times_fwd_mfma<NT_>), lds_times_mfma(NT_));
+              if (!rc) rc = allow_lds(e, (k_quad_bwd_mfma<NT_, true>), lds_qbwd_mfma(NT_));
+              if (!rc) rc = allow_lds(e, (k_quad_bwd_mfma<NT_, false>), lds_qbwd_mfma(NT_)));
   if (rc) return rc;
   DISPATCH_KS(e->KKT, rc = allow_lds(e, (k_quad_ell_mfma<KS_, 0>), lds_qell_mfma(e, 0));
               if (!rc) rc = allow_lds(e, (k_quad_ell_mfma<KS_, 2>), std::max(lds_qell_mfma(e, 0), lds_qell_mfma(e, 1))));
@@ -504,7 +504,7 @@ static int launch_quad_ell(svgpfa_engine* e, const double* C, const double* d, i
 static int launch_times(svgpfa_engine* e, const double* times, const long long* toff, int nper, double* mu,
                         double* var, long long os_t, long long os_k, int want_var) {
   EngineView& v = e->v;
-  DISPATCH_NT(e->NT, hipLaunchKernelGGL((k_times_fwd_mfma<NT_, SV_ANYTYPE>), dim3(v.R * v.K), dim3(256),
+  DISPATCH_NT(e->NT, hipLaunchKernelGGL((k_times_fwd_mfma<NT_>), dim3(v.R * v.K), dim3(256),
                                         lds_times_mfma(NT_), e->stream, v, times, toff, nper, mu, var, os_t, os_k, want_var));
   HIPCHK(e, hipGetLastError());
   return SVGPFA_OK;
@@ -580,10 +580,10 @@ int svgpfa_elbo(svgpfa_engine* e, const double* const* mean, const double* const
   if ((rc = launch_quad_ell(e, C, d, (mask & 2u) ? 1 : 0, want_lat ? 1 : 0))) return rc;
   if (want_lat) {
     if (mask & (4u | 8u)) {
-      DISPATCH_NT(e->NT, hipLaunchKernelGGL((k_quad_bwd_mfma<NT_, SV_ANYTYPE, true>), dim3(v.R * v.K), dim3(256),
+      DISPATCH_NT(e->NT, hipLaunchKernelGGL((k_quad_bwd_mfma<NT_, true>), dim3(v.R * v.K), dim3(256),
                                             lds_qbwd_mfma(NT_), sm, v));
     } else {
-      DISPATCH_NT(e->NT, hipLaunchKernelGGL((k_quad_bwd_mfma<NT_, SV_ANYTYPE, false>), dim3(v.R * v.K), dim3(256),
+      DISPATCH_NT(e->NT, hipLaunchKernelGGL((k_quad_bwd_mfma<NT_, false>), dim3(v.R * v.K), dim3(256),
                                             lds_qbwd_mfma(NT_), sm, v));
     }
   }
