@@ -761,7 +761,8 @@ __global__ __launch_bounds__(64 * NT) void k_prep_mfma(EngineView ev, LatentPtrT
 // of [C | C^2/2] and d, so that E = w 2^h.  The LOOPED operand matrix of the whole trial sits in LDS
 // (rows padded to LDK = 4 KS + 2 doubles: conflict-free fragment reads); the wave's own 16 rows of the
 // other matrix sit in a small per-wave LDS slice.  When the looped matrix exceeds the LDS budget (large N K or
-// Q K) it is streamed through LDS in chunks of lc tiles.  grid = R * parts blocks of 256 threads.
+// Q K) it is streamed through LDS in chunks of lc tiles.  grid = R * parts blocks of 64 NW threads (NW = 4 waves; the
+// count is a launch parameter, larger blocks measured slower because fewer of them fit a CU).
 template <int KS, int ROLE>
 __device__ __forceinline__ void quad_ell_mfma_body(const EngineView& ev, const double* C, const double* d,
                                                    int want_sums, int write_ell, int parts, int lc, int blk,
@@ -777,33 +778,34 @@ __device__ __forceinline__ void quad_ell_mfma_body(const EngineView& ev, const d
   const int Lrows = LC * 16;
   const int r = blk / parts, part = blk % parts;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 15, lg = lane >> 4;
+  const int NTH = blockDim.x, NW = NTH >> 6;   // waves per block (host launch parameter)
   double* LM = sm;                          // (Lrows + 1) * LDK  looped matrix: ROLE 0 [mu | var], ROLE 1 log2e [C | C^2/2]
   double* lv = LM + (Lrows + 1) * LDK;      // Lp   looped vector: ROLE 0 w_q, ROLE 1 log2e d_n
-  double* OW = lv + Lp;                     // 4 * 16 * LDK  per-wave rows of the other matrix
-  double* red = OW + 4 * 16 * LDK;          // 8
+  double* OW = lv + Lp;                     // NW * 16 * LDK  per-wave rows of the other matrix
+  double* red = OW + NW * 16 * LDK;         // 8
   const int lrows_tot = (ROLE == 0) ? Q : N;
 
   // fill rows [row0, row0 + Lrows) of the looped matrix: zero the padding, then batched independent loads
   // (8 in flight per thread) over the contiguous sources mu/var [Q x K] (ROLE 0) or C [N x K] (ROLE 1)
   auto fill_lm = [&](int row0) {
-    for (int e = tid; e < (Lrows + 1) * LDK; e += 256) LM[e] = 0.0;
+    for (int e = tid; e < (Lrows + 1) * LDK; e += NTH) LM[e] = 0.0;
     __syncthreads();
     const int nrow = (lrows_tot - row0 < Lrows) ? (lrows_tot - row0) : Lrows;
     const int tot = nrow * K;
     const double* s0 = ((ROLE == 0) ? ev.muq + (long long)r * Q * K : C) + (long long)row0 * K;
     const double* s1 = ((ROLE == 0) ? ev.varq + (long long)r * Q * K : C) + (long long)row0 * K;
-    for (int b0 = 0; b0 < tot; b0 += 256 * 8) {
+    for (int b0 = 0; b0 < tot; b0 += NTH * 8) {
       double v0[8], v1[8];
 #pragma unroll
       for (int u = 0; u < 8; ++u) {
-        const int idx = b0 + u * 256 + tid;
+        const int idx = b0 + u * NTH + tid;
         const bool ok = idx < tot;
         v0[u] = ok ? s0[idx] : 0.0;
         v1[u] = (ROLE == 0) ? (ok ? s1[idx] : 0.0) : v0[u];
       }
 #pragma unroll
       for (int u = 0; u < 8; ++u) {
-        const int idx = b0 + u * 256 + tid;
+        const int idx = b0 + u * NTH + tid;
         if (idx < tot) {
           const int row = idx / K, c = idx - row * K;
           if (ROLE == 0) {
@@ -819,14 +821,14 @@ __device__ __forceinline__ void quad_ell_mfma_body(const EngineView& ev, const d
     __syncthreads();
   };
 
-  for (int i = tid; i < Lp; i += 256)
+  for (int i = tid; i < Lp; i += NTH)
     lv[i] = (ROLE == 0) ? ((i < Q) ? ev.wq[(long long)r * Q + i] : 0.0) : ((i < N) ? d[i] * L2E : 0.0);
   if (LC == LT) fill_lm(0);     // common case: the whole looped matrix stays resident
   else __syncthreads();
 
   double esum = 0.0;
   double* ow = OW + wave * 16 * LDK;
-  for (int ot0 = part * 4; ot0 < OT; ot0 += parts * 4) {     // block-uniform rounds; wave `wave` owns tile ot0 + wave
+  for (int ot0 = part * NW; ot0 < OT; ot0 += parts * NW) {     // block-uniform rounds; wave `wave` owns tile ot0 + wave
     const int ot = ot0 + wave;
     const bool active = ot < OT;
     // own 16 rows -> per-wave LDS slice (wave-local: no block barrier needed); the source rows are
@@ -947,7 +949,7 @@ __device__ __forceinline__ void quad_ell_mfma_body(const EngineView& ev, const d
 // ROLE 0 / 1: one role per launch.  ROLE 2: both roles in one launch (blocks [0, nb) role 0, [nb, 2 nb) role 1) for
 // small shards, where each launch is latency- rather than throughput-bound.
 template <int KS, int ROLE>
-__global__ __launch_bounds__(256) void k_quad_ell_mfma(EngineView ev, const double* C, const double* d,
+__global__ __launch_bounds__(512) void k_quad_ell_mfma(EngineView ev, const double* C, const double* d,
                                                        int want_sums, int write_ell, int parts, int lc0, int lc1) {
   extern __shared__ double sm[];
   if (ROLE == 2) {

@@ -29,6 +29,7 @@ struct svgpfa_engine {
   int Mmax = 0, NT = 1;
   int ell_parts = 0, KKT = 1;  // ell_parts > 0: MFMA GEMM form of the quadrature term
   int ell_lc[2] = {0, 0};      // looped tiles resident in LDS per role (fewer than all: streamed in chunks)
+  int ell_nw = 4;              // waves per block of the ELL kernels
   long long totM = 0, totMM = 0;  // R*sum M, R*sum M^2
   bool have_quad = false, have_spikes = false, have_kernels = false, have_stats = false;
   bool aux_valid = false;   // Kzz / L buffers hold the matrices of the current kernel snapshot (getters only)
@@ -105,7 +106,7 @@ static size_t lds_qbwd_mfma(int NT) {
 static size_t lds_qell_mfma_lc(const svgpfa_engine* e, int role, int lc) {
   size_t K2 = 2 * e->v.K, KKP = (K2 + 3) & ~(size_t)3, LDK = KKP + 2;
   size_t Lp = (((role == 0 ? e->v.Q : e->v.N) + 15) / 16) * 16;
-  return (((size_t)lc * 16 + 1) * LDK + Lp + 4 * 16 * LDK + 8) * 8;
+  return (((size_t)lc * 16 + 1) * LDK + Lp + (size_t)e->ell_nw * 16 * LDK + 8) * 8;
 }
 static int qell_chunk(const svgpfa_engine* e, int role) {
   const int LT = ((role == 0 ? e->v.Q : e->v.N) + 15) / 16;
@@ -223,14 +224,18 @@ int svgpfa_create(const svgpfa_dims* d, int device, svgpfa_engine** out) {
   DALLOC(e, v.gaq, e->totM); DALLOC(e, v.GW, e->totMM); DALLOC(e, v.gZq, e->totM);
   DALLOC(e, v.gthq, (size_t)v.R * v.K * 2);
   e->KKT = (2 * v.K + 3) / 4;   // KS: k-steps of the h product
-  e->ell_lc[0] = qell_chunk(e, 0);
-  e->ell_lc[1] = qell_chunk(e, 1);
   // blocks per trial of the ELL kernels: every block re-stages the trial's looped operand in LDS, so fewer blocks
   // per trial are cheaper as long as the grid still fills the chip (measured on cfg3: 1 -> 151 us, 4 -> 168 us)
-  if (e->ell_lc[0] <= 0 || e->ell_lc[1] <= 0)
-    FAIL(e, SVGPFA_ERR_UNSUPPORTED, "n_neurons / n_quad too large for the LDS-resident ELL kernels");
   e->ell_parts = std::min(4, std::max(1, (383 + v.R) / v.R));
   if (getenv("SVGPFA_ELL_PARTS")) e->ell_parts = std::max(1, atoi(getenv("SVGPFA_ELL_PARTS")));
+  // waves per block: 4.  More waves per block would divide the 13 own tiles of cfg3 more evenly (7 waves: 2 rounds)
+  // but at ~165 VGPRs only 12 waves fit a CU, i.e. ONE such block instead of three: measured 152 us vs 128 us.
+  e->ell_nw = 4;
+  if (getenv("SVGPFA_ELL_NW")) e->ell_nw = std::min(8, std::max(1, atoi(getenv("SVGPFA_ELL_NW"))));
+  e->ell_lc[0] = qell_chunk(e, 0);
+  e->ell_lc[1] = qell_chunk(e, 1);
+  if (e->ell_lc[0] <= 0 || e->ell_lc[1] <= 0)
+    FAIL(e, SVGPFA_ERR_UNSUPPORTED, "n_neurons / n_quad too large for the LDS-resident ELL kernels");
   v.ncd = v.R;
   v.nell = v.R * e->ell_parts;
   DALLOC(e, v.gCpart, (size_t)v.ncd * v.N * 2 * v.K); DALLOC(e, v.gdpart, (size_t)v.ncd * v.N);
@@ -488,7 +493,7 @@ static int launch_quad_ell(svgpfa_engine* e, const double* C, const double* d, i
   EngineView& v = e->v;
   // role 0 (dC, dd and the ELL value) always runs: its column sums give sum E; role 1 (latent adjoints) rides in the
   // same launch when some latent-side gradient is wanted
-  dim3 gm(v.R * e->ell_parts), bm(256);
+  dim3 gm(v.R * e->ell_parts), bm(64 * e->ell_nw);
   if (want_lat) {
     const size_t l2 = std::max(lds_qell_mfma(e, 0), lds_qell_mfma(e, 1));
     DISPATCH_KS(e->KKT, hipLaunchKernelGGL((k_quad_ell_mfma<KS_, 2>), dim3(2 * gm.x), bm, l2, e->stream, v, C, d, want_cd,
