@@ -58,7 +58,7 @@ __device__ __forceinline__ void load_factors(const EngineView& ev, const LatentM
   const int M = m.M, tid = threadIdx.x;
   const long long base = m.offMM + (long long)r * M * M;
   const long long vbase = m.offM + (long long)r * M;
-  for (int e = tid; e < MP * MP; e += 256) {
+  for (int e = tid; e < MP * MP; e += (int)blockDim.x) {
     int i = e / MP, j = e % MP;
     bool in = (i < M) && (j < M);
     Li[i * LD + j] = in ? ev.Linv[base + i * M + j] : 0.0;
@@ -72,7 +72,7 @@ __device__ __forceinline__ void load_factors(const EngineView& ev, const LatentM
 
 // ------------------------------------------------------------------------ k_times_fwd_mfma
 // Posterior mean / variance of latent k at a CSR list of times (reference
-// svPosteriorOnLatents.py:185-216, :265-300).  grid = R*K blocks of 256 threads; each wavefront
+// svPosteriorOnLatents.py:185-216, :265-300).  grid = R*K blocks of 128 or 256 threads; each wavefront
 // walks tiles of 16 time points.  Output element (time gi, latent k) at gi*os_t + k*os_k.
 template <int NT, int KT>
 __device__ void times_fwd_body(const EngineView& ev, const int r, const int k, const double* times,
@@ -108,15 +108,16 @@ __device__ void times_fwd_body(const EngineView& ev, const int r, const int k, c
     }
 
   const int ntiles = (nt + 15) >> 4;
+  const int NWB = blockDim.x >> 6;     // waves per block (launch parameter; 4)
   // the time of the NEXT tile is fetched one iteration ahead (global latency hidden behind the MFMA chain)
   double tq_next = (wave < ntiles) ? times[t0 + ((16 * wave + li < nt) ? 16 * wave + li : 0)] : 0.0;
-  for (int tile = wave; tile < ntiles; tile += 4) {
+  for (int tile = wave; tile < ntiles; tile += NWB) {
     const int node = 16 * tile + li;
     const bool ok = node < nt;
     const double tq = tq_next;
     {
-      const int nn = node + 64;
-      if (tile + 4 < ntiles) tq_next = times[t0 + ((nn < nt) ? nn : 0)];
+      const int nn = node + 16 * NWB;
+      if (tile + NWB < ntiles) tq_next = times[t0 + ((nn < nt) ? nn : 0)];
     }
     d4 X0[NT];
     double stq = 0.0, ctq = 0.0;
@@ -194,11 +195,12 @@ __device__ void quad_bwd_mfma_body(const EngineView& ev, const int r, const int 
   double* Vl = Li + MP * LD;          // MP*LD
   double* ul = Vl + MP * LD;          // MP
   double* zl = ul + MP;               // MP
-  double* S = zl + MP;                // 4 * 16*LD  (per-wave transpose scratch; later the Gt sum buffer)
-  double* gvs = S + 4 * 16 * LD;      // 4 * 16
-  double* vred = gvs + 64;            // 4 * 2 * MP  (gu / dz partials per wave)
-  double* tred = vred + 8 * MP;       // 8
-  double* szl = tred + 8;             // MP  sin of the inducing-point phases (periodic)
+  const int NTHB = blockDim.x, NWB = NTHB >> 6;   // 2 or 4 waves per block (host: 2 when the grid is large enough)
+  double* S = zl + MP;                // NWB * 16*LD  (per-wave transpose scratch; later the MP x MP Gt sum buffer)
+  double* gvs = S + NWB * 16 * LD;    // NWB * 16
+  double* vred = gvs + NWB * 16;      // NWB * 2 * MP  (gu / dz partials per wave)
+  double* tred = vred + NWB * 2 * MP; // NWB * 2
+  double* szl = tred + NWB * 2;       // MP  sin of the inducing-point phases (periodic)
   double* czl = szl + MP;             // MP  cos
   const KPar p = make_kpar(m, ev.theta + 2 * k);
   const long long base = m.offMM + (long long)r * M * M;
@@ -262,10 +264,10 @@ __device__ void quad_bwd_mfma_body(const EngineView& ev, const int r, const int 
     gm_n = (nn < Q) ? ev.gmuq[gi * K + k] : 0.0;
     gv_n = (nn < Q) ? ev.gvarq[gi * K + k] : 0.0;
   }
-  for (int tile = wave; tile < ntiles; tile += 4) {
+  for (int tile = wave; tile < ntiles; tile += NWB) {
     const double tq = tq_n, gm = gm_n, gvv = gv_n;
-    if (tile + 4 < ntiles) {
-      const int nn = 16 * (tile + 4) + li;
+    if (tile + NWB < ntiles) {
+      const int nn = 16 * (tile + NWB) + li;
       const long long gi = (long long)r * Q + ((nn < Q) ? nn : 0);
       tq_n = ev.tq[gi];
       gm_n = (nn < Q) ? ev.gmuq[gi * K + k] : 0.0;
@@ -359,7 +361,7 @@ __device__ void quad_bwd_mfma_body(const EngineView& ev, const int r, const int 
     lds_wave_fence();
   }
 
-  // ---- reductions: over the 16 time lanes, then over the 4 wavefronts (fixed order)
+  // ---- reductions: over the 16 time lanes, then over the wavefronts (fixed order)
 #pragma unroll
   for (int a = 0; a < NT; ++a)
 #pragma unroll
@@ -378,7 +380,7 @@ __device__ void quad_bwd_mfma_body(const EngineView& ev, const int r, const int 
     tred[wave * 2 + 1] = th1;
   }
   __syncthreads();   // all waves done with their scratch: S becomes the MP x MP sum buffer
-  for (int w = 0; w < 4; ++w) {
+  for (int w = 0; w < NWB; ++w) {
     if (wave == w) {
       int t = 0;
 #pragma unroll
@@ -399,20 +401,27 @@ __device__ void quad_bwd_mfma_body(const EngineView& ev, const int r, const int 
     __syncthreads();
   }
   if (tid < M) {
-    double g = ((vred[0 * MP + tid] + vred[2 * MP + tid]) + vred[4 * MP + tid]) + vred[6 * MP + tid];
+    double g = vred[tid];
+    for (int w = 1; w < NWB; ++w) g += vred[(2 * w) * MP + tid];
     ev.gaq[vbase + tid] = g;
     if (FULL) {
-      double z = ((vred[1 * MP + tid] + vred[3 * MP + tid]) + vred[5 * MP + tid]) + vred[7 * MP + tid];
+      double z = vred[MP + tid];
+      for (int w = 1; w < NWB; ++w) z += vred[(2 * w + 1) * MP + tid];
       ev.gZq[vbase + tid] = p.cz * z;
     }
   }
-  for (int e = tid; e < M * M; e += 256) {
+  for (int e = tid; e < M * M; e += NTHB) {
     int i = e / M, j = e % M;
     ev.GW[base + e] = ((i >> 4) >= (j >> 4)) ? S[i * MP + j] : S[j * MP + i];
   }
   if (FULL && tid == 0) {
-    ev.gthq[item * 2 + 0] = p.c0 * (((tred[0] + tred[2]) + tred[4]) + tred[6]);
-    ev.gthq[item * 2 + 1] = p.c1 * (((tred[1] + tred[3]) + tred[5]) + tred[7]);
+    double t0s = tred[0], t1s = tred[1];
+    for (int w = 1; w < NWB; ++w) {
+      t0s += tred[2 * w];
+      t1s += tred[2 * w + 1];
+    }
+    ev.gthq[item * 2 + 0] = p.c0 * t0s;
+    ev.gthq[item * 2 + 1] = p.c1 * t1s;
   }
 }
 

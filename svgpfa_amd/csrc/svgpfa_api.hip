@@ -30,6 +30,9 @@ struct svgpfa_engine {
   int ell_parts = 0, KKT = 1;  // ell_parts > 0: MFMA GEMM form of the quadrature term
   int ell_lc[2] = {0, 0};      // looped tiles resident in LDS per role (fewer than all: streamed in chunks)
   int ell_nw = 4;              // waves per block of the ELL kernels
+  int tile_nw = 4;             // waves per block of k_quad_bwd: 2 when R K >= 2048 and M <= 32 (13 tiles of Q = 200 split
+                               // 7 + 6 instead of 4 + 3 + 3 + 3: 226 -> 203 us on cfg3), else 4 (shorter per-block latency).
+                               // k_times_fwd stays at 4 (2 measured slower: 107 vs 101 us)
   long long totM = 0, totMM = 0;  // R*sum M, R*sum M^2
   bool have_quad = false, have_spikes = false, have_kernels = false, have_stats = false;
   bool aux_valid = false;   // Kzz / L buffers hold the matrices of the current kernel snapshot (getters only)
@@ -91,9 +94,9 @@ static size_t lds_times_mfma(int NT) {
   size_t MP = 16 * NT, LD = MP + 2;
   return (2 * MP * LD + 4 * MP) * 8;
 }
-static size_t lds_qbwd_mfma(int NT) {
-  size_t MP = 16 * NT, LD = MP + 2;
-  return (2 * MP * LD + 2 * MP + 4 * 16 * LD + 64 + 8 * MP + 8 + 2 * MP) * 8;
+static size_t lds_qbwd_mfma(int NT, int NWB = 4) {
+  size_t MP = 16 * NT, LD = MP + 2, W = NWB;
+  return (2 * MP * LD + 2 * MP + W * 16 * LD + W * 16 + W * 2 * MP + W * 2 + 2 * MP) * 8;
 }
 #define DISPATCH_NT(nt, ...)                                 \
   switch (nt) {                                              \
@@ -232,6 +235,8 @@ int svgpfa_create(const svgpfa_dims* d, int device, svgpfa_engine** out) {
   // but at ~165 VGPRs only 12 waves fit a CU, i.e. ONE such block instead of three: measured 152 us vs 128 us.
   e->ell_nw = 4;
   if (getenv("SVGPFA_ELL_NW")) e->ell_nw = std::min(8, std::max(1, atoi(getenv("SVGPFA_ELL_NW"))));
+  e->tile_nw = ((long long)v.R * v.K >= 2048 && e->NT <= 2) ? 2 : 4;
+  if (getenv("SVGPFA_TILE_NW")) e->tile_nw = atoi(getenv("SVGPFA_TILE_NW")) == 2 && e->NT <= 2 ? 2 : 4;
   e->ell_lc[0] = qell_chunk(e, 0);
   e->ell_lc[1] = qell_chunk(e, 1);
   if (e->ell_lc[0] <= 0 || e->ell_lc[1] <= 0)
@@ -585,11 +590,11 @@ int svgpfa_elbo(svgpfa_engine* e, const double* const* mean, const double* const
   if ((rc = launch_quad_ell(e, C, d, (mask & 2u) ? 1 : 0, want_lat ? 1 : 0))) return rc;
   if (want_lat) {
     if (mask & (4u | 8u)) {
-      DISPATCH_NT(e->NT, hipLaunchKernelGGL((k_quad_bwd_mfma<NT_, true>), dim3(v.R * v.K), dim3(256),
-                                            lds_qbwd_mfma(NT_), sm, v));
+      DISPATCH_NT(e->NT, hipLaunchKernelGGL((k_quad_bwd_mfma<NT_, true>), dim3(v.R * v.K), dim3(64 * e->tile_nw),
+                                            lds_qbwd_mfma(NT_, e->tile_nw), sm, v));
     } else {
-      DISPATCH_NT(e->NT, hipLaunchKernelGGL((k_quad_bwd_mfma<NT_, false>), dim3(v.R * v.K), dim3(256),
-                                            lds_qbwd_mfma(NT_), sm, v));
+      DISPATCH_NT(e->NT, hipLaunchKernelGGL((k_quad_bwd_mfma<NT_, false>), dim3(v.R * v.K), dim3(64 * e->tile_nw),
+                                            lds_qbwd_mfma(NT_, e->tile_nw), sm, v));
     }
   }
   // ---- join the spike pass, per-item backward, then the fixed-order reductions
