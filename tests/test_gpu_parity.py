@@ -212,6 +212,32 @@ def test_empty_trials(which):
         assert rel_err(out["g_theta"][k], ref["g_theta"][k].numpy()) < TOL_A
 
 
+def test_trials_of_different_length():
+    """Every trial has its own window: quadrature nodes, inducing points and spikes of trial r live on [0, 1 + 0.4 r]
+    (the reference supports per-trial start / end times, utils/miscUtils.py:226-236)."""
+    from oracle import svgpfa_oracle as orc
+    prob = synthetic.make_problem(R=4, N=6, K=3, M=[8, 10, 7], kernels="mix", seed=29, n_quad=40, rate=12.0, jitter=1.0)
+    off = prob["spike_offsets"]
+    for r in range(prob["R"]):
+        f = 1.0 + 0.4 * r
+        prob["quad_points"][r] *= f
+        prob["quad_weights"][r] *= f
+        prob["spike_times"][off[r]:off[r + 1]] *= f
+        for k in range(prob["K"]):
+            prob["Z"][k][r] *= f
+    eng, P = _engine(prob)
+    out = _eval(eng, P, 15)
+    ref = orc.elbo_and_grads(orc.from_numpy_problem(prob), 15)
+    assert _close(out["elbo"], float(ref["elbo"]), TOL_S)
+    assert rel_err(out["g_C"], ref["g_C"].numpy()) < TOL_A
+    assert rel_err(out["g_d"], ref["g_d"].numpy()) < TOL_A
+    for k in range(prob["K"]):
+        assert rel_err(out["g_mean"][k], ref["g_mean"][k].numpy()[:, :, 0]) < TOL_A
+        assert rel_err(out["g_cholVecs"][k], ref["g_cholVecs"][k].numpy()[:, :, 0]) < TOL_A
+        assert rel_err(out["g_Z"][k], ref["g_Z"][k].numpy()[:, :, 0]) < TOL_A
+        assert rel_err(out["g_theta"][k], ref["g_theta"][k].numpy()) < TOL_A
+
+
 def test_half_size_spike_chunks(monkeypatch):
     """Optional 4-spikes-per-lane granularity of the spike pass (SVGPFA_SMALL_SPIKE_WAVES): different chunking,
     same sums to rounding (tolerance 1e-11 relative on the ELBO, 1e-9 on gradients)."""
