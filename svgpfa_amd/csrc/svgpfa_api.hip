@@ -306,6 +306,7 @@ int svgpfa_set_stream(svgpfa_engine* e, void* s) {
 
 int svgpfa_sync(svgpfa_engine* e) {
   if (!e) return SVGPFA_ERR_INVALID;
+  HIPCHK(e, hipSetDevice(e->device));   // the caller's thread may have another device current
   HIPCHK(e, hipMemcpyAsync(e->status_host, e->v.status, sizeof(int), hipMemcpyDeviceToHost, e->stream));
   HIPCHK(e, hipStreamSynchronize(e->stream));
   int st = *e->status_host;
@@ -330,6 +331,7 @@ int svgpfa_set_reg(svgpfa_engine* e, double eps) {
 
 int svgpfa_set_quad(svgpfa_engine* e, const double* t, const double* w) {
   if (!e || !t || !w) return SVGPFA_ERR_INVALID;
+  HIPCHK(e, hipSetDevice(e->device));   // the caller's thread may have another device current
   size_t n = sizeof(double) * e->v.R * e->v.Q;
   HIPCHK(e, hipMemcpyAsync((void*)e->v.tq, t, n, hipMemcpyDeviceToDevice, e->stream));
   HIPCHK(e, hipMemcpyAsync((void*)e->v.wq, w, n, hipMemcpyDeviceToDevice, e->stream));
@@ -340,6 +342,7 @@ int svgpfa_set_quad(svgpfa_engine* e, const double* t, const double* w) {
 
 int svgpfa_set_spikes(svgpfa_engine* e, const int64_t* off, const double* times, const int32_t* neuron) {
   if (!e || !off) return SVGPFA_ERR_INVALID;
+  HIPCHK(e, hipSetDevice(e->device));   // the caller's thread may have another device current
   EngineView& v = e->v;
   if (e->have_spikes) FAIL(e, SVGPFA_ERR_STATE, "svgpfa_set_spikes may be called once per engine");
   if (off[0] != 0) FAIL(e, SVGPFA_ERR_INVALID, "spike offsets must start at 0");
@@ -449,6 +452,7 @@ static void launch_build(svgpfa_engine* e, int write_aux, const SnapTable* snap)
 
 int svgpfa_build_kernels(svgpfa_engine* e, const double* const* Z, const double* const* theta) {
   if (!e || !Z || !theta) return SVGPFA_ERR_INVALID;
+  HIPCHK(e, hipSetDevice(e->device));   // the caller's thread may have another device current
   EngineView& v = e->v;
   SnapTable st;
   memset(&st, 0, sizeof st);
@@ -536,6 +540,7 @@ int svgpfa_elbo(svgpfa_engine* e, const double* const* mean, const double* const
                 const double* d, unsigned mask, double* shared, double* const* g_mean,
                 double* const* g_cholvec, double* const* g_Z) {
   if (!e || !C || !d || !shared) return SVGPFA_ERR_INVALID;
+  HIPCHK(e, hipSetDevice(e->device));
   int rc;
   if ((rc = check_ready(e))) return rc;
   EngineView& v = e->v;
@@ -610,6 +615,7 @@ int svgpfa_elbo(svgpfa_engine* e, const double* const* mean, const double* const
 int svgpfa_latent_stats(svgpfa_engine* e, const double* const* mean, const double* const* cholvec,
                         double* mu_quad, double* var_quad, double* mu_spk, double* var_spk) {
   if (!e) return SVGPFA_ERR_INVALID;
+  HIPCHK(e, hipSetDevice(e->device));
   int rc;
   if ((rc = check_ready(e))) return rc;
   EngineView& v = e->v;
@@ -635,6 +641,7 @@ int svgpfa_latent_stats(svgpfa_engine* e, const double* const* mean, const doubl
 
 int svgpfa_ell_given_stats(svgpfa_engine* e, const double* C, const double* d, int want_grad, double* out) {
   if (!e || !C || !d || !out) return SVGPFA_ERR_INVALID;
+  HIPCHK(e, hipSetDevice(e->device));
   if (!e->have_stats) FAIL(e, SVGPFA_ERR_STATE, "svgpfa_latent_stats has not been called since the last data / kernel change");
   EngineView& v = e->v;
   int rc;
@@ -648,6 +655,7 @@ int svgpfa_ell_given_stats(svgpfa_engine* e, const double* C, const double* d, i
 int svgpfa_predict(svgpfa_engine* e, const double* const* mean, const double* const* cholvec,
                    const double* times, int32_t T, double* mu, double* var) {
   if (!e || !times || !mu || T <= 0) return SVGPFA_ERR_INVALID;
+  HIPCHK(e, hipSetDevice(e->device));
   if (!e->have_kernels) FAIL(e, SVGPFA_ERR_STATE, "svgpfa_build_kernels has not been called");
   EngineView& v = e->v;
   PtrTable pt;
