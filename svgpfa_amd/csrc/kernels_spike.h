@@ -377,8 +377,8 @@ __global__ void k_mseg(EngineView ev) {
   ev.Mseg[id] = s;
 }
 
-#define SV_FIN_OUT 16   // outputs per block of k_finalize
-#define SV_FIN_GRP 16   // trial groups per block (256 threads): more, smaller blocks fill the chip better than 32 x 8
+#define SV_FIN_OUT 8   // outputs per block of k_finalize
+#define SV_FIN_GRP 32   // trial groups per block (256 threads): 8 x 32 measured best on cfg3: 16 us (32 x 8: 45, 16 x 16: 24, 4 x 64: 20)
 // ------------------------------------------------------------------------------ k_finalize
 // Fixed-order reductions of the per-trial partials into the `shared` output vector
 // [ELBO, ELL, KL, dC (N*K), dd (N), dtheta].  Block roles by blockIdx:
