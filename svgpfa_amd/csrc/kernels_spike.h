@@ -20,24 +20,33 @@
 #define SV_SPIKE_JG 8     // inducing points per LDS reduction group of the RBF / value-only spike pass
 #endif
 
-// One group of 64 consecutive, neuron-sorted spikes: inclusive segmented scan of v over equal
-// keys, continuing the carry (ck, cv) of the previous group; completed segments are stored
-// (each (neuron) has exactly one writer).  key < 0 marks padding lanes (always at the end).
-__device__ __forceinline__ void seg_emit(int key, double v, int& ck, double& cv, double* out, int K,
-                                         int lane) {
+// Per-neuron sums of v over the chunk when lane l owns the SPL CONSECUTIVE spikes [l SPL, (l + 1) SPL) (keys = neuron
+// ids, non-decreasing over the chunk, < 0 = padding at the end): a serial segmented sum inside the lane, ONE wave scan
+// over the lanes' tail partials (sorted keys: the lanes before l whose tail key equals l's head key are exactly those
+// that continue its head segment), then every segment end stores its total -- each neuron has exactly one writer.
+template <int SPL>
+__device__ __forceinline__ void seg_emit_lane(const int (&key)[SPL], const double (&v)[SPL], double* out, int K, int lane) {
+  double run[SPL];
+  run[0] = v[0];
+#pragma unroll
+  for (int i = 1; i < SPL; ++i) run[i] = (key[i] == key[i - 1]) ? run[i - 1] + v[i] : v[i];
+  const int kt = key[SPL - 1];
+  double t = run[SPL - 1];
 #pragma unroll
   for (int dd = 1; dd < 64; dd <<= 1) {
-    double vu = __shfl_up(v, dd, 64);
-    int ku = __shfl_up(key, dd, 64);
-    if (lane >= dd && ku == key) v += vu;
+    const double tu = __shfl_up(t, dd, 64);
+    const int ku = __shfl_up(kt, dd, 64);
+    if (lane >= dd && ku == kt) t += tu;
   }
-  if (key == ck) v += cv;
-  const int k0 = __shfl(key, 0, 64);
-  if (ck >= 0 && k0 != ck && lane == 0) out[(long long)ck * K] = cv;
-  const int kn = __shfl_down(key, 1, 64);
-  if (lane < 63 && key >= 0 && key != kn) out[(long long)key * K] = v;
-  ck = __shfl(key, 63, 64);
-  cv = __shfl(v, 63, 64);
+  const double tprev = __shfl_up(t, 1, 64);
+  const int kprev = __shfl_up(kt, 1, 64);
+  const double carry = (lane > 0 && kprev == key[0]) ? tprev : 0.0;
+  const int knext = __shfl_down(key[0], 1, 64);
+#pragma unroll
+  for (int i = 0; i < SPL; ++i) {
+    const int kn = (i + 1 < SPL) ? key[i + 1] : ((lane < 63) ? knext : -1);
+    if (key[i] >= 0 && key[i] != kn) out[(long long)key[i] * K] = run[i] + ((key[i] == key[0]) ? carry : 0.0);
+  }
 }
 
 // Periodic kernel, value + all gradients.  With theta_s = 2 pi t_s / p and phi_j = 2 pi z_j / p every sum over spikes the
@@ -66,7 +75,7 @@ __device__ void spike_body_periodic_full(const EngineView& ev, const double* __r
   double cw[SPL], mu[SPL], st[SPL], ct[SPL], stt[SPL], ctt[SPL];
 #pragma unroll
   for (int i = 0; i < SPL; ++i) {
-    int idx = i * 64 + lane;
+    int idx = lane * SPL + i;          // lane owns SPL consecutive spikes
     bool ok = idx < c.count;
     long long gs = c.start + (ok ? idx : 0);
     const double tsc = ev.spk_t[gs] * sc;
@@ -159,7 +168,7 @@ __device__ void spike_body_periodic_full(const EngineView& ev, const double* __r
   int nid[SPL];
 #pragma unroll
   for (int i = 0; i < SPL; ++i) {
-    const int idx = i * 64 + lane;
+    const int idx = lane * SPL + i;
     nid[i] = (idx < c.count) ? ev.spk_n[c.start + idx] : -1;
   }
   if (c.split) {
@@ -170,11 +179,9 @@ __device__ void spike_body_periodic_full(const EngineView& ev, const double* __r
     if (lane == 0) ev.splitPart[(long long)ch * K + k] = p.s2 * tot;
   } else {
     double* out = ev.gCspk + (long long)r * ev.N * K + k;
-    int ck = -1;
-    double cv = 0.0;
 #pragma unroll
-    for (int i = 0; i < SPL; ++i) seg_emit(nid[i], p.s2 * mu[i], ck, cv, out, K, lane);
-    if (ck >= 0 && lane == 0) out[(long long)ck * K] = cv;
+    for (int i = 0; i < SPL; ++i) mu[i] *= p.s2;
+    seg_emit_lane<SPL>(nid, mu, out, K, lane);
   }
 }
 
@@ -220,7 +227,7 @@ __device__ void spike_body(const EngineView& ev, const double* __restrict__ C, i
   int nid[SPL];
 #pragma unroll
   for (int i = 0; i < SPL; ++i) {
-    int idx = i * 64 + lane;
+    int idx = lane * SPL + i;          // lane owns SPL consecutive spikes
     bool ok = idx < c.count;
     long long gs = c.start + (ok ? idx : 0);
     ts[i] = ev.spk_t[gs] * sc;
@@ -326,11 +333,9 @@ __device__ void spike_body(const EngineView& ev, const double* __restrict__ C, i
       if (lane == 0) ev.splitPart[(long long)ch * K + k] = p.s2 * tot;
     } else {
       double* out = ev.gCspk + (long long)r * ev.N * K + k;
-      int ck = -1;
-      double cv = 0.0;
 #pragma unroll
-      for (int i = 0; i < SPL; ++i) seg_emit(nid[i], p.s2 * mu[i], ck, cv, out, K, lane);
-      if (ck >= 0 && lane == 0) out[(long long)ck * K] = cv;
+      for (int i = 0; i < SPL; ++i) mu[i] *= p.s2;
+      seg_emit_lane<SPL>(nid, mu, out, K, lane);
     }
   }
 }
