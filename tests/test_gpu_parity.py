@@ -360,3 +360,34 @@ def test_cfg3_properties():
     _, _, _, gC, gd, _ = eng.split_shared(shared)
     an = float((gd * v).sum())
     assert abs(fd - an) <= 1e-6 * max(1.0, abs(an)), (fd, an)
+
+
+def test_cfg5_properties():
+    """Largest BASELINE configuration (2000 x 500 x 20 x 64, 2.0e7 spikes, M = 64 -> four 16-column panels per item, ELL
+    operands streamed through LDS in chunks): trial additivity of the ELBO and of the shared gradients over two shards,
+    and bit-reproducibility at that size."""
+    prob = synthetic.make_config("cfg5")
+    eng, P = _engine(prob)
+    shared, gm, gc, gz = eng.elbo(P["mean"], P["cholVecs"], P["C"], P["d"], 15)
+    eng.sync()
+    full = shared.cpu().numpy()
+    again, _, _, _ = eng.elbo(P["mean"], P["cholVecs"], P["C"], P["d"], 15)
+    eng.sync()
+    assert torch.equal(shared, again)
+    assert np.isfinite(full).all()
+    eng.close()
+    del eng, P, gm, gc, gz
+    torch.cuda.empty_cache()
+    acc = np.zeros_like(full)
+    for rank in range(2):
+        sh = synthetic.shard_trials(prob, rank, 2)
+        e2, P2 = _engine(sh)
+        s2, _, _, _ = e2.elbo(P2["mean"], P2["cholVecs"], P2["C"], P2["d"], 15)
+        e2.sync()
+        acc += s2.cpu().numpy()
+        e2.close()
+        del e2, P2
+        torch.cuda.empty_cache()
+    assert abs(acc[0] - full[0]) <= 1e-11 * abs(full[0])
+    assert rel_err(acc[3:], full[3:]) < 1e-10
+
