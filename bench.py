@@ -138,6 +138,9 @@ def main():
     ap.add_argument("--variant", default="all", choices=["all", "estep"])
     ap.add_argument("--cpu-sample-trials", type=int, default=200)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="collective backend; gloo + --single-device rehearses the N > 1 path on a one-GPU box")
+    ap.add_argument("--single-device", action="store_true", help="every rank uses cuda:0 (rehearsal only)")
     ap.add_argument("--estep-cache", action="store_true",
                     help="E-step variant only: let value-only evaluations reuse the spike sums while C, Z, theta are "
                          "unchanged (svgpfa_set_embedding_token), as the closure of a real E-step does")
@@ -145,6 +148,7 @@ def main():
 
     import torch
     import torch.distributed as dist
+    from svgpfa_amd.distributed import allreduce_shared
     from svgpfa_amd.engine import engine_from_problem
     from svgpfa_amd.utils import synthetic
 
@@ -153,13 +157,18 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus and rank == 0:
         print(f"[bench] note: --gpus {args.gpus} but WORLD_SIZE={world}; using WORLD_SIZE", file=sys.stderr)
+    if args.single_device:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     use_dist = world > 1 or "RANK" in os.environ      # launched by torch.distributed.run (also with 1 rank)
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
-        dist.init_process_group("nccl", device_id=dev)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group("gloo")
 
     full = synthetic.make_config(args.config)
     prob = synthetic.shard_trials(full, rank, world) if world > 1 else full
@@ -176,7 +185,7 @@ def main():
             eng.build_kernels(P["Z"], P["theta"])
         eng.elbo(P["mean"], P["cholVecs"], P["C"], P["d"], mask, out=shared, grads=grads)
         if use_dist:
-            dist.all_reduce(shared)   # RCCL sum of [ELBO, ELL, KL, dC, dd, dtheta]
+            allreduce_shared(shared)   # RCCL sum of [ELBO, ELL, KL, dC, dd, dtheta]
 
     # one-off initialisation outside the W + K protocol: first launches load the code objects and create the RCCL
     # communicator channels lazily; W warm-up steps then run at steady state even when W is small
@@ -203,7 +212,8 @@ def main():
     elbo = float(shared[0])
 
     if use_dist:
-        t = torch.tensor([elapsed, spike_ms / max(launches, 1)], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed, spike_ms / max(launches, 1)], dtype=torch.float64,
+                         device=dev if args.backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed, spike_avg_ms = float(t[0]), float(t[1])
     else:

@@ -1,0 +1,46 @@
+"""bench.py contract on the GPU: the one-rank line carries the required fields, and the N = 2 launch line of the driver
+(torch.distributed.run, one rank per GPU) is rehearsed with two ranks sharing cuda:0 over gloo: same metric, n_gpus = 2,
+and the all-reduced ELBO equals the one-rank ELBO."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _last_json(text):
+    lines = [l for l in text.splitlines() if l.startswith("{")]
+    assert lines, text[-2000:]
+    return json.loads(lines[-1])
+
+
+def test_bench_lines_one_and_two_ranks():
+    common = ["--config", "cfg2", "--steps", "5", "--warmup", "1"]
+    one = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--cpu-sample-trials", "10"] + common,
+                         capture_output=True, text=True, timeout=600, cwd=REPO)
+    assert one.returncode == 0, one.stderr[-2000:]
+    j1 = _last_json(one.stdout)
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert key in j1, key
+    assert j1["n_gpus"] == 1 and j1["steps"] == 5 and j1["dtype"] == "f64" and j1["vs_baseline"] is None
+    assert set(("bound", "achieved", "peak", "unit", "frac", "traffic")) <= set(j1["roofline"])
+    assert set(("value", "unit", "cores", "kind", "sample")) <= set(j1["cpu_baseline"])
+    assert "workload" in j1["config"] and "model" not in j1["config"]
+
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    two = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                          "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(REPO, "bench.py"),
+                          "--gpus", "2", "--backend", "gloo", "--single-device", "--no-cpu-baseline"] + common,
+                         capture_output=True, text=True, timeout=900, cwd=REPO)
+    assert two.returncode == 0, two.stderr[-2000:]
+    j2 = _last_json(two.stdout)
+    assert j2["n_gpus"] == 2 and j2["metric"] == j1["metric"] and "cpu_baseline" not in j2
+    assert abs(j2["elbo"] - j1["elbo"]) <= 1e-11 * abs(j1["elbo"])
