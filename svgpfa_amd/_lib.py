@@ -66,6 +66,10 @@ def load():
         raise ImportError(
             f"{LIB_PATH} not found: the svGPFA HIP engine is not built. "
             "Run `python __graft_entry__.py` (hipcc --offload-arch=gfx950). There is no CPU fallback.")
+    # The engine works on torch's device memory and streams, so it must share torch's HIP runtime: import torch FIRST.
+    # Loaded the other way round, this library binds the system libamdhip64 and torch then brings its own copy -- two
+    # runtimes in one process, and the first one reports "no ROCm-capable device".
+    import torch  # noqa: F401
     lib = ctypes.CDLL(LIB_PATH)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)  # AttributeError if the symbol is absent
