@@ -44,3 +44,12 @@ def test_bench_lines_one_and_two_ranks():
     j2 = _last_json(two.stdout)
     assert j2["n_gpus"] == 2 and j2["metric"] == j1["metric"] and "cpu_baseline" not in j2
     assert abs(j2["elbo"] - j1["elbo"]) <= 1e-11 * abs(j1["elbo"])
+
+
+def test_graft_entry_smoke_in_a_fresh_interpreter():
+    """The driver's entry point exactly as it calls it: build() then smoke() in a new process (this is the path where
+    the HIP library could be loaded before torch)."""
+    run = subprocess.run([sys.executable, "-c", "import __graft_entry__ as g; g.build(); g.smoke()"],
+                         capture_output=True, text=True, timeout=900, cwd=REPO)
+    assert run.returncode == 0, (run.stdout[-1000:], run.stderr[-2000:])
+    assert "smoke ok" in run.stdout
