@@ -1,6 +1,7 @@
 """Model factory with the reference's constants and call signature
-(/root/reference/src/svGPFA/stats/svGPFAModelFactory.py:11-148).  Only the default option set is
-accelerated (point process / exponential link / linear embedding / Cholesky Kzz / Cholesky q(u));
+(/root/reference/src/svGPFA/stats/svGPFAModelFactory.py:11-148).  The default option set is accelerated
+(point process / exponential link / linear embedding / Cholesky Kzz), with q(u) covariances either as Cholesky
+vectors (default) or in the reference's rank-1 + diagonal form (converted on the GPU, autograd-transparent);
 the other switches raise, exactly where the reference raises or builds an unusable object."""
 from . import svLowerBound
 
@@ -39,10 +40,10 @@ class SVGPFAModelFactory:
             raise ValueError("Invalid embeddingType={:s}".format(repr(embeddingType)))
         if linkFunction != ExponentialLink:
             raise ValueError("Invalid linkFunction={:s}".format(repr(linkFunction)))
-        if indPointsCovRep != indPointsCovChol:
-            raise ValueError("Invalid indPointsCovRep (HIP engine: indPointsCovChol only)")
+        if indPointsCovRep not in (indPointsCovChol, indPointsCovRank1PlusDiag):
+            raise ValueError("Invalid indPointsCovRep")
         if kernelMatrixInvMethod != kernelMatrixInvChol:
             raise ValueError("Invalid kernelMatrixInvMethod (HIP engine: kernelMatrixInvChol only)")
-        model = svLowerBound.SVLowerBound(device=device)
+        model = svLowerBound.SVLowerBound(device=device, rank1_plus_diag=(indPointsCovRep == indPointsCovRank1PlusDiag))
         model.setKernels(kernels=kernels)
         return model

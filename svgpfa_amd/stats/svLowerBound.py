@@ -49,7 +49,9 @@ class _ELBOFunction(torch.autograd.Function):
         # content id of C: torch bumps _version on every in-place update (optimiser steps), a new tensor has a new address
         C = model._C
         eng.set_embedding_token((hash((C.data_ptr(), C._version)) & 0x7FFFFFFFFFFFFFFF) | 1)
-        shared, gm, gc, gz = eng.elbo(model._mean, model._cholVecs, model._C, model._d, mask)
+        mean_t = [p.detach() for p in params[0:K]]
+        chol_t = [p.detach().contiguous() for p in params[K:2 * K]]
+        shared, gm, gc, gz = eng.elbo(mean_t, chol_t, model._C, model._d, mask)
         model._sync()
         if model._reduce is not None:      # trials sharded over ranks: ONE all-reduce of the shared vector
             model._reduce(shared)
@@ -112,12 +114,16 @@ class _ELLGivenStatsFunction(torch.autograd.Function):
 
 class SVLowerBound:
 
-    def __init__(self, device=None):
+    def __init__(self, device=None, rank1_plus_diag=False):
         if not torch.cuda.is_available():
             raise RuntimeError("svgpfa_amd.stats.SVLowerBound needs a ROCm GPU; there is no CPU fallback")
         self._device = torch.device("cuda", torch.cuda.current_device() if device is None else device)
         self._engine = None
         self._engine_key = None
+        # q(u) covariance representation: Cholesky vectors (default) or S = q q^T + diag(d^2)
+        # (reference svPosteriorOnIndPoints.py:86-119, factory switch indPointsCovRank1PlusDiag)
+        self._rank1 = bool(rank1_plus_diag)
+        self._qSVec = self._qSDiag = None
         self._kernels = None
         self._reg = None
         self._quad = None
@@ -166,7 +172,12 @@ class SVLowerBound:
         emb = initial_params["embedding"]
         dev = self._device
         self._mean = [_to_dev(t, dev) for t in qU["mean"]]
-        self._cholVecs = [_to_dev(t, dev) for t in qU["cholVecs"]]
+        if self._rank1:
+            self._qSVec = [_to_dev(t, dev) for t in qU["qSVec0"]]
+            self._qSDiag = [_to_dev(t, dev) for t in qU["qSDiag0"]]
+            self._cholVecs = None
+        else:
+            self._cholVecs = [_to_dev(t, dev) for t in qU["cholVecs"]]
         self._Z = [_to_dev(t, dev) for t in kms["inducing_points_locs0"]]
         theta = [_to_dev(t, dev) for t in kms["kernels_params0"]]
         for k, kern in enumerate(self._kernels):
@@ -189,7 +200,24 @@ class SVLowerBound:
 
     # ----------------------------------------------------------------- getters (svLowerBound.py:101-120)
     def getSVPosteriorOnIndPointsParams(self):
+        if self._rank1:                                             # svPosteriorOnIndPoints.py:93-100
+            return list(self._mean) + list(self._qSVec) + list(self._qSDiag)
         return list(self._mean) + list(self._cholVecs)          # svPosteriorOnIndPoints.py:37-42
+
+    def _chol_vecs(self):
+        """Cholesky vectors the engine consumes.  Rank-1 + diagonal representation: S = q q^T + diag(d^2)
+        (svPosteriorOnIndPoints.py:104-119), factorised by torch on the GPU; the result stays attached to the autograd
+        graph, so the engine's gradient wrt the Cholesky vectors flows on to qSVec / qSDiag."""
+        if not self._rank1:
+            return self._cholVecs
+        out = []
+        for q, d in zip(self._qSVec, self._qSDiag):
+            S = q @ q.transpose(1, 2) + torch.diag_embed(d[:, :, 0] ** 2)
+            L = torch.linalg.cholesky(S)
+            M = L.shape[1]
+            idx = torch.tril_indices(M, M, device=L.device)
+            out.append(L[:, idx[0], idx[1]].unsqueeze(-1).contiguous())
+        return out
 
     def getSVEmbeddingParams(self):
         return [self._C, self._d]
@@ -262,8 +290,9 @@ class SVLowerBound:
         """svLowerBound.py:47-54."""
         if self._engine is None:
             self.buildKernelsMatrices()
-        self._check_live(self._mean + self._cholVecs + [self._C, self._d], "variational / embedding")
-        theEval = _ELBOFunction.apply(self, *self._mean, *self._cholVecs, self._C, self._d,
+        chol = self._chol_vecs()
+        self._check_live(self._mean + [c.detach() for c in chol] + [self._C, self._d], "variational / embedding")
+        theEval = _ELBOFunction.apply(self, *self._mean, *chol, self._C, self._d,
                                       *self._theta(), *self._Z)
         if torch.isinf(theEval):
             warnings.warn("infinity lower bound detected")
@@ -274,7 +303,7 @@ class SVLowerBound:
         resident for evalELLSumAcrossTrialsAndNeurons."""
         if self._engine is None:
             self.buildKernelsMatrices()
-        muq, varq, mus, vars_ = self._engine.latent_stats(self._mean, self._cholVecs)
+        muq, varq, mus, vars_ = self._engine.latent_stats(self._mean, [c.detach() for c in self._chol_vecs()])
         self._sync()
         off = self._spikes[0]
         R = len(off) - 1
@@ -298,7 +327,8 @@ class SVLowerBound:
         if self._engine is None:
             self.buildKernelsMatrices()
         t = _to_dev(times, self._device)
-        mu, var = self._engine.predict(self._mean, self._cholVecs, t.reshape(t.shape[0], -1).contiguous())
+        mu, var = self._engine.predict(self._mean, [c.detach() for c in self._chol_vecs()],
+                                       t.reshape(t.shape[0], -1).contiguous())
         self._sync()
         self._stats_token = None
         return mu, var

@@ -25,6 +25,9 @@ What is written (all float64 numpy arrays, inputs AND reference outputs):
                       ragged case.
   em_small.npz      - the reference's own SVEM_PyTorch.maximize (ECM, 2 iterations) on a small
                       seeded problem: lowerBoundHist and final shared parameters.
+  rank1_small.npz   - the rank-1 + diagonal representation of the variational covariances
+                      (indPointsCovRep = indPointsCovRank1PlusDiag, stats/svPosteriorOnIndPoints.py:86-119)
+                      on the ragged case: ELBO / ELL / KL and gradients wrt mean, qSVec, qSDiag.
   cfg1_bundled.npz  - BASELINE config 1: the bundled simulated data
                       (examples/data/32451751_simRes.pickle: spike times only, as CSR) with the
                       parameters of examples/params/00000545_estimation_metaData.ini, and the
@@ -365,11 +368,69 @@ def cfg1_bundled():
                         lowerBoundHist=np.array(hist))
 
 
+def rank1_small():
+    """Non-default q(u) covariance: S = q q^T + diag(d^2) (svPosteriorOnIndPoints.py:104-119)."""
+    prob = ragged_problem()
+    rng = np.random.default_rng(5)
+    K, R, N = prob["K"], prob["R"], prob["N"]
+    qSVec = [0.3 * rng.standard_normal((R, M)) for M in prob["Ms"]]
+    qSDiag = [0.2 + 0.1 * rng.random((R, M)) for M in prob["Ms"]]
+    model0, params = ref_model_from_problem(prob)          # for kernels / measurements plumbing
+    t = lambda a: torch.from_numpy(np.array(a, dtype=np.float64, copy=True, order="C"))
+    qv = [t(a).unsqueeze(-1) for a in qSVec]
+    qd = [t(a).unsqueeze(-1) for a in qSDiag]
+    scales = prob.get("scales", [1.0] * K)
+    lss = prob.get("lengthscale_scales", [1.0] * K)
+    pss = prob.get("period_scales", [1.0] * K)
+    kernels = []
+    for k in range(K):
+        if prob["kernel_types"][k] == synthetic.RBF:
+            kernels.append(svGPFA.stats.kernels.ExponentialQuadraticKernel(scale=scales[k], lengthscaleScale=lss[k]))
+        else:
+            kernels.append(svGPFA.stats.kernels.PeriodicKernel(scale=scales[k], lengthscaleScale=lss[k],
+                                                               periodScale=pss[k]))
+    off, times, neuron = prob["spike_offsets"], prob["spike_times"], prob["spike_neuron"]
+    measurements = []
+    for r in range(R):
+        tr_t, tr_n = times[off[r]:off[r + 1]], neuron[off[r]:off[r + 1]]
+        measurements.append([t(tr_t[tr_n == n]) for n in range(N)])
+    initial_params = {
+        "posterior_on_latents": {
+            "posterior_on_ind_points": {"mean": params["mean"], "qSVec0": qv, "qSDiag0": qd},
+            "kernels_matrices_store": {"kernels_params0": params["theta"], "inducing_points_locs0": params["Z"]}},
+        "embedding": {"C0": params["C"], "d0": params["d"]}}
+    ell_params = {"leg_quad_points": t(prob["quad_points"]).unsqueeze(-1),
+                  "leg_quad_weights": t(prob["quad_weights"]).unsqueeze(-1)}
+    F = svGPFA.stats.svGPFAModelFactory
+    model = F.SVGPFAModelFactory.buildModelPyTorch(kernels=kernels, indPointsCovRep=F.indPointsCovRank1PlusDiag)
+    model.setParamsAndData(measurements=measurements, initial_params=initial_params,
+                           eLLCalculationParams=ell_params, priorCovRegParam=prob["reg"])
+    leaves = params["mean"] + qv + qd
+    for x in leaves:
+        x.requires_grad_(True)
+    model.buildKernelsMatrices()
+    ell = model._eLL.evalSumAcrossTrialsAndNeurons()
+    kl = model._klDiv.evalSumAcrossLatentsAndTrials()
+    elbo = model.eval()
+    grads = torch.autograd.grad(elbo, leaves)
+    out = {"ref_elbo": float(elbo), "ref_ell": float(ell), "ref_kl": float(kl)}
+    names = [f"g_mean_{k}" for k in range(K)] + [f"g_qSVec_{k}" for k in range(K)] + [f"g_qSDiag_{k}" for k in range(K)]
+    for nme, g in zip(names, grads):
+        out[nme] = g.detach().numpy()[:, :, 0]
+    for k in range(K):
+        out[f"qSVec_{k}"], out[f"qSDiag_{k}"] = qSVec[k], qSDiag[k]
+    print("rank1: ref elbo %.10f ell %.10f kl %.10f" % (out["ref_elbo"], out["ref_ell"], out["ref_kl"]))
+    np.savez_compressed(os.path.join(HERE, "rank1_small.npz"), **problem_inputs(prob), **out)
+
+
 if __name__ == "__main__":
-    if len(sys.argv) > 1 and sys.argv[1] == "em":
+    if len(sys.argv) > 1 and sys.argv[1] == "rank1":
+        rank1_small()
+    elif len(sys.argv) > 1 and sys.argv[1] == "em":
         em_small()
         cfg1_bundled()
     else:
         main()
         em_small()
         cfg1_bundled()
+        rank1_small()

@@ -186,3 +186,53 @@ def test_pickle_roundtrip():
     model2 = pickle.loads(pickle.dumps({"model": model}))["model"]
     assert model2._engine is None
     assert float(model2.eval()) == v0
+
+
+def test_rank1_plus_diag_variational_covariance():
+    """Factory switch indPointsCovRank1PlusDiag (stats/svGPFAModelFactory.py:65-67, svPosteriorOnIndPoints.py:86-119):
+    q(u) covariances as q q^T + diag(d^2); value and gradients wrt mean, qSVec, qSDiag against the reference."""
+    from svgpfa_amd.stats import svGPFAModelFactory as F
+    from helpers import build_kernels
+    prob, ref = load_golden("rank1_small")
+    K, R, N = prob["K"], prob["R"], prob["N"]
+    t = lambda a: torch.from_numpy(np.array(a, dtype=np.float64, copy=True, order="C"))
+    off, times, neuron = prob["spike_offsets"], prob["spike_times"], prob["spike_neuron"]
+    measurements = []
+    for r in range(R):
+        tt, nn = times[off[r]:off[r + 1]], neuron[off[r]:off[r + 1]]
+        measurements.append([t(tt[nn == n]) for n in range(N)])
+    initial_params = {
+        "posterior_on_latents": {
+            "posterior_on_ind_points": {"mean": [t(a).unsqueeze(-1) for a in prob["mean"]],
+                                        "qSVec0": [t(ref[f"qSVec_{k}"]).unsqueeze(-1) for k in range(K)],
+                                        "qSDiag0": [t(ref[f"qSDiag_{k}"]).unsqueeze(-1) for k in range(K)]},
+            "kernels_matrices_store": {"kernels_params0": [t(a) for a in prob["theta"]],
+                                       "inducing_points_locs0": [t(a).unsqueeze(-1) for a in prob["Z"]]}},
+        "embedding": {"C0": t(prob["C"]), "d0": t(prob["d"])}}
+    ell = {"leg_quad_points": t(prob["quad_points"]).unsqueeze(-1),
+           "leg_quad_weights": t(prob["quad_weights"]).unsqueeze(-1)}
+    model = F.SVGPFAModelFactory.buildModelPyTorch(kernels=build_kernels(prob), indPointsCovRep=F.indPointsCovRank1PlusDiag)
+    model.setParamsAndData(measurements=measurements, initial_params=initial_params, eLLCalculationParams=ell,
+                           priorCovRegParam=prob["reg"])
+    x = model.getSVPosteriorOnIndPointsParams()
+    assert len(x) == 3 * K
+    for p in x:
+        p.requires_grad_(True)
+    val = model.eval()
+    assert abs(float(val) - float(ref["ref_elbo"])) < 1e-9 * abs(float(ref["ref_elbo"]))
+    _, ell_v, kl_v = model.lastTerms()
+    assert abs(float(ell_v) - float(ref["ref_ell"])) < 1e-9 * abs(float(ref["ref_ell"]))
+    assert abs(float(kl_v) - float(ref["ref_kl"])) < 1e-9 * abs(float(ref["ref_kl"]))
+    val.backward()
+    names = [f"g_mean_{k}" for k in range(K)] + [f"g_qSVec_{k}" for k in range(K)] + [f"g_qSDiag_{k}" for k in range(K)]
+    for p, nme in zip(x, names):
+        assert p.grad is not None
+        assert rel_err(p.grad.cpu().numpy()[:, :, 0], ref[nme]) < 1e-8, (nme, rel_err(p.grad.cpu().numpy()[:, :, 0], ref[nme]))
+    # the E-step of the EM loop runs on this representation too
+    from svgpfa_amd.stats.svEM import SVEM_PyTorch
+    for p in x:
+        p.requires_grad_(False)
+    before = float(model.eval())
+    res = SVEM_PyTorch()._eStep(model=model, optim_params=dict(max_iter=5, lr=1.0, tolerance_grad=1e-7,
+                                                                tolerance_change=1e-9, line_search_fn="strong_wolfe"))
+    assert float(res["lowerBound"]) > before

@@ -109,3 +109,22 @@ def test_predict_latents(golden_dir):
     mu, var = orc.predict_latents(p, torch.from_numpy(ref["times"]).unsqueeze(-1))
     assert rel_err(mu.numpy(), ref["mu"]) < TOL_ARRAY
     assert rel_err(var.numpy(), ref["var"]) < TOL_ARRAY
+
+
+def test_rank1_plus_diag_covariance():
+    """q(u) covariance S = q q^T + diag(d^2) (reference svPosteriorOnIndPoints.py:104-119): the oracle fed with the
+    Cholesky vectors of that S reproduces the reference's ELBO / ELL / KL for the rank-1 + diagonal model."""
+    prob, ref = load_golden("rank1_small")
+    K = prob["K"]
+    chol = []
+    for k in range(K):
+        q, d = ref[f"qSVec_{k}"], ref[f"qSDiag_{k}"]
+        S = q[:, :, None] * q[:, None, :] + np.stack([np.diag(x ** 2) for x in d])
+        L = np.linalg.cholesky(S)
+        i, j = np.tril_indices(L.shape[-1])
+        chol.append(np.ascontiguousarray(L[:, i, j]))
+    prob["cholVecs"] = chol
+    elbo, ell, kl = orc.elbo_terms(orc.from_numpy_problem(prob))
+    assert abs(float(elbo) - float(ref["ref_elbo"])) <= 1e-10 * abs(float(ref["ref_elbo"]))
+    assert abs(float(ell) - float(ref["ref_ell"])) <= 1e-10 * abs(float(ref["ref_ell"]))
+    assert abs(float(kl) - float(ref["ref_kl"])) <= 1e-10 * abs(float(ref["ref_kl"]))
