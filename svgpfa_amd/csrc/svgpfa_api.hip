@@ -47,9 +47,12 @@ struct svgpfa_engine {
   // shorter grid tails; cfg3 +3 %).  The spike pass keeps one launch per type above merge_spike_blocks (the merged
   // kernel carries the periodic type's VGPR count) and is merged, longest items first, below it.
   long long merge_spike_blocks = 8192;          // SVGPFA_MERGE_SPIKE_BLOCKS
-  // SVGPFA_OVERLAP=1: spike pass on a side stream beside the quadrature chain.  Measured on MI355X / ROCm 7.2: SLOWER
-  // than one stream at every size (cfg3 1.81 vs 1.51 ms, 8-way shard 0.41 vs 0.27 ms), so it is opt-in only.
-  int side_stream = 0;
+  // Spike pass on a side stream beside the quadrature chain (two cross-stream edges: prep -> spike, spike -> bwd).
+  // Measured with the current kernels (cfg3, ms per evaluation, one stream -> side stream): 1-way 1.219 -> 1.183,
+  // 2-way 0.664 -> 0.648, 4-way 0.384 -> 0.355, 8-way 0.236 -> 0.230.  Default (-1): on for small shards
+  // (R K <= 2048), where every launch under-fills the chip; at full size one stream is kept so that the spike pass
+  // runs alone and its hipEvent duration is comparable with the roofline.  SVGPFA_OVERLAP=0 / 1 forces it off / on.
+  int side_stream = -1;
   hipStream_t s_side = nullptr;
   hipEvent_t ev_prep = nullptr, ev_spk = nullptr;
   int spl = SV_SPL;                             // spikes per lane of the spike pass: 8, or 4 below small_spike_waves
@@ -257,7 +260,7 @@ int svgpfa_create(const svgpfa_dims* d, int device, svgpfa_engine** out) {
   HIPCHK(e, hipStreamCreateWithFlags(&e->s_side, hipStreamNonBlocking));
   {
     const char* ov = getenv("SVGPFA_OVERLAP");
-    if (ov) e->side_stream = atoi(ov) != 0;
+    if (ov) e->side_stream = atoi(ov) != 0 ? 1 : 0;
     const char* ms = getenv("SVGPFA_MERGE_SPIKE_BLOCKS");
     if (ms) e->merge_spike_blocks = atoll(ms);
     const char* sw = getenv("SVGPFA_SMALL_SPIKE_WAVES");
@@ -551,7 +554,8 @@ int svgpfa_elbo(svgpfa_engine* e, const double* const* mean, const double* const
 
   launch_prep(e, pt);
   hipStream_t sm = e->stream;
-  const bool side = e->side_stream && v.nchunks > 0;     // opt-in: spike pass beside the quadrature chain
+  const bool side = v.nchunks > 0 &&
+                    (e->side_stream == 1 || (e->side_stream < 0 && (long long)v.R * v.K <= 2048));
   hipStream_t sk = side ? e->s_side : sm;
   if (side) {
     HIPCHK(e, hipEventRecord(e->ev_prep, sm));

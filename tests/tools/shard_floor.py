@@ -6,8 +6,11 @@ import torch
 from svgpfa_amd.engine import engine_from_problem
 from svgpfa_amd.utils import synthetic
 full = synthetic.make_config("cfg3")
-for world, mode in [(w, m) for w in (1, 2, 4, 8) for m in ("0", "1")]:
-    os.environ["SVGPFA_OVERLAP"] = mode
+for world, mode in [(w, m) for w in (1, 2, 4, 8) for m in ("0", "1", "auto")]:
+    if mode == "auto":
+        os.environ.pop("SVGPFA_OVERLAP", None)
+    else:
+        os.environ["SVGPFA_OVERLAP"] = mode
     prob = synthetic.shard_trials(full, 0, world)
     eng, P = engine_from_problem(prob)
     shared = torch.empty(eng.shared_len, dtype=torch.float64, device=eng.device)
