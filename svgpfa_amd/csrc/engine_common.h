@@ -25,7 +25,7 @@
 #define SV_MAX_M 64
 #define SV_MAX_K 32
 
-#define SV_SPL 8                      // spikes per lane in the spike pass (4 on small shards, engine::spl)
+#define SV_SPL 8                      // spikes per lane in the spike pass (optionally 4, engine::spl)
 #define SV_SPIKE_CHUNK (64 * SV_SPL)  // largest number of spikes per wavefront work item
 
 struct LatentMeta {

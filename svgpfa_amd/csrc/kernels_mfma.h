@@ -955,8 +955,8 @@ __device__ __forceinline__ void quad_ell_mfma_body(const EngineView& ev, const d
   }
 }
 
-// ROLE 0 / 1: one role per launch.  ROLE 2: both roles in one launch (blocks [0, nb) role 0, [nb, 2 nb) role 1) for
-// small shards, where each launch is latency- rather than throughput-bound.
+// ROLE 0: dC / dd / ELL only (no latent-side gradient wanted).  ROLE 2: both roles in one launch (blocks [0, nb) role 0,
+// [nb, 2 nb) role 1): measured faster than two launches at every size.
 template <int KS, int ROLE>
 __global__ __launch_bounds__(512) void k_quad_ell_mfma(EngineView ev, const double* C, const double* d,
                                                        int want_sums, int write_ell, int parts, int lc0, int lc1) {

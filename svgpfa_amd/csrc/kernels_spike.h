@@ -1,6 +1,6 @@
 // Spike-time pass: the dominant kernel (sum_k R M_k S_r kernel evaluations per ELBO).
 //
-// One wavefront per (spike chunk, latent).  Each lane owns SPL (= 8, or 4 on small shards) spikes of the chunk (times and
+// One wavefront per (spike chunk, latent).  Each lane owns SPL (= 8) consecutive spikes of the chunk (times and
 // embedding weights c_s = C[n_s, k] in registers); the inducing points z_j and a_j = (Kzz^-1 m)_j
 // are wave-uniform.  For the exponential link the spike term of the ELL needs only the posterior
 // MEAN, whose adjoint is known a priori (d ELL / d mu_k(t_s) = C[n_s, k]), so value and all

@@ -355,7 +355,7 @@ int svgpfa_set_spikes(svgpfa_engine* e, const int64_t* off, const double* times,
   if (S > 0 && (!times || !neuron)) return SVGPFA_ERR_INVALID;
   if (S > 2000000000LL) FAIL(e, SVGPFA_ERR_UNSUPPORTED, "more than 2e9 spikes on one GPU");
   v.S = (int)S;
-  // granularity of the spike pass: a small shard gets half-size chunks so that its waves still fill the chip evenly
+  // granularity of the spike pass: optional half-size chunks for small shards (off by default: measured slower)
   e->spl = ((S + 459) / 460) * v.K < e->small_spike_waves ? 4 : 8;
   const long long CHUNK = 64LL * e->spl;
   std::vector<int32_t> nh((size_t)S);
