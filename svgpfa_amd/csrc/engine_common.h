@@ -21,7 +21,6 @@
 
 #define SV_RBF 0
 #define SV_PERIODIC 1
-#define SV_ANYTYPE 2   // spike pass: one launch over all latents, type resolved per block
 #define SV_MAX_M 64
 #define SV_MAX_K 32
 

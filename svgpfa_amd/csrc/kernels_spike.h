@@ -340,30 +340,24 @@ __device__ void spike_body(const EngineView& ev, const double* __restrict__ C, i
   }
 }
 
-// KT = SV_RBF / SV_PERIODIC: one launch per covariance type; KT = 2 (any): type resolved per block (small shards).
-template <int KT, bool FULL, int SPL>
+// One launch over all (chunk, latent) work items; the covariance type is resolved per block.  Longest jobs first: all
+// periodic items, then the RBF ones, so that the tail of the grid is filled with the shorter work items (a small shard
+// is only 2-3 occupancy rounds long).  Registers are capped so that 3 waves / SIMD stay resident.
+template <bool FULL, int SPL>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 8))) void k_spike(EngineView ev,
                                                                                          const double* __restrict__ C) {
-  // LDS bounds the waves per CU: RBF full 3 x 8 rows + 3 x 64 (14.0 KB), periodic full 5 x 6 rows + 5 x 64 + 30 (18.4 KB,
-  // VGPR-limited to 2 waves / SIMD anyway), value-only 8 rows
+  // LDS bounds the waves per CU: RBF full 3 x 8 rows + 3 x 64 (14.0 KB), periodic full 5 x 4 rows + 5 x 64 + 32 (13.2 KB),
+  // value-only 8 rows
   constexpr int LDS_RBF = 3 * SV_SPIKE_JG * 65 + 3 * 64, LDS_PER = 5 * 4 * 65 + 5 * 64 + 32;
-  __shared__ double red[FULL ? (KT == SV_RBF ? LDS_RBF : LDS_PER) : SV_SPIKE_JG * 65 + 3 * 64];
+  __shared__ double red[FULL ? (LDS_RBF > LDS_PER ? LDS_RBF : LDS_PER) : SV_SPIKE_JG * 65 + 3 * 64];
   const int item = blockIdx.x;
-  if (KT == 2) {
-    // longest jobs first: all periodic (chunk, latent) items, then the RBF ones, so that the tail of the grid is
-    // filled with the shorter work items (a small shard is only 2-3 occupancy rounds long)
-    const int nper = ev.ntype[SV_PERIODIC], nrbf = ev.ntype[SV_RBF];
-    const int nb_per = ev.nchunks * nper;
-    if (item < nb_per) {
-      spike_body<SV_PERIODIC, FULL, SPL>(ev, C, item / nper, ev.klist[SV_PERIODIC][item % nper], red);
-    } else {
-      const int it = item - nb_per;
-      spike_body<SV_RBF, FULL, SPL>(ev, C, it / nrbf, ev.klist[SV_RBF][it % nrbf], red);
-    }
+  const int nper = ev.ntype[SV_PERIODIC], nrbf = ev.ntype[SV_RBF];
+  const int nb_per = ev.nchunks * nper;
+  if (item < nb_per) {
+    spike_body<SV_PERIODIC, FULL, SPL>(ev, C, item / nper, ev.klist[SV_PERIODIC][item % nper], red);
   } else {
-    const int nk = ev.ntype[KT == 2 ? 0 : KT];
-    const int ch = item / nk, k = ev.klist[KT == 2 ? 0 : KT][item % nk];
-    spike_body<(KT == 2 ? SV_RBF : KT), FULL, SPL>(ev, C, ch, k, red);
+    const int it = item - nb_per;
+    spike_body<SV_RBF, FULL, SPL>(ev, C, it / nrbf, ev.klist[SV_RBF][it % nrbf], red);
   }
 }
 

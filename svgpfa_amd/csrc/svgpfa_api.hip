@@ -42,11 +42,10 @@ struct svgpfa_engine {
   size_t ev_used = 0;
   std::string err;
   int* status_host = nullptr;  // pinned
-  // Launch strategy.  The per-item kernels (times / ELL roles / quad_bwd / bwd) are launched ONCE over all latents with
-  // the covariance type resolved per block (measured faster than one launch per type at every size: fewer launches,
-  // shorter grid tails; cfg3 +3 %).  The spike pass keeps one launch per type above merge_spike_blocks (the merged
-  // kernel carries the periodic type's VGPR count) and is merged, longest items first, below it.
-  long long merge_spike_blocks = 8192;          // SVGPFA_MERGE_SPIKE_BLOCKS
+  // Launch strategy.  Every kernel is launched ONCE over all latents with the covariance type resolved per block
+  // (wave-uniform branch): measured faster than one launch per type for the per-item kernels (+3 % on cfg3: fewer
+  // launches, shorter grid tails) and, since both types of the spike pass fit 3 waves / SIMD, for the spike pass too
+  // (+1.5 %; its grid lists the longer periodic work items first).
   // Spike pass on a side stream beside the quadrature chain (two cross-stream edges: prep -> spike, spike -> bwd).
   // Measured with the current kernels (cfg3, ms per evaluation, one stream -> side stream): 1-way 1.219 -> 1.183,
   // 2-way 0.664 -> 0.648, 4-way 0.384 -> 0.355, 8-way 0.236 -> 0.230.  Default (-1): on for small shards
@@ -141,18 +140,6 @@ __global__ __launch_bounds__(64 * NT) void k_bwd_mfma(EngineView ev, PtrTable pt
   else
     bwd_mfma_body<NT, SV_PERIODIC>(ev, r, k, pt.p[k], mask, sm);
 }
-// Spike pass over covariance types.  merged = true: ONE launch with KT_ = SV_ANYTYPE over all latents (NKT_ = K);
-// merged = false: one launch per type that has latents (NKT_ = that type's latent count).
-#define FOR_TYPES(e, merged, ST, ...)                                                                         \
-  do {                                                                                                        \
-    hipStream_t ST_ = (ST);                                                                                   \
-    if (merged) {                                                                                             \
-      constexpr int KT_ = SV_ANYTYPE; const int NKT_ = (e)->v.K; __VA_ARGS__;                                  \
-    } else {                                                                                                  \
-      if ((e)->v.ntype[0] > 0) { constexpr int KT_ = SV_RBF; const int NKT_ = (e)->v.ntype[0]; __VA_ARGS__; }       \
-      if ((e)->v.ntype[1] > 0) { constexpr int KT_ = SV_PERIODIC; const int NKT_ = (e)->v.ntype[1]; __VA_ARGS__; }  \
-    }                                                                                                         \
-  } while (0)
 static size_t lds_prep_mfma(int NT) {
   size_t MP = 16 * NT, LD = MP + 2;
   return (2 * MP * LD + NT) * 8;
@@ -261,8 +248,6 @@ int svgpfa_create(const svgpfa_dims* d, int device, svgpfa_engine** out) {
   {
     const char* ov = getenv("SVGPFA_OVERLAP");
     if (ov) e->side_stream = atoi(ov) != 0 ? 1 : 0;
-    const char* ms = getenv("SVGPFA_MERGE_SPIKE_BLOCKS");
-    if (ms) e->merge_spike_blocks = atoll(ms);
     const char* sw = getenv("SVGPFA_SMALL_SPIKE_WAVES");
     if (sw) e->small_spike_waves = atoll(sw);
   }
@@ -579,17 +564,13 @@ int svgpfa_elbo(svgpfa_engine* e, const double* const* mean, const double* const
       evp = &e->ev_pool[e->ev_used++];
       HIPCHK(e, hipEventRecord(evp->first, sk));
     }
-    const bool mspk = (long long)v.nchunks * v.K * e->spl / 8 <= e->merge_spike_blocks;
+    const dim3 gs(v.nchunks * v.K), bs(64);
     if (e->spl == 4) {
-      if (full) {
-        FOR_TYPES(e, mspk, sk, hipLaunchKernelGGL((k_spike<KT_, true, 4>), dim3(v.nchunks * NKT_), dim3(64), 0, ST_, v, C));
-      } else {
-        FOR_TYPES(e, mspk, sk, hipLaunchKernelGGL((k_spike<KT_, false, 4>), dim3(v.nchunks * NKT_), dim3(64), 0, ST_, v, C));
-      }
-    } else if (full) {
-      FOR_TYPES(e, mspk, sk, hipLaunchKernelGGL((k_spike<KT_, true, 8>), dim3(v.nchunks * NKT_), dim3(64), 0, ST_, v, C));
+      if (full) hipLaunchKernelGGL((k_spike<true, 4>), gs, bs, 0, sk, v, C);
+      else hipLaunchKernelGGL((k_spike<false, 4>), gs, bs, 0, sk, v, C);
     } else {
-      FOR_TYPES(e, mspk, sk, hipLaunchKernelGGL((k_spike<KT_, false, 8>), dim3(v.nchunks * NKT_), dim3(64), 0, ST_, v, C));
+      if (full) hipLaunchKernelGGL((k_spike<true, 8>), gs, bs, 0, sk, v, C);
+      else hipLaunchKernelGGL((k_spike<false, 8>), gs, bs, 0, sk, v, C);
     }
     if (evp) HIPCHK(e, hipEventRecord(evp->second, sk));
     if (side) HIPCHK(e, hipEventRecord(e->ev_spk, sk));

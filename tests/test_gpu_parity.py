@@ -162,15 +162,12 @@ def test_not_positive_definite_raises():
 
 
 def test_launch_strategies_agree(monkeypatch):
-    """One spike launch per covariance type (full-size strategy), the merged spike launch (small-shard strategy) and
-    the opt-in side-stream variant must give the same numbers (fixed-order reductions: bit-identical)."""
+    """One stream and the side-stream variant of the spike pass must give the same numbers (fixed-order reductions:
+    bit-identical)."""
     prob = synthetic.make_problem(R=5, N=12, K=4, M=[10, 12, 9, 16], kernels="mix", seed=13, n_quad=60, rate=25.0, jitter=1.0)
     outs = []
-    for env in ({"SVGPFA_MERGE_SPIKE_BLOCKS": "0", "SVGPFA_OVERLAP": "0"},
-                {"SVGPFA_MERGE_SPIKE_BLOCKS": "1000000", "SVGPFA_OVERLAP": "0"},
-                {"SVGPFA_OVERLAP": "1"}, {"SVGPFA_OVERLAP": "1", "SVGPFA_MERGE_SPIKE_BLOCKS": "0"}, {}):
-        for k in ("SVGPFA_MERGE_SPIKE_BLOCKS", "SVGPFA_OVERLAP"):
-            monkeypatch.delenv(k, raising=False)
+    for env in ({"SVGPFA_OVERLAP": "0"}, {"SVGPFA_OVERLAP": "1"}, {}):
+        monkeypatch.delenv("SVGPFA_OVERLAP", raising=False)
         for k, v in env.items():
             monkeypatch.setenv(k, v)
         eng, P = _engine(prob)
