@@ -119,13 +119,15 @@ def measured_traffic(config, variant, full_mask):
         if d.get("config") != config or d.get("variant") != variant:
             continue
         tot, n = 0.0, 0     # the spike pass of one evaluation = the k_spike launches of all covariance types
+        insts = 0.0
         for k, e in d.get("kernels", {}).items():
-            if k.startswith("k_spike<") and k.endswith("true>" if full_mask else "false>") \
+            if k.startswith("k_spike<") and (("true" in k) == bool(full_mask)) \
                     and "hbm_read_bytes_raw" in e and "hbm_write_bytes" in e:
                 tot += e["hbm_read_bytes_raw"] + e["hbm_write_bytes"]
+                insts += e.get("SQ_INSTS_VALU", 0.0)
                 n += 1
         if n:
-            best = (tot, os.path.basename(f))
+            best = (tot, os.path.basename(f), insts)
     return best
 
 
@@ -248,7 +250,16 @@ def main():
                          "kernel_avg_ms": spike_avg_ms, "kernel_launches": launches,
                          "algorithmic_flops_per_launch": work["flops_spike"],
                          "note": "fp64 compute-bound on the VALU (software exp/sincospi); fp64 vector and matrix "
-                                 "peaks are both 78.6 TFLOP/s on MI355X, so the MFMA-peak field is that figure",
+                                 "peaks are both 78.6 TFLOP/s on MI355X, so the MFMA-peak field is that figure. "
+                                 "`achieved` uses SURVEY 8(d)'s convention (24 flop-equivalents per kernel evaluation, "
+                                 "x3 for value + gradients = 78 per spike / inducing-point pair); this kernel needs "
+                                 "about 21 fp64 instructions per pair, so the conventional fraction can exceed 1. "
+                                 "`issued_*` prices the VALU instructions the PMC pass counted at one FMA each.",
+                         "issued_valu_insts_per_launch": traffic[2] if traffic else None,
+                         "issued_tflops": (2.0 * 64.0 * traffic[2] / (spike_avg_ms * 1e-3) / 1e12)
+                         if traffic and spike_avg_ms > 0 else None,
+                         "issued_frac": (2.0 * 64.0 * traffic[2] / (spike_avg_ms * 1e-3) / 1e12 / FP64_PEAK_TFLOPS)
+                         if traffic and spike_avg_ms > 0 else None,
                          "eval_frac_fp64": work_full["flops_eval"] / world / (ms_per_step * 1e-3) / 1e12 / FP64_PEAK_TFLOPS,
                          "eval_frac_hbm": work_full["bytes_eval"] / world / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS},
         }
