@@ -14,11 +14,17 @@ spike count across ranks (total work fixed: "strong" scaling) and every step end
 all-reduce of the shared vector [ELBO, ELL, KL, dC, dd, dtheta].
 
 Rank 0 prints one JSON line.  Extra objects:
-  roofline     : the dominant kernel (k_spike): algorithmic fp64 flop-equivalents per launch
-                 (SURVEY 8(d) convention: 24 per kernel evaluation, x3 for value+gradients) over
-                 its mean device time from hipEvents recorded inside the timed region.
+  roofline     : the dominant kernel (k_spike, fp64 VALU bound): fp64 operations the kernel must
+                 execute per launch -- counted from its instruction mix per (spike, inducing point)
+                 pair, FMA = 2, other fp64 arithmetic = 1, ldexp / cvt = 0 (PAIR_FLOPS below,
+                 DESIGN.md section 4) -- over its mean device time from hipEvents recorded inside
+                 the timed region, against the 78.6 TFLOP/s fp64 vector peak; frac <= 1 by
+                 construction.  SURVEY 8(d)'s flop-EQUIVALENT convention (24 per kernel evaluation,
+                 x3 for value + gradients) is reported beside it as `survey_convention_*`, never
+                 as `frac`.
   cpu_baseline : the CPU oracle (oracle/svgpfa_oracle.py, PyTorch-CPU fp64, the reference's
-                 unfused algorithm) timed on this host on a bounded sample of the same workload.
+                 unfused algorithm) timed on this host on a bounded sample of the same workload:
+                 1 warm-up + 3 repetitions, min and mean, CPU model stated.
 """
 import argparse
 import json
@@ -33,6 +39,36 @@ if REPO not in sys.path:
 FP64_PEAK_TFLOPS = 78.6   # MI355X fp64 vector = fp64 matrix peak (AMD public figure)
 HBM_PEAK_GBS = 8000.0
 
+# fp64 operations per (spike, inducing point) pair of the spike pass, from the instruction mix of
+# svgpfa_amd/csrc/kernels_spike.h (FMA = 2 flops, add / mul / rndne = 1, ldexp / cvt = 0):
+#   2^y kernel (sv_math.h sv_exp2_neg): rndne + sub + 10 FMA                      = 22
+#   RBF      full : u = t - z, y = -u u, 2^y, ck = c kt, p0 += ck, 3 FMA (p1, p2, mu)      = 32
+#   periodic full : y = 2 FMA, 2^y, ck, p0 += ck, 5 FMA (qa, qb, qc, qd, mu)                = 38
+#   RBF      value: u, y, 2^y, 1 FMA (p0)                                                   = 26
+#   periodic value: cs = mul + FMA, y = FMA, 2^y, 1 FMA (p0)                                = 29
+# Per-spike set-up (loads, one sincos per spike of a periodic latent, the dC scan) is NOT counted:
+# the figure is a lower bound of the executed operations, so the fraction cannot exceed 1.
+PAIR_FLOPS = {("exponentialQuadratic", True): 32, ("periodic", True): 38,
+              ("exponentialQuadratic", False): 26, ("periodic", False): 29}
+
+
+def spike_pass_flops(prob, full):
+    """fp64 operations one spike pass must execute (PAIR_FLOPS x pairs), this rank's shard."""
+    S = int(prob["spike_offsets"][-1])
+    return float(sum(S * M * PAIR_FLOPS[(t, bool(full))] for M, t in zip(prob["Ms"], prob["kernel_types"])))
+
+
+def kernel_source_sha():
+    """Content hash of the device code: a PMC digest only describes the kernels it was measured on."""
+    import hashlib
+    h = hashlib.sha256()
+    csrc = os.path.join(REPO, "svgpfa_amd", "csrc")
+    for f in sorted(os.listdir(csrc)):
+        if f.endswith((".h", ".hip")):
+            with open(os.path.join(csrc, f), "rb") as fh:
+                h.update(f.encode() + b"\0" + fh.read())
+    return h.hexdigest()[:16]
+
 
 def algorithmic_work(prob, variant):
     """flop-equivalents and bytes per evaluation, and the spike kernel's share."""
@@ -46,7 +82,7 @@ def algorithmic_work(prob, variant):
     flops_eval = 3 * (F_fwd + 24 * T_fwd)
     T_spk = sum(M * S for M in Ms)
     F_spk = sum(2 * M * S for M in Ms) + 2 * S * K
-    flops_spike = 3 * (F_spk + 24 * T_spk)
+    flops_spike = (3 if variant == "all" else 1) * (F_spk + 24 * T_spk)   # value-only pass: forward work only
     ngrad = sum(R * (M + M * (M + 1) // 2) for M in Ms)
     if variant == "all":
         ngrad += sum(R * M for M in Ms) + N * K + N + sum(1 if t == "exponentialQuadratic" else 2
@@ -60,7 +96,7 @@ def algorithmic_work(prob, variant):
                 kernel_evals=T_fwd)
 
 
-def cpu_baseline(config, variant, sample_trials):
+def cpu_baseline(config, variant, sample_trials, reps=3):
     """Time the CPU oracle on the first `sample_trials` trials of the workload (same seed)."""
     import torch
     from oracle import svgpfa_oracle as orc
@@ -93,22 +129,40 @@ def cpu_baseline(config, variant, sample_trials):
         warm[key] = [a[:2] for a in sample[key]]
     orc.elbo_and_grads(orc.from_numpy_problem(warm), mask)
     p = orc.from_numpy_problem(sub)
-    t0 = time.perf_counter()
-    orc.elbo_and_grads(p, mask)
-    dt = time.perf_counter() - t0
+    times = []
+    for _ in range(max(1, reps)):       # 1 warm-up + >= 3 timed repetitions, min and mean
+        t0 = time.perf_counter()
+        orc.elbo_and_grads(p, mask)
+        times.append(time.perf_counter() - t0)
     frac = ns / R
-    return dict(value=frac / dt, unit="evals/s", cores=int(torch.get_num_threads()), kind="port",
+    tmin, tmean = min(times), sum(times) / len(times)
+    return dict(value=frac / tmin, value_mean=frac / tmean, unit="evals/s", cores=int(torch.get_num_threads()),
+                kind="port", cpu_model=_cpu_model(), repetitions=len(times), seconds=[round(t, 3) for t in times],
                 sample=f"oracle ({'ALL' if mask == 15 else 'E-step'} closure) on the first {ns} of {R} trials of "
-                       f"{config} ({int(off[ns])} spikes), {dt:.2f} s; value = ({ns}/{R}) / time "
+                       f"{config} ({int(off[ns])} spikes), {len(times)} repetitions after a warm-up, min {tmin:.2f} s / "
+                       f"mean {tmean:.2f} s; value = ({ns}/{R}) / min time, value_mean from the mean "
                        f"(linear in trials; the reference itself is super-linear, SURVEY 3.4)")
 
 
+def _cpu_model():
+    try:
+        with open("/proc/cpuinfo") as fh:
+            for line in fh:
+                if line.startswith("model name"):
+                    return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
 def measured_traffic(config, variant, full_mask):
-    """HBM bytes per k_spike launch from the committed PMC digest (profiles/*_pmc.json, made by
+    """HBM bytes per k_spike launch from a committed PMC digest (profiles/*_pmc.json, made by
     tests/tools/collect_profiles.sh + digest_profiles.py in separate rocprofv3 --pmc passes of this same
-    command).  Counters cannot be read inside the timed run, so the figure is the latest committed one for
-    the same config / variant; None when there is none."""
+    command).  Counters cannot be read inside the timed run, so the figure comes from a digest -- and only from one
+    taken on THESE kernels: the digest records the content hash of svgpfa_amd/csrc at collection time and is
+    ignored (traffic = null) when the device code has changed since.  Returns (bytes, file, valu_insts, sha)."""
     import glob
+    sha = kernel_source_sha()
     best = None
     for f in sorted(glob.glob(os.path.join(REPO, "profiles", "*_pmc.json"))):
         try:
@@ -116,7 +170,7 @@ def measured_traffic(config, variant, full_mask):
                 d = json.load(fh)
         except (OSError, ValueError):
             continue
-        if d.get("config") != config or d.get("variant") != variant:
+        if d.get("config") != config or d.get("variant") != variant or d.get("kernel_source_sha") != sha:
             continue
         tot, n = 0.0, 0     # the spike pass of one evaluation = the k_spike launches of all covariance types
         insts = 0.0
@@ -127,7 +181,7 @@ def measured_traffic(config, variant, full_mask):
                 insts += e.get("SQ_INSTS_VALU", 0.0)
                 n += 1
         if n:
-            best = (tot, os.path.basename(f), insts)
+            best = (tot, os.path.basename(f), insts, sha)
     return best
 
 
@@ -139,6 +193,7 @@ def main():
     ap.add_argument("--config", default="cfg3", choices=["cfg2", "cfg3", "cfg5"])
     ap.add_argument("--variant", default="all", choices=["all", "estep"])
     ap.add_argument("--cpu-sample-trials", type=int, default=200)
+    ap.add_argument("--cpu-reps", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="collective backend; gloo + --single-device rehearses the N > 1 path on a one-GPU box")
@@ -225,8 +280,12 @@ def main():
         work = algorithmic_work(prob, args.variant)      # this rank's shard (what one launch processes)
         work_full = algorithmic_work(full, args.variant)
         ms_per_step = 1e3 * elapsed / args.steps
-        achieved = work["flops_spike"] / (spike_avg_ms * 1e-3) / 1e12 if spike_avg_ms > 0 else None
-        traffic = measured_traffic(args.config, args.variant, bool(mask & 14)) if world == 1 else None
+        full_pass = bool(mask & 14)
+        exec_flops = spike_pass_flops(prob, full_pass)
+        secs = spike_avg_ms * 1e-3
+        achieved = exec_flops / secs / 1e12 if spike_avg_ms > 0 else None
+        conv = work["flops_spike"] / secs / 1e12 if spike_avg_ms > 0 else None
+        traffic = measured_traffic(args.config, args.variant, full_pass) if world == 1 else None
         out = {
             "metric": "ELBO+grad evals/sec at (trials,neurons,latents,ind)=(%d,%d,%d,%d)" % (
                 full["R"], full["N"], full["K"], full["Ms"][0]),
@@ -240,31 +299,34 @@ def main():
                                          + (", spike sums reused across evaluations" if args.estep_cache else "")),
                        "parallelism": f"trials sharded {world}-way by spike count, 1 RCCL all-reduce/step" if world > 1 else "single GPU"},
             "elbo": elbo,
-            "roofline": {"bound": "mfma", "achieved": achieved, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
+            "roofline": {"bound": "valu_fp64", "achieved": achieved, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": (achieved / FP64_PEAK_TFLOPS) if achieved else None,
                          "traffic": traffic[0] if traffic else None,
                          "traffic_unit": "HBM bytes per spike pass (FETCH_SIZE + WRITE_SIZE of its k_spike launches, separate PMC passes)",
-                         "traffic_source": ("profiles/" + traffic[1]) if traffic else None,
+                         "traffic_source": ("profiles/%s @ csrc %s" % (traffic[1], traffic[3])) if traffic
+                         else "none: no committed PMC digest was taken on this device code (csrc %s)" % kernel_source_sha(),
                          "algorithmic_bytes_per_launch": work.get("bytes_spike"),
-                         "kernel": "k_spike<%s>" % ("true" if mask & 14 else "false"),
+                         "kernel": "k_spike<%s>" % ("true" if full_pass else "false"),
                          "kernel_avg_ms": spike_avg_ms, "kernel_launches": launches,
-                         "algorithmic_flops_per_launch": work["flops_spike"],
-                         "note": "fp64 compute-bound on the VALU (software exp/sincospi); fp64 vector and matrix "
-                                 "peaks are both 78.6 TFLOP/s on MI355X, so the MFMA-peak field is that figure. "
-                                 "`achieved` uses SURVEY 8(d)'s convention (24 flop-equivalents per kernel evaluation, "
-                                 "x3 for value + gradients = 78 per spike / inducing-point pair); this kernel needs "
-                                 "about 21 fp64 instructions per pair, so the conventional fraction can exceed 1. "
-                                 "`issued_*` prices the VALU instructions the PMC pass counted at one FMA each.",
+                         "executed_fp64_flops_per_launch": exec_flops,
+                         "pair_flops": {"%s/%s" % (t[:3], "full" if f else "value"): v for (t, f), v in PAIR_FLOPS.items()},
+                         "note": "k_spike issues no MFMA: its work is one software 2^y (rndne, sub, 10 FMA, ldexp, cvt) and 3-7 "
+                                 "FMAs per (spike, inducing point) pair on the fp64 VALU.  `achieved` = fp64 operations the "
+                                 "kernel must execute (FMA = 2, add / mul / rndne = 1, ldexp / cvt = 0; per-spike set-up not "
+                                 "counted) / its hipEvent time; peak = 78.6 TFLOP/s fp64 vector.  survey_convention_* prices a "
+                                 "kernel evaluation at 24 flop-EQUIVALENTS (x3 with gradients) as SURVEY 8(d) does; it is not "
+                                 "a hardware fraction and can exceed the peak.  issued_* prices every VALU instruction the "
+                                 "PMC pass counted as one 64-lane FMA issue slot (an issue-slot figure, not flops).",
+                         "survey_convention_flops_eq_per_launch": work["flops_spike"],
+                         "survey_convention_tflops_eq": conv,
                          "issued_valu_insts_per_launch": traffic[2] if traffic else None,
-                         "issued_tflops": (2.0 * 64.0 * traffic[2] / (spike_avg_ms * 1e-3) / 1e12)
+                         "issue_slot_frac": (2.0 * 64.0 * traffic[2] / secs / 1e12 / FP64_PEAK_TFLOPS)
                          if traffic and spike_avg_ms > 0 else None,
-                         "issued_frac": (2.0 * 64.0 * traffic[2] / (spike_avg_ms * 1e-3) / 1e12 / FP64_PEAK_TFLOPS)
-                         if traffic and spike_avg_ms > 0 else None,
-                         "eval_frac_fp64": work_full["flops_eval"] / world / (ms_per_step * 1e-3) / 1e12 / FP64_PEAK_TFLOPS,
+                         "eval_survey_convention_frac_fp64": work_full["flops_eval"] / world / (ms_per_step * 1e-3) / 1e12 / FP64_PEAK_TFLOPS,
                          "eval_frac_hbm": work_full["bytes_eval"] / world / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS},
         }
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(args.config, args.variant, args.cpu_sample_trials)
+            out["cpu_baseline"] = cpu_baseline(args.config, args.variant, args.cpu_sample_trials, args.cpu_reps)
         print(json.dumps(out), flush=True)
     if use_dist:
         dist.barrier()

@@ -116,21 +116,9 @@ def make_config(name, n_trials=None, **over):
     return make_problem(seed=20260103 + idx, **c)
 
 
-def shard_trials(prob, rank, world):
-    """Contiguous block of trials for `rank`, balanced by spike count (SURVEY 8(e))."""
-    R = prob["R"]
+def slice_trials(prob, lo, hi):
+    """Trials [lo, hi) of a problem as a problem of its own (CSR arrays re-based)."""
     off = prob["spike_offsets"]
-    total = off[-1]
-    # boundaries at equal spike-count quantiles, snapped to trial edges
-    targets = [total * i / world for i in range(world + 1)]
-    bounds = [int(np.searchsorted(off, t, side="left")) for t in targets]
-    bounds[0], bounds[-1] = 0, R
-    for i in range(1, world + 1):          # keep boundaries monotone and non-empty when R >= world
-        bounds[i] = max(bounds[i], bounds[i - 1] + (1 if R >= world else 0))
-    bounds[-1] = R
-    for i in range(world - 1, 0, -1):
-        bounds[i] = min(bounds[i], bounds[i + 1] - (1 if R >= world else 0))
-    lo, hi = bounds[rank], bounds[rank + 1]
     s0, s1 = off[lo], off[hi]
     out = dict(prob)
     out["R"] = hi - lo
@@ -143,3 +131,32 @@ def shard_trials(prob, rank, world):
         out[key] = [a[lo:hi] for a in prob[key]]
     out["trial_range"] = (lo, hi)
     return out
+
+
+def shard_bounds(prob, world):
+    """Trial boundaries of a `world`-way contiguous partition balanced by spike count.
+    Every rank gets at least one trial; fewer trials than ranks is an error on EVERY rank (the same
+    arguments give the same exception everywhere, so no rank is left waiting in a collective)."""
+    R = prob["R"]
+    if world < 1:
+        raise ValueError("world must be positive")
+    if R < world:
+        raise ValueError(f"cannot shard {R} trials over {world} ranks: every rank needs at least one trial")
+    off = prob["spike_offsets"]
+    total = off[-1]
+    # boundaries at equal spike-count quantiles, snapped to trial edges
+    targets = [total * i / world for i in range(world + 1)]
+    bounds = [int(np.searchsorted(off, t, side="left")) for t in targets]
+    bounds[0], bounds[-1] = 0, R
+    for i in range(1, world + 1):          # keep boundaries monotone and shards non-empty
+        bounds[i] = max(bounds[i], bounds[i - 1] + 1)
+    bounds[-1] = R
+    for i in range(world - 1, 0, -1):
+        bounds[i] = min(bounds[i], bounds[i + 1] - 1)
+    return bounds
+
+
+def shard_trials(prob, rank, world):
+    """Contiguous block of trials for `rank`, balanced by spike count (SURVEY 8(e))."""
+    bounds = shard_bounds(prob, world)
+    return slice_trials(prob, bounds[rank], bounds[rank + 1])

@@ -28,6 +28,9 @@ What is written (all float64 numpy arrays, inputs AND reference outputs):
   rank1_small.npz   - the rank-1 + diagonal representation of the variational covariances
                       (indPointsCovRep = indPointsCovRank1PlusDiag, stats/svPosteriorOnIndPoints.py:86-119)
                       on the ragged case: ELBO / ELL / KL and gradients wrt mean, qSVec, qSDiag.
+  cfg3_shape.npz    - the north-star geometry (BASELINE config 3: 200 neurons, 10 latents RBF + periodic, 32 inducing
+                      points, Q = 200, ~4000 spikes per trial) on the first 6 trials of the SURVEY 8(d) inputs:
+                      scalars + gradients of all four groups (inputs are regenerated from the seed in the tests).
   cfg1_bundled.npz  - BASELINE config 1: the bundled simulated data
                       (examples/data/32451751_simRes.pickle: spike times only, as CSR) with the
                       parameters of examples/params/00000545_estimation_metaData.ini, and the
@@ -368,6 +371,15 @@ def cfg1_bundled():
                         lowerBoundHist=np.array(hist))
 
 
+def cfg3_shape():
+    prob = synthetic.make_config("cfg3", n_trials=6)
+    model, params = ref_model_from_problem(prob)
+    out = ref_outputs(model, params, intermediates=False)
+    print("cfg3_shape: ref elbo %.8f ell %.8f kl %.8f" % (out["ref_elbo"], out["ref_ell"], out["ref_kl"]))
+    np.savez_compressed(os.path.join(HERE, "cfg3_shape.npz"), n_trials=6, n_spikes=prob["spike_offsets"][-1],
+                        spike_times_sum=prob["spike_times"].sum(), C_sum=prob["C"].sum(), **out)
+
+
 def rank1_small():
     """Non-default q(u) covariance: S = q q^T + diag(d^2) (svPosteriorOnIndPoints.py:104-119)."""
     prob = ragged_problem()
@@ -426,6 +438,8 @@ def rank1_small():
 if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "rank1":
         rank1_small()
+    elif len(sys.argv) > 1 and sys.argv[1] == "cfg3":
+        cfg3_shape()
     elif len(sys.argv) > 1 and sys.argv[1] == "em":
         em_small()
         cfg1_bundled()
@@ -434,3 +448,4 @@ if __name__ == "__main__":
         em_small()
         cfg1_bundled()
         rank1_small()
+        cfg3_shape()

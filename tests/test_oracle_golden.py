@@ -91,6 +91,26 @@ def test_cfg2_seeded_inputs_and_outputs(golden_dir):
     assert rel_err(out["g_d"].numpy(), ref["g_d"]) < TOL_ARRAY
 
 
+def test_cfg3_shape_seeded_inputs_and_outputs(golden_dir):
+    """North-star geometry (BASELINE config 3 shapes, first 6 trials of the SURVEY 8(d) inputs): the oracle equals the
+    reference on ELBO / ELL / KL and every gradient group."""
+    ref = np.load(golden_dir + "/cfg3_shape.npz")
+    prob = synthetic.make_config("cfg3", n_trials=int(ref["n_trials"]))
+    assert int(prob["spike_offsets"][-1]) == int(ref["n_spikes"])
+    assert prob["spike_times"].sum() == float(ref["spike_times_sum"])
+    assert prob["C"].sum() == float(ref["C_sum"])
+    out = orc.elbo_and_grads(orc.from_numpy_problem(prob), orc.GRAD_ALL)
+    for key in ("elbo", "ell", "kl"):
+        assert abs(float(out[key]) - float(ref["ref_" + key])) < 1e-10 * abs(float(ref["ref_" + key]))
+    for k in range(prob["K"]):
+        assert rel_err(out["g_mean"][k].numpy()[:, :, 0], ref[f"g_mean_{k}"]) < TOL_ARRAY
+        assert rel_err(out["g_cholVecs"][k].numpy()[:, :, 0], ref[f"g_cholVecs_{k}"]) < TOL_ARRAY
+        assert rel_err(out["g_Z"][k].numpy()[:, :, 0], ref[f"g_Z_{k}"]) < TOL_ARRAY
+        assert rel_err(out["g_theta"][k].numpy(), ref[f"g_theta_{k}"]) < TOL_ARRAY
+    assert rel_err(out["g_C"].numpy(), ref["g_C"]) < TOL_ARRAY
+    assert rel_err(out["g_d"].numpy(), ref["g_d"]) < TOL_ARRAY
+
+
 def test_embedding_mstep_closure(golden_dir):
     prob, _ = load_golden("ragged_small")
     ref = np.load(golden_dir + "/estep_embedding.npz")

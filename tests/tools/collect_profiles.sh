@@ -8,6 +8,8 @@ tag=${1:-run}; shift || true
 root=${GRAFT_REPO_ROOT:-$(pwd)}
 out=$root/gpurun_out/profile_$tag
 mkdir -p "$out"
+# content hash of the device code these counters describe (bench.py ignores a digest whose hash differs from its tree)
+(cd "$root" && python3 -c "import bench; print(bench.kernel_source_sha())") > "$out/csrc_sha.txt"
 cd /tmp && export TMPDIR=/tmp
 common="$root/bench.py --steps 20 --warmup 3 --no-cpu-baseline $*"
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/trace" -- python3 $common > "$out/trace.log" 2>&1

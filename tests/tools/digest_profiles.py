@@ -61,8 +61,12 @@ def main():
         if k in avg_ns:
             e["avg_ns_trace"] = avg_ns[k]
         out[k] = e
+    sha = None
+    if os.path.exists(os.path.join(src, "csrc_sha.txt")):
+        sha = open(os.path.join(src, "csrc_sha.txt")).read().strip()
     with open(os.path.join(dst, f"{name}_pmc.json"), "w") as fh:
         json.dump({"source": f"collect_profiles.sh {tag}: separate rocprofv3 --pmc passes, per-dispatch averages",
+                   "kernel_source_sha": sha,
                    "config": sys.argv[3] if len(sys.argv) > 3 else "cfg3",
                    "variant": sys.argv[4] if len(sys.argv) > 4 else "all",
                    "kernels": out}, fh, indent=1, sort_keys=True)
