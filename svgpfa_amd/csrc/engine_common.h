@@ -10,7 +10,7 @@
 // ut = L^-1 m, Vt = L^-1 L_S): mu = kt.ut, var = s2 - |kt|^2 + |Vt^T kt|^2.  All whitened
 // quantities are O(1), which keeps fp64 error at ~sqrt(cond(Kzz)) u instead of cond(Kzz)^2 u
 // for the explicit-inverse algebra (measured against a 40-digit referee, tests/tools/).
-//   quad stats mu/var/gmu/gvar : [r][q][k]
+//   quad stats mu/var/gmu/gvar : [r][k][q]  (a tile of 16 nodes of one latent = 128 contiguous bytes)
 //   spikes: times[S], neuron[S] (CSR over trials, neuron-major inside a trial), mu_spk[k][S]
 //   spike chunks: <= SPIKE_CHUNK spikes of one trial; partial sums P0/P1 [chunk][sumM], T [chunk][K][2]
 #pragma once
@@ -84,7 +84,6 @@ struct EngineView {
   double* Kzz; double* L; double* Linv;
   double* a; double* ut; double* Vt; double* klpart;   // klpart [R*K]
   double* muq; double* varq; double* gmuq; double* gvarq;
-  double* gaq; double* GW; double* gZq; double* gthq;   // quad-side adjoints of ut, Vt Vt^T, direct Z / theta; gthq [R*K*2]
   double* P0; double* P1; double* Tpart;           // spike partials
   double* gCspk;                                   // [R][N][K] spike part of dC per trial (whole segments)
   double* splitPart;                               // [nchunks][K] spike part of dC of split chunks
@@ -94,6 +93,7 @@ struct EngineView {
   double* ells; double* gthitem;                   // [R*K], [R*K*2]
   double* Mseg;                                    // [N][K] sum over spikes of mu_spk per neuron (stats path)
   int* status;
+  unsigned* fin_ticket;       // blocks of k_item_bwd that have finished (the last one does the cross-trial sums)
 };
 
 // ------------------------------------------------------------------ covariance functions

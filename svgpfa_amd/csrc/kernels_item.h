@@ -2,7 +2,7 @@
 //   k_build_reg (this file) : Kzz + eps I, Cholesky L, Linv = L^-1   (reference kernelsMatricesStore.py:107-117, miscUtils.py:209-216)
 //   k_prep_mfma (kernels_mfma.h) : ut = Linv m, a = Linv^T ut (= Kzz^-1 m), Vt = Linv L_S, KL
 //             (reference svPosteriorOnLatents.py:185-216 algebra in whitened form, klDivergence.py:31-44)
-//   k_bwd_mfma (kernels_mfma.h)  : adjoints of (ut, Vt Vt^T, KL, direct kappa terms) -> gradients wrt m, cholVecs, Z, theta
+//   k_item_bwd (kernels_item_bwd.h) : adjoints of (ut, Vt Vt^T, KL, direct kappa terms) -> gradients wrt m, cholVecs, Z, theta
 // Derivation (per trial/latent; Kzz = L L^T, S = L_S L_S^T, kt = Linv k(t)):
 //   mu(t) = kt.ut,  var(t) = s2 - |kt|^2 + |Vt^T kt|^2,  KL = (|Vt|_F^2 + |ut|^2 + logdet Kzz - logdet S - M)/2
 //   with gt = dELL/d ut and Gt = sum_t dELL/dvar(t) kt kt^T (adjoint of Vt Vt^T):

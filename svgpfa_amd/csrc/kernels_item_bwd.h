@@ -1,0 +1,644 @@
+// k_item_bwd: everything downstream of the expected log-likelihood for one (trial, latent) item, in ONE kernel:
+//   phase 1  adjoints of the quadrature term wrt ut (gt), Vt Vt^T (Gt) and -- FULL -- the direct dependence on
+//            Z / theta through kappa(t_q, Z)                       (was k_quad_bwd_mfma)
+//   phase 2  backward through the whitened algebra: gradients wrt m, cholVecs, Z, theta of the item
+//            (derivation: kernels_item.h header)                  (was k_bwd_mfma)
+//   phase 3  the fixed-order reductions of the per-trial partials into the `shared` vector
+//            [ELBO, ELL, KL, dC, dd, dtheta]                      (was k_finalize)
+// Linv, a, ut, Z and the adjoints gt / Gt stay in LDS between phases 1 and 2 (the two-kernel version wrote Gt to HBM and
+// re-staged Linv / Gt: 164 MB and a 34 us fill phase per evaluation at the north-star size).
+// Phase 3: the dC / dd sums only read partials of EARLIER kernels (spike pass, ELL kernel), so they are dealt out over
+// the blocks of this grid; the dtheta sums and the three scalars need this kernel's own per-item results and are done
+// by the block that finishes last (ticket counter; agent-scope release before the ticket, acquire after it).  Every sum
+// keeps a fixed order, so results stay bit-reproducible.
+// Replaces autograd backward of the reference (stats/svEM.py:274-288) for stats/svPosteriorOnLatents.py:185-216,
+// stats/klDivergence.py:18-44, stats/kernelsMatricesStore.py:107-117.
+#pragma once
+#include "engine_common.h"
+#include "kernels_mfma.h"
+
+#define SV_FIN_OUT 8   // outputs per reduction group of phase 3 (8 consecutive doubles = one 64-B segment per trial)
+
+// stride (doubles) of the per-wave transpose scratch of phase 1: rows are written with lane -> row (stride LDS2) and
+// read with lane -> column; LDS2 = 17 mod 32 makes the 16-lane row writes and the 32-lane transposed reads conflict free
+// up to one bank (the old stride MP + 2 cost a 2-way conflict on every transposed ds_read_b64)
+__host__ __device__ constexpr int sv_tr_stride(int MP) { return ((MP + 14) / 32) * 32 + 17; }
+
+__host__ __device__ constexpr size_t sv_item_bwd_lds_doubles(int NT, int NWB) {
+  const size_t MP = 16 * NT, LD = MP + 2, L2 = sv_tr_stride(16 * NT);
+  const size_t S = (NWB * 16 * L2 > MP * MP) ? NWB * 16 * L2 : MP * MP;
+  return 3 * MP * LD + S + 9 * MP + NWB * 16 + NWB * 2 * MP + NWB * 2 + NT * MP + 2 * NT + 8;
+}
+
+// ---- phase 3 -------------------------------------------------------------------------------------------------------
+// dC / dd: group g of SV_FIN_OUT consecutive outputs; thread (o, pg) sums the trials pg, pg + NG, ... and the NG partial
+// sums are added in order through LDS.  red needs blockDim.x doubles.
+__device__ __forceinline__ void fin_cd_group(const EngineView& ev, const double* C, unsigned mask, double* shared, int g,
+                                             double* red) {
+  const int tid = threadIdx.x, o = tid % SV_FIN_OUT, pg = tid / SV_FIN_OUT, NG = blockDim.x / SV_FIN_OUT;
+  const int NK = ev.N * ev.K, N = ev.N, K = ev.K, R = ev.R;
+  const int nbC = (NK + SV_FIN_OUT - 1) / SV_FIN_OUT;
+  double s = 0.0;
+  int out = -1;
+  if (g < nbC) {
+    const int id = g * SV_FIN_OUT + o;
+    if (id < NK) {
+      out = 3 + id;
+      if (mask & 2u) {
+        const int n = id / K, k = id % K;
+        const double cnk = C[id];
+        for (int r = pg; r < R; r += NG) s += ev.gCspk[(long long)r * NK + id];
+        for (int b = pg; b < ev.ncd; b += NG) {      // dC = -(E^T mu + C . E^T var)
+          const long long o2 = ((long long)b * N + n) * 2 * K + k;
+          s -= ev.gCpart[o2] + cnk * ev.gCpart[o2 + K];
+        }
+        if (pg == 0)
+          for (int l = 0; l < ev.nsplit; ++l) {
+            const int ch = ev.split_chunks[l];
+            if (ev.chunks[ch].neuron == n) s += ev.splitPart[(long long)ch * K + k];
+          }
+      }
+    }
+  } else {
+    const int n = (g - nbC) * SV_FIN_OUT + o;
+    if (n < N) {
+      out = 3 + NK + n;
+      if (mask & 2u) {
+        for (int b = pg; b < ev.ncd; b += NG) s += ev.gdpart[(long long)b * N + n];
+        if (pg == 0) s += ev.spk_cnt[n];
+      }
+    }
+  }
+  __syncthreads();
+  red[pg * SV_FIN_OUT + o] = s;
+  __syncthreads();
+  if (pg == 0 && out >= 0) {
+    double t = red[o];
+    for (int q = 1; q < NG; ++q) t += red[q * SV_FIN_OUT + o];
+    shared[out] = t;
+  }
+}
+
+// The last block: dtheta (sums over trials of the per-item values) and [ELBO, ELL, KL].
+__device__ __forceinline__ void fin_last_block(const EngineView& ev, const double* d, unsigned mask, double* shared,
+                                               double* red) {
+  const int tid = threadIdx.x, NTH = blockDim.x, N = ev.N, K = ev.K, R = ev.R, NK = N * K;
+  double e = 0.0, kl = 0.0;
+  for (int i = tid; i < ev.nell; i += NTH) e += ev.ellq[i];
+  for (int i = tid; i < R * K; i += NTH) {
+    e += ev.ells[i];
+    kl += ev.klpart[i];
+  }
+  for (int n = tid; n < N; n += NTH) e += ev.spk_cnt[n] * d[n];
+  e = block_sum(e, red);
+  kl = block_sum(kl, red);
+  if (tid == 0) {
+    shared[0] = e - kl;
+    shared[1] = e;
+    shared[2] = kl;
+  }
+  // dtheta: one wavefront per parameter, lanes over trials, fixed-order wave tree
+  const int lane = tid & 63, wave = tid >> 6, NW = NTH >> 6;
+  for (int ti = wave; ti < ev.nth_total; ti += NW) {
+    double s = 0.0;
+    if (mask & 4u) {
+      int k = 0;
+      while (k + 1 < K && ev.meta[k + 1].thoff <= ti) ++k;
+      const int t = ti - ev.meta[k].thoff;
+      for (int r = lane; r < R; r += 64) s += ev.gthitem[((long long)r * K + k) * 2 + t];
+      s = wave_sum(s);
+    }
+    if (lane == 0) shared[3 + NK + N + ti] = s;
+  }
+}
+
+__device__ __forceinline__ void fin_tail(const EngineView& ev, const double* C, const double* d, unsigned mask,
+                                         double* shared, double* red, int* flag) {
+  const int nbC = (ev.N * ev.K + SV_FIN_OUT - 1) / SV_FIN_OUT, nbD = (ev.N + SV_FIN_OUT - 1) / SV_FIN_OUT;
+  for (int g = blockIdx.x; g < nbC + nbD; g += gridDim.x) fin_cd_group(ev, C, mask, shared, g, red);
+  // hand-off of this block's per-item results (ells, gthitem) to the block that finishes last
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const unsigned t = __hip_atomic_fetch_add(ev.fin_ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const int last = (t == gridDim.x - 1);
+    if (last) {
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __hip_atomic_store(ev.fin_ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
+    }
+    *flag = last;
+  }
+  __syncthreads();
+  if (*flag) fin_last_block(ev, d, mask, shared, red);
+}
+
+// ---- phases 1 + 2 --------------------------------------------------------------------------------------------------
+template <int NT, int KT, bool FULL>
+__device__ void item_bwd_body(const EngineView& ev, const int r, const int k, const LatentPtrs pt, unsigned mask,
+                              double* sm) {
+  constexpr int MP = 16 * NT, LD = MP + 2, NTRI = NT * (NT + 1) / 2, L2S = sv_tr_stride(MP);
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6, li = lane & 15, lg = lane >> 4;
+  const int NTHB = blockDim.x, NWB = NTHB >> 6;   // 2 or 4 waves per block (host: 2 when the grid is large and M <= 32)
+  const int item = r * ev.K + k;
+  const LatentMeta m = ev.meta[k];
+  const int M = m.M, Q = ev.Q, K = ev.K;
+  const size_t SZ = ((size_t)NWB * 16 * L2S > (size_t)MP * MP) ? (size_t)NWB * 16 * L2S : (size_t)MP * MP;
+  double* Li = sm;                    // MP*LD  Linv
+  double* Vl = Li + MP * LD;          // MP*LD  phase 1 (FULL): D = Linv^T (Vt Vt^T - I); phase 2: Vt, later C
+  double* Gl = Vl + MP * LD;          // MP*LD  phase 2: Gt, later At
+  double* S = Gl + MP * LD;           // SZ     phase 1: per-wave transpose scratch, then the MP x MP sum of Gt
+  double* ul = S + SZ;                // MP     ut
+  double* al = ul + MP;               // MP     a = Linv^T ut
+  double* zl = al + MP;               // MP     Z
+  double* gt = zl + MP;               // MP
+  double* gs = gt + MP;               // MP
+  double* gq = gs + MP;               // MP     quadrature part of the adjoint of ut
+  double* gzq = gq + MP;              // MP     quadrature part of dZ (direct)
+  double* szl = gzq + MP;             // MP     sin of the inducing-point phases (periodic)
+  double* czl = szl + MP;             // MP     cos
+  double* gvs = czl + MP;             // NWB*16
+  double* vred = gvs + NWB * 16;      // NWB*2*MP  gu / dz partials per wave
+  double* tred = vred + NWB * 2 * MP; // NWB*2
+  double* redz = tred + NWB * 2;      // NT*MP  per-panel row sums of the dZ contraction
+  double* redt = redz + NT * MP;      // NT*2   per-panel dtheta partials
+  double* thq = redt + 2 * NT;        // 2      quadrature part of dtheta (direct)
+  const KPar p = make_kpar(m, ev.theta + 2 * k);
+  const long long base = m.offMM + (long long)r * M * M;
+  const long long vbase = m.offM + (long long)r * M;
+  const bool want_lat = (mask & (1u | 4u | 8u)) != 0;
+  const bool want_zt = (mask & (4u | 8u)) != 0;
+
+  if (want_lat) {
+    // ================================================================= phase 1: quadrature adjoints
+    load_factors<NT>(ev, m, r, Li, Vl, ul, zl, FULL);
+    if (tid < MP) al[tid] = (tid < M) ? ev.a[vbase + tid] : 0.0;
+    __syncthreads();
+    if (KT == SV_PERIODIC && tid < MP) sv_sincos_quarter(zl[tid] * p.q4, szl[tid], czl[tid]);
+    if (FULL) {
+      // The adjoint of kappa(t, Z) at a node is gk = Linv^T [gm ut + 2 gv (Vt Vt^T - I) kt] = gm a + 2 gv D kt with the
+      // per-item matrix D = Linv^T (Vt Vt^T - I): one dense M x M x 16 product per tile instead of three triangular ones
+      // (T = Vt^T kt, Vt T, Linv^T .).  D is built once per item, one 16-column panel per wavefront, and replaces Vt in LDS.
+      d4 Dp[NT];
+      for (int c = wave; c < NT; c += NWB) {     // NWB >= NT in every launch configuration: one panel per wave
+        d4 P[NT], VV[NT];
+#pragma unroll
+        for (int b = 0; b < NT; ++b)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) P[b][q] = Vl[(16 * c + li) * LD + 16 * b + 4 * q + lg];   // Vt^T panel
+        tri_chain<NT, 0>(VV, Vl, LD, P, li, lg);
+#pragma unroll
+        for (int a = 0; a < NT; ++a)
+#pragma unroll
+          for (int q = 0; q < 4; ++q)
+            if (16 * a + 4 * q + lg == 16 * c + li) VV[a][q] -= 1.0;
+        tri_chain<NT, 1>(Dp, Li, LD, VV, li, lg);
+      }
+      __syncthreads();                                                   // every wave is done reading Vt
+      if (wave < NT) {
+        const int c = wave;
+#pragma unroll
+        for (int a = 0; a < NT; ++a)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) Vl[(16 * a + 4 * q + lg) * LD + 16 * c + li] = Dp[a][q];
+      }
+    }
+    __syncthreads();
+    d4 gu[NT], dz[NT], GW[NTRI];
+#pragma unroll
+    for (int a = 0; a < NT; ++a) {
+      gu[a] = (d4){0.0, 0.0, 0.0, 0.0};
+      dz[a] = (d4){0.0, 0.0, 0.0, 0.0};
+    }
+#pragma unroll
+    for (int t = 0; t < NTRI; ++t) GW[t] = (d4){0.0, 0.0, 0.0, 0.0};
+    double th0 = 0.0, th1 = 0.0;
+    double* Sw = S + wave * 16 * L2S;
+    double* gvw = gvs + wave * 16;
+    // periodic: kappa and its derivative bases follow from the node's own sin / cos and the inducing
+    // points' (szl, czl) by angle addition (no per-pair sincos, no second exp).  Per-j constants are read
+    // from LDS at their use sites (jo is an opaque 0: it keeps them out of long-lived registers).
+    const double inv_s2 = 1.0 / p.s2;
+    const double* gmq = ev.gmuq + ((long long)r * K + k) * Q;     // [r][k][q]: this item's nodes are contiguous
+    const double* gvq = ev.gvarq + ((long long)r * K + k) * Q;
+    const double* tqr = ev.tq + (long long)r * Q;
+
+    const int ntiles = (Q + 15) >> 4;
+    // inputs of the NEXT tile are fetched one iteration ahead (global latency hidden behind the MFMA chain)
+    double tq_n = 0.0, gm_n = 0.0, gv_n = 0.0;
+    if (wave < ntiles) {
+      const int nn = 16 * wave + li;
+      tq_n = tqr[(nn < Q) ? nn : 0];
+      gm_n = (nn < Q) ? gmq[nn] : 0.0;
+      gv_n = (nn < Q) ? gvq[nn] : 0.0;
+    }
+    for (int tile = wave; tile < ntiles; tile += NWB) {
+      const double tq = tq_n, gm = gm_n, gvv = gv_n;
+      if (tile + NWB < ntiles) {
+        const int nn = 16 * (tile + NWB) + li;
+        tq_n = tqr[(nn < Q) ? nn : 0];
+        gm_n = (nn < Q) ? gmq[nn] : 0.0;
+        gv_n = (nn < Q) ? gvq[nn] : 0.0;
+      }
+      double stq = 0.0, ctq = 0.0;
+      if (KT == SV_PERIODIC) sv_sincos_quarter(tq * p.q4, stq, ctq);
+      int jo = lg;
+      asm volatile("" : "+v"(jo));
+      d4 X0[NT];
+#pragma unroll
+      for (int a = 0; a < NT; ++a)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int j = 16 * a + 4 * q + jo;
+          if (KT == SV_RBF) {
+            const double dd = tq - zl[j];
+            X0[a][q] = p.s2 * sv_exp2_neg(-(dd * dd) * p.h2);
+          } else {
+            const double cs = fma(stq, szl[j], ctq * czl[j]);
+            X0[a][q] = p.s2 * sv_exp2_neg(fma(cs, p.h2, -p.h2));
+          }
+        }
+      d4 Kw[NT];
+      tri_chain<NT, 0>(Kw, Li, LD, X0, li, lg);
+#pragma unroll
+      for (int a = 0; a < NT; ++a)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) gu[a][q] = fma(gm, Kw[a][q], gu[a][q]);
+      if (FULL) {
+        d4 Gk[NT];
+#pragma unroll
+        for (int a = 0; a < NT; ++a) {
+          d4 acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+          for (int b = 0; b < NT; ++b)
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+              acc = __builtin_amdgcn_mfma_f64_16x16x4f64(Vl[(16 * a + li) * LD + 16 * b + 4 * q + lg], Kw[b][q], acc, 0, 0, 0);
+          Gk[a] = acc;                                            // D kt
+        }
+#pragma unroll
+        for (int a = 0; a < NT; ++a)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) Gk[a][q] = fma(2.0 * gvv, Gk[a][q], gm * al[16 * a + 4 * q + jo]);
+        asm volatile("" : "+v"(jo));
+#pragma unroll
+        for (int a = 0; a < NT; ++a)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const int j = 16 * a + 4 * q + jo;
+            const double gkk = Gk[a][q] * (X0[a][q] * inv_s2);    // gk * ktil
+            const double dd = tq - zl[j];
+            if (KT == SV_RBF) {
+              const double gd = gkk * dd;
+              dz[a][q] += gd;                                    // bz = delta
+              th0 = fma(gd, dd, th0);                            // b0 = delta^2
+            } else {
+              const double cs = fma(stq, szl[j], ctq * czl[j]);
+              const double sn = fma(stq, czl[j], -(ctq * szl[j]));
+              const double gsn = gkk * sn;
+              dz[a][q] += gsn;                                   // bz = sin(2 pi delta / p)
+              th0 = fma(gkk, 0.5 - 0.5 * cs, th0);               // b0 = sin^2(pi delta / p)
+              th1 = fma(gsn, dd, th1);                           // b1 = delta sin(2 pi delta / p)
+            }
+          }
+      }
+      // Gt += Kw^T diag(gvar) Kw : contraction over the time index -> transpose through LDS
+#pragma unroll
+      for (int a = 0; a < NT; ++a)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) Sw[li * L2S + 16 * a + 4 * q + lg] = Kw[a][q];
+      if (lg == 0) gvw[li] = gvv;
+      lds_wave_fence();
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const int nc = 4 * c + lg;
+        const double g = gvw[nc];
+        double aop[NT];
+#pragma unroll
+        for (int a = 0; a < NT; ++a) aop[a] = Sw[nc * L2S + 16 * a + li];
+        int t = 0;
+#pragma unroll
+        for (int a = 0; a < NT; ++a)
+#pragma unroll
+          for (int b = 0; b <= a; ++b) {
+            GW[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(aop[a], g * aop[b], GW[t], 0, 0, 0);
+            ++t;
+          }
+      }
+      lds_wave_fence();
+    }
+
+    // ---- reductions: over the 16 time lanes, then over the wavefronts (fixed order)
+#pragma unroll
+    for (int a = 0; a < NT; ++a)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        double g = row16_sum(gu[a][q]);
+        double z = FULL ? row16_sum(dz[a][q]) : 0.0;
+        if (li == 0) {
+          vred[(wave * 2 + 0) * MP + 16 * a + 4 * q + lg] = g;
+          vred[(wave * 2 + 1) * MP + 16 * a + 4 * q + lg] = z;
+        }
+      }
+    th0 = wave_sum(th0);
+    th1 = wave_sum(th1);
+    if (lane == 0) {
+      tred[wave * 2 + 0] = th0;
+      tred[wave * 2 + 1] = th1;
+    }
+    __syncthreads();   // all waves done with their scratch (and with D): S becomes the MP x MP sum buffer
+    for (int w = 0; w < NWB; ++w) {
+      if (wave == w) {
+        int t = 0;
+#pragma unroll
+        for (int a = 0; a < NT; ++a)
+#pragma unroll
+          for (int b = 0; b <= a; ++b) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+              int row = 16 * a + lg + 4 * q, col = 16 * b + li;
+              if (w == 0)
+                S[row * MP + col] = GW[t][q];
+              else
+                S[row * MP + col] += GW[t][q];
+            }
+            ++t;
+          }
+      }
+      __syncthreads();
+    }
+    if (tid < MP) {
+      double g = 0.0, z = 0.0;
+      if (tid < M) {
+        g = vred[tid];
+        for (int w = 1; w < NWB; ++w) g += vred[(2 * w) * MP + tid];
+        if (FULL) {
+          z = vred[MP + tid];
+          for (int w = 1; w < NWB; ++w) z += vred[(2 * w + 1) * MP + tid];
+          z *= p.cz;
+        }
+      }
+      gq[tid] = g;
+      gzq[tid] = z;
+    }
+    if (tid == 0) {
+      double t0s = 0.0, t1s = 0.0;
+      if (FULL) {
+        t0s = tred[0];
+        t1s = tred[1];
+        for (int w = 1; w < NWB; ++w) {
+          t0s += tred[2 * w];
+          t1s += tred[2 * w + 1];
+        }
+      }
+      thq[0] = p.c0 * t0s;
+      thq[1] = p.c1 * t1s;
+    }
+    // stage Vt (phase 2 needs it; in the FULL variant the buffer held D) and the symmetric Gt in fragment layout
+    for (int e = tid; e < MP * MP; e += NTHB) {
+      const int i = e / MP, j = e % MP;
+      const bool in = (i < M) && (j < M);
+      Vl[i * LD + j] = in ? ev.Vt[base + i * M + j] : 0.0;
+      Gl[i * LD + j] = in ? (((i >> 4) >= (j >> 4)) ? S[i * MP + j] : S[j * MP + i]) : 0.0;
+    }
+  } else {
+    if (tid < MP) {
+      ul[tid] = 0.0;
+      zl[tid] = 0.0;
+      al[tid] = (tid < M) ? ev.a[vbase + tid] : 0.0;
+    }
+  }
+
+  // =================================================================== phase 2: per-item backward
+  // ---- gather the spike partial sums of this trial (fixed chunk order); thread j < M owns inducing point j
+  double p1sum = 0.0, espk = 0.0, a_l = 0.0;
+  if (tid < MP) {
+    gs[tid] = 0.0;
+    gt[tid] = 0.0;
+  }
+  __syncthreads();
+  const int c0 = ev.chunk_first[r], c1 = ev.chunk_first[r + 1];
+  if (tid < M) {
+    double p0 = 0.0;
+    for (int ch = c0; ch < c1; ch += 4) {          // 4 chunks per step: independent loads in flight, fixed order
+      double v[4], w[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const bool in = ch + u < c1;
+        const long long o = (long long)(in ? ch + u : ch) * ev.sumM + m.colM + tid;
+        v[u] = ev.P0[o];
+        w[u] = want_zt ? ev.P1[o] : 0.0;
+        if (!in) { v[u] = 0.0; w[u] = 0.0; }
+      }
+      p0 += (v[0] + v[1]) + (v[2] + v[3]);
+      p1sum += (w[0] + w[1]) + (w[2] + w[3]);
+    }
+    a_l = al[tid];
+    const double gsp = p.s2 * p0;
+    espk = a_l * gsp;
+    gs[tid] = gsp;
+  }
+  // spike-direct theta partials: one chunk per lane of wave 0, then a fixed-order wave tree
+  double tp0 = 0.0, tp1 = 0.0;
+  if (wave == 0) {
+    espk = wave_sum(espk);
+    if (want_zt) {
+      for (int ch = c0 + lane; ch < c1; ch += 64) {
+        tp0 += ev.Tpart[((long long)ch * ev.K + k) * 2 + 0];
+        tp1 += ev.Tpart[((long long)ch * ev.K + k) * 2 + 1];
+      }
+      tp0 = wave_sum(tp0);
+      tp1 = wave_sum(tp1);
+    }
+    if (lane == 0) ev.ells[item] = espk;
+  }
+  if (!want_lat) return;
+
+  __syncthreads();
+  if (tid < M) {
+    double s = gq[tid];
+    for (int q = 0; q <= tid; ++q) s += Li[tid * LD + q] * gs[q];
+    gt[tid] = s;
+  }
+  __syncthreads();
+
+  const int c = wave;                     // panel index of this wavefront (waves >= NT idle through the panel work)
+  const bool pan = c < NT;
+  if (mask & 1u) {
+    if (tid < M) {
+      double s = 0.0;
+      for (int q = tid; q < M; ++q) s += Li[q * LD + tid] * (gt[q] - ul[q]);
+      pt.g_mean[(long long)r * M + tid] = s;
+    }
+    if (pan) {
+      // dL_S = tril(Linv^T (2 Gt - I) Vt) + diag(1 / L_S,ii): this wave's 16-column panel
+      const double* cv = pt.cholvec + (long long)r * m.P;
+      double* gcv = pt.g_cholvec + (long long)r * m.P;
+      d4 P[NT], X[NT];
+#pragma unroll
+      for (int b = 0; b < NT; ++b)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) P[b][q] = Vl[(16 * b + 4 * q + lg) * LD + 16 * c + li];
+#pragma unroll
+      for (int a = 0; a < NT; ++a) {
+        d4 acc = {0.0, 0.0, 0.0, 0.0};
+        if (a >= c) {
+#pragma unroll
+          for (int b = 0; b < NT; ++b) {
+            if (b >= c) {   // Vt lower triangular: panel c has zero tiles above the diagonal
+#pragma unroll
+              for (int q = 0; q < 4; ++q) {
+                int row = 16 * a + li, col = 16 * b + 4 * q + lg;
+                double av = 2.0 * Gl[row * LD + col] - (row == col ? 1.0 : 0.0);
+                acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, P[b][q], acc, 0, 0, 0);
+              }
+            }
+          }
+        }
+        X[a] = acc;
+      }
+#pragma unroll
+      for (int a = 0; a < NT; ++a) {
+        if (a >= c) {
+          d4 acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+          for (int b = a; b < NT; ++b)
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+              acc = __builtin_amdgcn_mfma_f64_16x16x4f64(Li[(16 * b + 4 * q + lg) * LD + 16 * a + li], X[b][q], acc, 0, 0, 0);
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            int i = 16 * a + 4 * q + lg, j = 16 * c + li;
+            if (i < M && j <= i) {
+              double g = acc[q];
+              if (i == j) g += 1.0 / cv[i * (i + 1) / 2 + i];
+              gcv[i * (i + 1) / 2 + j] = g;
+            }
+          }
+        }
+      }
+    }
+  }
+  if (!want_zt) return;
+
+  // ---- panel c of C = Vt Vt^T Gt and of VV = Vt Vt^T, kept in registers until Vt is dead in every wave
+  d4 VV[NT], Cm[NT];
+  if (pan) {
+    d4 P[NT], Bm[NT];
+#pragma unroll
+    for (int b = 0; b < NT; ++b)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) P[b][q] = Gl[(16 * b + 4 * q + lg) * LD + 16 * c + li];
+    tri_chain<NT, 1>(Bm, Vl, LD, P, li, lg);
+    tri_chain<NT, 0>(Cm, Vl, LD, Bm, li, lg);
+#pragma unroll
+    for (int b = 0; b < NT; ++b)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) P[b][q] = Vl[(16 * c + li) * LD + 16 * b + 4 * q + lg];   // Vt^T panel
+    tri_chain<NT, 0>(VV, Vl, LD, P, li, lg);
+  }
+  __syncthreads();
+  double* Cs = Vl;
+  if (pan) {
+#pragma unroll
+    for (int a = 0; a < NT; ++a)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) Cs[(16 * a + 4 * q + lg) * LD + 16 * c + li] = Cm[a][q];
+  }
+  __syncthreads();
+  // ---- At (in place over Gt): each element is read and written by exactly one lane; the transposed reads of Gt
+  //      itself do not occur (only C is read transposed), so no wave sees a half-updated panel
+  if (pan) {
+#pragma unroll
+    for (int a = 0; a < NT; ++a)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        int i = 16 * a + 4 * q + lg, j = 16 * c + li;
+        double v = -0.5 * (gt[i] * ul[j] + ul[i] * gt[j]) + 0.5 * ul[i] * ul[j] + Gl[i * LD + j] +
+                   0.5 * (VV[a][q] - (i == j ? 1.0 : 0.0)) - Cs[i * LD + j] - Cs[j * LD + i];
+        Gl[i * LD + j] = v;
+      }
+  }
+  __syncthreads();
+  // ---- panel c of A = Linv^T At Linv, contracted on the fly with dKzz/dZ and dKzz/dtheta
+  if (pan) {
+    d4 P[NT], Dm[NT], Am[NT];
+#pragma unroll
+    for (int b = 0; b < NT; ++b)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) P[b][q] = Li[(16 * b + 4 * q + lg) * LD + 16 * c + li];
+#pragma unroll
+    for (int a = 0; a < NT; ++a) {
+      d4 acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+      for (int b = 0; b < NT; ++b)
+        if (b >= c) {   // Linv lower triangular
+#pragma unroll
+          for (int q = 0; q < 4; ++q)
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(Gl[(16 * a + li) * LD + 16 * b + 4 * q + lg], P[b][q], acc, 0, 0, 0);
+        }
+      Dm[a] = acc;
+    }
+    tri_chain<NT, 1>(Am, Li, LD, Dm, li, lg);
+    const double zc = zl[16 * c + li];
+    double t0 = 0.0, t1 = 0.0;
+#pragma unroll
+    for (int a = 0; a < NT; ++a)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        int i = 16 * a + 4 * q + lg, j = 16 * c + li;
+        double gz = 0.0;
+        if (i < M && j < M) {
+          double kt, bz, b0, b1;
+          kern_eval<KT>(zl[i] - zc, p, kt, bz, b0, b1);
+          double ak = Am[a][q] * kt;
+          gz = -(ak * bz);
+          t0 = fma(ak, b0, t0);
+          t1 = fma(ak, b1, t1);
+        }
+        gz = row16_sum(gz);
+        if (li == 0) redz[c * MP + i] = gz;
+      }
+    t0 = wave_sum(t0);
+    t1 = wave_sum(t1);
+    if (lane == 0) {
+      redt[2 * c + 0] = t0;
+      redt[2 * c + 1] = t1;
+    }
+  }
+  __syncthreads();
+  if ((mask & 8u) && tid < M) {
+    double g = 0.0;
+#pragma unroll
+    for (int w = 0; w < NT; ++w) g += redz[w * MP + tid];     // fixed panel order
+    // direct spike part a_j cz P1_j is already on this thread
+    pt.g_Z[(long long)r * M + tid] = g * 2.0 * p.cz + gzq[tid] + a_l * p.cz * p1sum;
+  }
+  if (tid == 0) {
+    double t0 = 0.0, t1 = 0.0;
+#pragma unroll
+    for (int w = 0; w < NT; ++w) {
+      t0 += redt[2 * w + 0];
+      t1 += redt[2 * w + 1];
+    }
+    ev.gthitem[item * 2 + 0] = t0 * p.c0 + thq[0] + p.c0 * tp0;
+    ev.gthitem[item * 2 + 1] = t1 * p.c1 + thq[1] + p.c1 * tp1;
+  }
+}
+
+// grid = R*K blocks of 64 NWB threads (NWB = 2 or 4 >= NT); FULL = gradients wrt Z / theta wanted (mask & 12).
+template <int NT, bool FULL>
+__global__ __launch_bounds__(256, (NT <= 2 ? 2 : 1)) void k_item_bwd(EngineView ev, LatentPtrTable ptab, unsigned mask,
+                                                                     const double* C, const double* d, double* shared) {
+  extern __shared__ double sm[];
+  const int r = blockIdx.x / ev.K, k = blockIdx.x % ev.K;
+  if (ev.meta[k].ktype == SV_RBF)
+    item_bwd_body<NT, SV_RBF, FULL>(ev, r, k, ptab.p[k], mask, sm);
+  else
+    item_bwd_body<NT, SV_PERIODIC, FULL>(ev, r, k, ptab.p[k], mask, sm);
+  __shared__ int flag;
+  fin_tail(ev, C, d, mask, shared, sm, &flag);    // sm is free again: every wave passes the barriers inside
+}

@@ -5,7 +5,7 @@
 // layout an accumulator tile is exactly the B operand of the next MFMA that contracts over its
 // row index (probe: tests/tools/mfma_f64_probe.hip), so the whole whitening chain
 //     Kt^T -> Kw^T = Linv Kt^T -> T^T = Vt^T Kw^T -> Y^T = Vt T^T -> adj -> gk^T = Linv^T adj
-// runs register-to-register; only the A operands (fragments of the M x M factors) come from LDS.
+// runs register-to-register (the backward half lives in kernels_item_bwd.h); only the A operands (fragments of the M x M factors) come from LDS.
 // kappa(t, z) itself is evaluated straight into B-operand layout (lane = time point, registers =
 // inducing points), so Ktz never touches LDS or HBM.
 //
@@ -73,11 +73,14 @@ __device__ __forceinline__ void load_factors(const EngineView& ev, const LatentM
 // ------------------------------------------------------------------------ k_times_fwd_mfma
 // Posterior mean / variance of latent k at a CSR list of times (reference
 // svPosteriorOnLatents.py:185-216, :265-300).  grid = R*K blocks of 128 or 256 threads; each wavefront
-// walks tiles of 16 time points.  Output element (time gi, latent k) at gi*os_t + k*os_k.
+// walks tiles of 16 time points.  Output element (trial r, time i of that trial, latent k) at
+// base_r + i*os_t + k*os_k with base_r = toff[r]*os_t (CSR times) or r*os_r (nper times per trial).  The engine's own
+// quadrature statistics use [r][k][q] (os_r = K Q, os_t = 1, os_k = Q): the 16 nodes of a tile are 128 contiguous bytes
+// for this kernel's stores, for the adjoint loads of k_item_bwd and for the ELL kernel's rows.
 template <int NT, int KT>
 __device__ void times_fwd_body(const EngineView& ev, const int r, const int k, const double* times,
-                               const long long* toff, int nper, double* mu_out, double* var_out, long long os_t,
-                               long long os_k, int want_var, double* sm) {
+                               const long long* toff, int nper, double* mu_out, double* var_out, long long os_r,
+                               long long os_t, long long os_k, int want_var, double* sm) {
   constexpr int MP = 16 * NT, LD = MP + 2;
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6, li = lane & 15, lg = lane >> 4;
@@ -109,6 +112,7 @@ __device__ void times_fwd_body(const EngineView& ev, const int r, const int k, c
 
   const int ntiles = (nt + 15) >> 4;
   const int NWB = blockDim.x >> 6;     // waves per block (launch parameter; 4)
+  const long long obase = (toff ? t0 * os_t : (long long)r * os_r) + (long long)k * os_k;
   // the time of the NEXT tile is fetched one iteration ahead (global latency hidden behind the MFMA chain)
   double tq_next = (wave < ntiles) ? times[t0 + ((16 * wave + li < nt) ? 16 * wave + li : 0)] : 0.0;
   for (int tile = wave; tile < ntiles; tile += NWB) {
@@ -158,9 +162,9 @@ __device__ void times_fwd_body(const EngineView& ev, const int r, const int k, c
     n2 = grp4_sum(n2);
     tt = grp4_sum(tt);
     if (lg == 0 && ok) {
-      long long gi = t0 + node;
-      mu_out[gi * os_t + k * os_k] = pm;
-      if (want_var) var_out[gi * os_t + k * os_k] = (p.s2 - n2) + tt;
+      const long long o = obase + (long long)node * os_t;
+      mu_out[o] = pm;
+      if (want_var) var_out[o] = (p.s2 - n2) + tt;
     }
   }
 }
@@ -169,512 +173,14 @@ __device__ void times_fwd_body(const EngineView& ev, const int r, const int k, c
 template <int NT>
 __global__ __launch_bounds__(256) void k_times_fwd_mfma(EngineView ev, const double* times,
                                                         const long long* toff, int nper, double* mu_out,
-                                                        double* var_out, long long os_t, long long os_k,
-                                                        int want_var) {
+                                                        double* var_out, long long os_r, long long os_t,
+                                                        long long os_k, int want_var) {
   extern __shared__ double sm[];
   const int r = blockIdx.x / ev.K, k = blockIdx.x % ev.K;
   if (ev.meta[k].ktype == SV_RBF)
-    times_fwd_body<NT, SV_RBF>(ev, r, k, times, toff, nper, mu_out, var_out, os_t, os_k, want_var, sm);
+    times_fwd_body<NT, SV_RBF>(ev, r, k, times, toff, nper, mu_out, var_out, os_r, os_t, os_k, want_var, sm);
   else
-    times_fwd_body<NT, SV_PERIODIC>(ev, r, k, times, toff, nper, mu_out, var_out, os_t, os_k, want_var, sm);
-}
-
-// ------------------------------------------------------------------------- k_quad_bwd_mfma
-// Adjoints of the quadrature term wrt ut (gt), Vt Vt^T (Gt) and -- FULL -- the direct dependence
-// on Z / theta through kappa(t_q, Z).  grid = R*K blocks of 256 threads.
-// (forcing 3 waves/SIMD with amdgpu_waves_per_eu spills 76 VGPRs and is 36 % slower: the FULL variant stays at 2)
-template <int NT, int KT, bool FULL>
-__device__ void quad_bwd_mfma_body(const EngineView& ev, const int r, const int k, double* sm) {
-  constexpr int MP = 16 * NT, LD = MP + 2, NTRI = NT * (NT + 1) / 2;
-  const int tid = threadIdx.x;
-  const int lane = tid & 63, wave = tid >> 6, li = lane & 15, lg = lane >> 4;
-  const int item = r * ev.K + k;
-  const LatentMeta m = ev.meta[k];
-  const int M = m.M, Q = ev.Q, K = ev.K;
-  double* Li = sm;                    // MP*LD
-  double* Vl = Li + MP * LD;          // MP*LD
-  double* ul = Vl + MP * LD;          // MP
-  double* zl = ul + MP;               // MP
-  const int NTHB = blockDim.x, NWB = NTHB >> 6;   // 2 or 4 waves per block (host: 2 when the grid is large enough)
-  double* S = zl + MP;                // NWB * 16*LD  (per-wave transpose scratch; later the MP x MP Gt sum buffer)
-  double* gvs = S + NWB * 16 * LD;    // NWB * 16
-  double* vred = gvs + NWB * 16;      // NWB * 2 * MP  (gu / dz partials per wave)
-  double* tred = vred + NWB * 2 * MP; // NWB * 2
-  double* szl = tred + NWB * 2;       // MP  sin of the inducing-point phases (periodic)
-  double* czl = szl + MP;             // MP  cos
-  const KPar p = make_kpar(m, ev.theta + 2 * k);
-  const long long base = m.offMM + (long long)r * M * M;
-  const long long vbase = m.offM + (long long)r * M;
-  load_factors<NT>(ev, m, r, Li, Vl, ul, zl, FULL);
-  __syncthreads();
-  if (KT == SV_PERIODIC && tid < MP) sv_sincos_quarter(zl[tid] * p.q4, szl[tid], czl[tid]);
-  if (FULL) {
-    // The adjoint of kappa(t, Z) at a node is gk = Linv^T [gm ut + 2 gv (Vt Vt^T - I) kt] = gm a + 2 gv D kt with the
-    // per-item matrix D = Linv^T (Vt Vt^T - I): one dense M x M x 16 product per tile instead of three triangular ones
-    // (T = Vt^T kt, Vt T, Linv^T .).  D is built once per item, one 16-column panel per wavefront, and replaces Vt in LDS.
-    d4 Dp[NT];
-    const int c = wave;
-    if (c < NT) {
-      d4 P[NT], VV[NT];
-#pragma unroll
-      for (int b = 0; b < NT; ++b)
-#pragma unroll
-        for (int q = 0; q < 4; ++q) P[b][q] = Vl[(16 * c + li) * LD + 16 * b + 4 * q + lg];   // Vt^T panel
-      tri_chain<NT, 0>(VV, Vl, LD, P, li, lg);
-#pragma unroll
-      for (int a = 0; a < NT; ++a)
-#pragma unroll
-        for (int q = 0; q < 4; ++q)
-          if (16 * a + 4 * q + lg == 16 * c + li) VV[a][q] -= 1.0;
-      tri_chain<NT, 1>(Dp, Li, LD, VV, li, lg);
-    }
-    if (tid < MP) ul[tid] = (tid < M) ? ev.a[vbase + tid] : 0.0;     // a = Linv^T ut takes the place of ut
-    __syncthreads();                                                   // every wave is done reading Vt
-    if (c < NT) {
-#pragma unroll
-      for (int a = 0; a < NT; ++a)
-#pragma unroll
-        for (int q = 0; q < 4; ++q) Vl[(16 * a + 4 * q + lg) * LD + 16 * c + li] = Dp[a][q];
-    }
-  }
-  __syncthreads();
-  d4 gu[NT], dz[NT], GW[NTRI];
-#pragma unroll
-  for (int a = 0; a < NT; ++a) {
-    gu[a] = (d4){0.0, 0.0, 0.0, 0.0};
-    dz[a] = (d4){0.0, 0.0, 0.0, 0.0};
-  }
-#pragma unroll
-  for (int t = 0; t < NTRI; ++t) GW[t] = (d4){0.0, 0.0, 0.0, 0.0};
-  double th0 = 0.0, th1 = 0.0;
-  double* Sw = S + wave * 16 * LD;
-  double* gvw = gvs + wave * 16;
-  // periodic: kappa and its derivative bases follow from the node's own sin / cos and the inducing
-  // points' (szl, czl) by angle addition (no per-pair sincos, no second exp).  Per-j constants are read
-  // from LDS at their use sites (jo is an opaque 0: it keeps them out of long-lived registers).
-  const double inv_s2 = 1.0 / p.s2;
-
-  const int ntiles = (Q + 15) >> 4;
-  // inputs of the NEXT tile are fetched one iteration ahead (global latency hidden behind the MFMA chain)
-  double tq_n = 0.0, gm_n = 0.0, gv_n = 0.0;
-  if (wave < ntiles) {
-    const int nn = 16 * wave + li;
-    const long long gi = (long long)r * Q + ((nn < Q) ? nn : 0);
-    tq_n = ev.tq[gi];
-    gm_n = (nn < Q) ? ev.gmuq[gi * K + k] : 0.0;
-    gv_n = (nn < Q) ? ev.gvarq[gi * K + k] : 0.0;
-  }
-  for (int tile = wave; tile < ntiles; tile += NWB) {
-    const double tq = tq_n, gm = gm_n, gvv = gv_n;
-    if (tile + NWB < ntiles) {
-      const int nn = 16 * (tile + NWB) + li;
-      const long long gi = (long long)r * Q + ((nn < Q) ? nn : 0);
-      tq_n = ev.tq[gi];
-      gm_n = (nn < Q) ? ev.gmuq[gi * K + k] : 0.0;
-      gv_n = (nn < Q) ? ev.gvarq[gi * K + k] : 0.0;
-    }
-    double stq = 0.0, ctq = 0.0;
-    if (KT == SV_PERIODIC) sv_sincos_quarter(tq * p.q4, stq, ctq);
-    int jo = lg;
-    asm volatile("" : "+v"(jo));
-    d4 X0[NT];
-#pragma unroll
-    for (int a = 0; a < NT; ++a)
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const int j = 16 * a + 4 * q + jo;
-        if (KT == SV_RBF) {
-          const double dd = tq - zl[j];
-          X0[a][q] = p.s2 * sv_exp2_neg(-(dd * dd) * p.h2);
-        } else {
-          const double cs = fma(stq, szl[j], ctq * czl[j]);
-          X0[a][q] = p.s2 * sv_exp2_neg(fma(cs, p.h2, -p.h2));
-        }
-      }
-    d4 Kw[NT];
-    tri_chain<NT, 0>(Kw, Li, LD, X0, li, lg);
-#pragma unroll
-    for (int a = 0; a < NT; ++a)
-#pragma unroll
-      for (int q = 0; q < 4; ++q) gu[a][q] = fma(gm, Kw[a][q], gu[a][q]);
-    if (FULL) {
-      d4 Gk[NT];
-#pragma unroll
-      for (int a = 0; a < NT; ++a) {
-        d4 acc = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-        for (int b = 0; b < NT; ++b)
-#pragma unroll
-          for (int q = 0; q < 4; ++q)
-            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(Vl[(16 * a + li) * LD + 16 * b + 4 * q + lg], Kw[b][q], acc, 0, 0, 0);
-        Gk[a] = acc;                                            // D kt
-      }
-#pragma unroll
-      for (int a = 0; a < NT; ++a)
-#pragma unroll
-        for (int q = 0; q < 4; ++q) Gk[a][q] = fma(2.0 * gvv, Gk[a][q], gm * ul[16 * a + 4 * q + jo]);
-      asm volatile("" : "+v"(jo));
-#pragma unroll
-      for (int a = 0; a < NT; ++a)
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const int j = 16 * a + 4 * q + jo;
-          const double gkk = Gk[a][q] * (X0[a][q] * inv_s2);    // gk * ktil
-          const double dd = tq - zl[j];
-          if (KT == SV_RBF) {
-            const double gd = gkk * dd;
-            dz[a][q] += gd;                                    // bz = delta
-            th0 = fma(gd, dd, th0);                            // b0 = delta^2
-          } else {
-            const double cs = fma(stq, szl[j], ctq * czl[j]);
-            const double sn = fma(stq, czl[j], -(ctq * szl[j]));
-            const double gs = gkk * sn;
-            dz[a][q] += gs;                                    // bz = sin(2 pi delta / p)
-            th0 = fma(gkk, 0.5 - 0.5 * cs, th0);               // b0 = sin^2(pi delta / p)
-            th1 = fma(gs, dd, th1);                            // b1 = delta sin(2 pi delta / p)
-          }
-        }
-    }
-    // Gt += Kw^T diag(gvar) Kw : contraction over the time index -> transpose through LDS
-#pragma unroll
-    for (int a = 0; a < NT; ++a)
-#pragma unroll
-      for (int q = 0; q < 4; ++q) Sw[li * LD + 16 * a + 4 * q + lg] = Kw[a][q];
-    if (lg == 0) gvw[li] = gvv;
-    lds_wave_fence();
-#pragma unroll
-    for (int c = 0; c < 4; ++c) {
-      const int nc = 4 * c + lg;
-      const double g = gvw[nc];
-      double aop[NT];
-#pragma unroll
-      for (int a = 0; a < NT; ++a) aop[a] = Sw[nc * LD + 16 * a + li];
-      int t = 0;
-#pragma unroll
-      for (int a = 0; a < NT; ++a)
-#pragma unroll
-        for (int b = 0; b <= a; ++b) {
-          GW[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(aop[a], g * aop[b], GW[t], 0, 0, 0);
-          ++t;
-        }
-    }
-    lds_wave_fence();
-  }
-
-  // ---- reductions: over the 16 time lanes, then over the wavefronts (fixed order)
-#pragma unroll
-  for (int a = 0; a < NT; ++a)
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      double g = row16_sum(gu[a][q]);
-      double z = FULL ? row16_sum(dz[a][q]) : 0.0;
-      if (li == 0) {
-        vred[(wave * 2 + 0) * MP + 16 * a + 4 * q + lg] = g;
-        vred[(wave * 2 + 1) * MP + 16 * a + 4 * q + lg] = z;
-      }
-    }
-  th0 = wave_sum(th0);
-  th1 = wave_sum(th1);
-  if (lane == 0) {
-    tred[wave * 2 + 0] = th0;
-    tred[wave * 2 + 1] = th1;
-  }
-  __syncthreads();   // all waves done with their scratch: S becomes the MP x MP sum buffer
-  for (int w = 0; w < NWB; ++w) {
-    if (wave == w) {
-      int t = 0;
-#pragma unroll
-      for (int a = 0; a < NT; ++a)
-#pragma unroll
-        for (int b = 0; b <= a; ++b) {
-#pragma unroll
-          for (int q = 0; q < 4; ++q) {
-            int row = 16 * a + lg + 4 * q, col = 16 * b + li;
-            if (w == 0)
-              S[row * MP + col] = GW[t][q];
-            else
-              S[row * MP + col] += GW[t][q];
-          }
-          ++t;
-        }
-    }
-    __syncthreads();
-  }
-  if (tid < M) {
-    double g = vred[tid];
-    for (int w = 1; w < NWB; ++w) g += vred[(2 * w) * MP + tid];
-    ev.gaq[vbase + tid] = g;
-    if (FULL) {
-      double z = vred[MP + tid];
-      for (int w = 1; w < NWB; ++w) z += vred[(2 * w + 1) * MP + tid];
-      ev.gZq[vbase + tid] = p.cz * z;
-    }
-  }
-  for (int e = tid; e < M * M; e += NTHB) {
-    int i = e / M, j = e % M;
-    ev.GW[base + e] = ((i >> 4) >= (j >> 4)) ? S[i * MP + j] : S[j * MP + i];
-  }
-  if (FULL && tid == 0) {
-    double t0s = tred[0], t1s = tred[1];
-    for (int w = 1; w < NWB; ++w) {
-      t0s += tred[2 * w];
-      t1s += tred[2 * w + 1];
-    }
-    ev.gthq[item * 2 + 0] = p.c0 * t0s;
-    ev.gthq[item * 2 + 1] = p.c1 * t1s;
-  }
-}
-
-template <int NT, bool FULL>
-__global__ __launch_bounds__(256, (NT <= 2 ? 2 : 1)) void k_quad_bwd_mfma(EngineView ev) {   // M <= 32: keep 2 waves / SIMD
-  extern __shared__ double sm[];
-  const int r = blockIdx.x / ev.K, k = blockIdx.x % ev.K;
-  if (ev.meta[k].ktype == SV_RBF)
-    quad_bwd_mfma_body<NT, SV_RBF, FULL>(ev, r, k, sm);
-  else
-    quad_bwd_mfma_body<NT, SV_PERIODIC, FULL>(ev, r, k, sm);
-}
-
-// ------------------------------------------------------------------------------ k_bwd_mfma
-// Per-(trial, latent) backward through the whitened algebra (derivation: kernels_item.h header).
-// NT wavefronts per item (block = 64 NT threads): wave c owns the 16-column panel c of every M x M product, all on
-// the f64 MFMA with the left operand read from LDS as A fragments and the right operand held as register tiles.
-// The panels only meet at the LDS hand-offs (C, At) and in the fixed-order sums of the dZ / dtheta partials.
-template <int NT, int KT>
-__device__ void bwd_mfma_body(const EngineView& ev, const int r, const int k, const LatentPtrs pt, unsigned mask,
-                              double* sm) {
-  constexpr int MP = 16 * NT, LD = MP + 2, NTH = 64 * NT;
-  const int tid = threadIdx.x, lane = tid & 63, c = tid >> 6, li = lane & 15, lg = lane >> 4;
-  const int item = r * ev.K + k;
-  const LatentMeta m = ev.meta[k];
-  const int M = m.M;
-  double* Li = sm;               // MP*LD
-  double* Vl = Li + MP * LD;     // MP*LD  Vt; once C and Vt Vt^T are in registers it is reused for C
-  double* Gl = Vl + MP * LD;     // MP*LD  Gt, later At
-  double* Cs = Vl;
-  double* gt = Gl + MP * LD;     // MP
-  double* ul = gt + MP;          // MP
-  double* gs = ul + MP;          // MP
-  double* zl = gs + MP;          // MP
-  double* redz = zl + MP;        // NT*MP  per-panel row sums of the dZ contraction
-  double* redt = redz + NT * MP; // NT*2   per-panel dtheta partials
-  const long long base = m.offMM + (long long)r * M * M;
-  const long long vbase = m.offM + (long long)r * M;
-  const KPar p = make_kpar(m, ev.theta + 2 * k);
-  const bool want_zt = (mask & (4u | 8u)) != 0;
-
-  // ---- gather the spike partial sums of this trial (fixed chunk order); thread j < M owns inducing point j
-  double p1sum = 0.0, espk = 0.0, a_l = 0.0;
-  for (int i = tid; i < MP; i += NTH) {
-    gs[i] = 0.0; ul[i] = 0.0; zl[i] = 0.0; gt[i] = 0.0;
-  }
-  const int c0 = ev.chunk_first[r], c1 = ev.chunk_first[r + 1];
-  if (tid < M) {
-    double p0 = 0.0;
-    for (int ch = c0; ch < c1; ch += 4) {          // 4 chunks per step: independent loads in flight, fixed order
-      double v[4], w[4];
-#pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        const bool in = ch + u < c1;
-        const long long o = (long long)(in ? ch + u : ch) * ev.sumM + m.colM + tid;
-        v[u] = ev.P0[o];
-        w[u] = want_zt ? ev.P1[o] : 0.0;
-        if (!in) { v[u] = 0.0; w[u] = 0.0; }
-      }
-      p0 += (v[0] + v[1]) + (v[2] + v[3]);
-      p1sum += (w[0] + w[1]) + (w[2] + w[3]);
-    }
-    a_l = ev.a[vbase + tid];
-    double gsp = p.s2 * p0;
-    espk = a_l * gsp;
-    gs[tid] = gsp;
-    ul[tid] = ev.ut[vbase + tid];
-    zl[tid] = ev.Zs[vbase + tid];
-  }
-  // spike-direct theta partials: one chunk per lane of wave 0, then a fixed-order wave tree
-  double tp0 = 0.0, tp1 = 0.0;
-  if (c == 0) {
-    espk = wave_sum(espk);
-    if (want_zt) {
-      for (int ch = c0 + lane; ch < c1; ch += 64) {
-        tp0 += ev.Tpart[((long long)ch * ev.K + k) * 2 + 0];
-        tp1 += ev.Tpart[((long long)ch * ev.K + k) * 2 + 1];
-      }
-      tp0 = wave_sum(tp0);
-      tp1 = wave_sum(tp1);
-    }
-    if (lane == 0) ev.ells[item] = espk;
-  }
-  if ((mask & (1u | 4u | 8u)) == 0) return;
-
-  for (int e = tid; e < MP * MP; e += NTH) {
-    int i = e / MP, j = e % MP;
-    bool in = (i < M) && (j < M);
-    Li[i * LD + j] = in ? ev.Linv[base + i * M + j] : 0.0;
-    Vl[i * LD + j] = in ? ev.Vt[base + i * M + j] : 0.0;
-    Gl[i * LD + j] = in ? ev.GW[base + i * M + j] : 0.0;
-  }
-  __syncthreads();
-  if (tid < M) {
-    double s = ev.gaq[vbase + tid];
-    for (int q = 0; q <= tid; ++q) s += Li[tid * LD + q] * gs[q];
-    gt[tid] = s;
-  }
-  __syncthreads();
-
-  if (mask & 1u) {
-    if (tid < M) {
-      double s = 0.0;
-      for (int q = tid; q < M; ++q) s += Li[q * LD + tid] * (gt[q] - ul[q]);
-      pt.g_mean[(long long)r * M + tid] = s;
-    }
-    // dL_S = tril(Linv^T (2 Gt - I) Vt) + diag(1 / L_S,ii): this wave's 16-column panel
-    const double* cv = pt.cholvec + (long long)r * m.P;
-    double* gcv = pt.g_cholvec + (long long)r * m.P;
-    d4 P[NT], X[NT];
-#pragma unroll
-    for (int b = 0; b < NT; ++b)
-#pragma unroll
-      for (int q = 0; q < 4; ++q) P[b][q] = Vl[(16 * b + 4 * q + lg) * LD + 16 * c + li];
-#pragma unroll
-    for (int a = 0; a < NT; ++a) {
-      d4 acc = {0.0, 0.0, 0.0, 0.0};
-      if (a >= c) {
-#pragma unroll
-        for (int b = 0; b < NT; ++b) {
-          if (b >= c) {   // Vt lower triangular: panel c has zero tiles above the diagonal
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-              int row = 16 * a + li, col = 16 * b + 4 * q + lg;
-              double av = 2.0 * Gl[row * LD + col] - (row == col ? 1.0 : 0.0);
-              acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, P[b][q], acc, 0, 0, 0);
-            }
-          }
-        }
-      }
-      X[a] = acc;
-    }
-#pragma unroll
-    for (int a = 0; a < NT; ++a) {
-      if (a >= c) {
-        d4 acc = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-        for (int b = a; b < NT; ++b)
-#pragma unroll
-          for (int q = 0; q < 4; ++q)
-            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(Li[(16 * b + 4 * q + lg) * LD + 16 * a + li], X[b][q], acc, 0, 0, 0);
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          int i = 16 * a + 4 * q + lg, j = 16 * c + li;
-          if (i < M && j <= i) {
-            double g = acc[q];
-            if (i == j) g += 1.0 / cv[i * (i + 1) / 2 + i];
-            gcv[i * (i + 1) / 2 + j] = g;
-          }
-        }
-      }
-    }
-  }
-  if (!want_zt) return;
-
-  // ---- panel c of C = Vt Vt^T Gt and of VV = Vt Vt^T, kept in registers until Vt is dead in every wave
-  d4 VV[NT], Cm[NT];
-  {
-    d4 P[NT], Bm[NT];
-#pragma unroll
-    for (int b = 0; b < NT; ++b)
-#pragma unroll
-      for (int q = 0; q < 4; ++q) P[b][q] = Gl[(16 * b + 4 * q + lg) * LD + 16 * c + li];
-    tri_chain<NT, 1>(Bm, Vl, LD, P, li, lg);
-    tri_chain<NT, 0>(Cm, Vl, LD, Bm, li, lg);
-#pragma unroll
-    for (int b = 0; b < NT; ++b)
-#pragma unroll
-      for (int q = 0; q < 4; ++q) P[b][q] = Vl[(16 * c + li) * LD + 16 * b + 4 * q + lg];   // Vt^T panel
-    tri_chain<NT, 0>(VV, Vl, LD, P, li, lg);
-  }
-  __syncthreads();
-#pragma unroll
-  for (int a = 0; a < NT; ++a)
-#pragma unroll
-    for (int q = 0; q < 4; ++q) Cs[(16 * a + 4 * q + lg) * LD + 16 * c + li] = Cm[a][q];
-  __syncthreads();
-  // ---- At (in place over Gt): each element is read and written by exactly one lane; the transposed reads of Gt
-  //      itself do not occur (only C is read transposed), so no wave sees a half-updated panel
-#pragma unroll
-  for (int a = 0; a < NT; ++a)
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      int i = 16 * a + 4 * q + lg, j = 16 * c + li;
-      double v = -0.5 * (gt[i] * ul[j] + ul[i] * gt[j]) + 0.5 * ul[i] * ul[j] + Gl[i * LD + j] +
-                 0.5 * (VV[a][q] - (i == j ? 1.0 : 0.0)) - Cs[i * LD + j] - Cs[j * LD + i];
-      Gl[i * LD + j] = v;
-    }
-  __syncthreads();
-  // ---- panel c of A = Linv^T At Linv, contracted on the fly with dKzz/dZ and dKzz/dtheta
-  {
-    d4 P[NT], Dm[NT], Am[NT];
-#pragma unroll
-    for (int b = 0; b < NT; ++b)
-#pragma unroll
-      for (int q = 0; q < 4; ++q) P[b][q] = Li[(16 * b + 4 * q + lg) * LD + 16 * c + li];
-#pragma unroll
-    for (int a = 0; a < NT; ++a) {
-      d4 acc = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-      for (int b = 0; b < NT; ++b)
-        if (b >= c) {   // Linv lower triangular
-#pragma unroll
-          for (int q = 0; q < 4; ++q)
-            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(Gl[(16 * a + li) * LD + 16 * b + 4 * q + lg], P[b][q], acc, 0, 0, 0);
-        }
-      Dm[a] = acc;
-    }
-    tri_chain<NT, 1>(Am, Li, LD, Dm, li, lg);
-    const double zc = zl[16 * c + li];
-    double t0 = 0.0, t1 = 0.0;
-#pragma unroll
-    for (int a = 0; a < NT; ++a)
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        int i = 16 * a + 4 * q + lg, j = 16 * c + li;
-        double gz = 0.0;
-        if (i < M && j < M) {
-          double kt, bz, b0, b1;
-          kern_eval<KT>(zl[i] - zc, p, kt, bz, b0, b1);
-          double ak = Am[a][q] * kt;
-          gz = -(ak * bz);
-          t0 = fma(ak, b0, t0);
-          t1 = fma(ak, b1, t1);
-        }
-        gz = row16_sum(gz);
-        if (li == 0) redz[c * MP + i] = gz;
-      }
-    t0 = wave_sum(t0);
-    t1 = wave_sum(t1);
-    if (lane == 0) {
-      redt[2 * c + 0] = t0;
-      redt[2 * c + 1] = t1;
-    }
-  }
-  __syncthreads();
-  if ((mask & 8u) && tid < M) {
-    double g = 0.0;
-#pragma unroll
-    for (int w = 0; w < NT; ++w) g += redz[w * MP + tid];     // fixed panel order
-    // direct spike part a_j cz P1_j is already on this thread
-    pt.g_Z[(long long)r * M + tid] = g * 2.0 * p.cz + ev.gZq[vbase + tid] + a_l * p.cz * p1sum;
-  }
-  if (tid == 0) {
-    double t0 = 0.0, t1 = 0.0;
-#pragma unroll
-    for (int w = 0; w < NT; ++w) {
-      t0 += redt[2 * w + 0];
-      t1 += redt[2 * w + 1];
-    }
-    ev.gthitem[item * 2 + 0] = t0 * p.c0 + ev.gthq[item * 2 + 0] + p.c0 * tp0;
-    ev.gthitem[item * 2 + 1] = t1 * p.c1 + ev.gthq[item * 2 + 1] + p.c1 * tp1;
-  }
+    times_fwd_body<NT, SV_PERIODIC>(ev, r, k, times, toff, nper, mu_out, var_out, os_r, os_t, os_k, want_var, sm);
 }
 
 // ----------------------------------------------------------------------------- k_prep_mfma
@@ -795,28 +301,41 @@ __device__ __forceinline__ void quad_ell_mfma_body(const EngineView& ev, const d
   const int lrows_tot = (ROLE == 0) ? Q : N;
 
   // fill rows [row0, row0 + Lrows) of the looped matrix: zero the padding, then batched independent loads
-  // (8 in flight per thread) over the contiguous sources mu/var [Q x K] (ROLE 0) or C [N x K] (ROLE 1)
+  // (8 in flight per thread).  ROLE 0: the trial's statistics mu / var, stored [k][q] (K runs of nrow contiguous nodes);
+  // ROLE 1: C [N x K], contiguous
   auto fill_lm = [&](int row0) {
     for (int e = tid; e < (Lrows + 1) * LDK; e += NTH) LM[e] = 0.0;
     __syncthreads();
     const int nrow = (lrows_tot - row0 < Lrows) ? (lrows_tot - row0) : Lrows;
     const int tot = nrow * K;
-    const double* s0 = ((ROLE == 0) ? ev.muq + (long long)r * Q * K : C) + (long long)row0 * K;
-    const double* s1 = ((ROLE == 0) ? ev.varq + (long long)r * Q * K : C) + (long long)row0 * K;
+    const double* s0 = (ROLE == 0) ? ev.muq + (long long)r * Q * K + row0 : C + (long long)row0 * K;
+    const double* s1 = (ROLE == 0) ? ev.varq + (long long)r * Q * K + row0 : s0;
     for (int b0 = 0; b0 < tot; b0 += NTH * 8) {
       double v0[8], v1[8];
 #pragma unroll
       for (int u = 0; u < 8; ++u) {
         const int idx = b0 + u * NTH + tid;
         const bool ok = idx < tot;
-        v0[u] = ok ? s0[idx] : 0.0;
-        v1[u] = (ROLE == 0) ? (ok ? s1[idx] : 0.0) : v0[u];
+        long long src = idx;
+        if (ROLE == 0) {
+          const int kk = idx / nrow;
+          src = (long long)kk * Q + (idx - kk * nrow);
+        }
+        v0[u] = ok ? s0[src] : 0.0;
+        v1[u] = (ROLE == 0) ? (ok ? s1[src] : 0.0) : v0[u];
       }
 #pragma unroll
       for (int u = 0; u < 8; ++u) {
         const int idx = b0 + u * NTH + tid;
         if (idx < tot) {
-          const int row = idx / K, c = idx - row * K;
+          int row, c;
+          if (ROLE == 0) {
+            c = idx / nrow;
+            row = idx - c * nrow;
+          } else {
+            row = idx / K;
+            c = idx - row * K;
+          }
           if (ROLE == 0) {
             LM[row * LDK + c] = v0[u];
             LM[row * LDK + K + c] = v1[u];
@@ -840,29 +359,41 @@ __device__ __forceinline__ void quad_ell_mfma_body(const EngineView& ev, const d
   for (int ot0 = part * NW; ot0 < OT; ot0 += parts * NW) {     // block-uniform rounds; wave `wave` owns tile ot0 + wave
     const int ot = ot0 + wave;
     const bool active = ot < OT;
-    // own 16 rows -> per-wave LDS slice (wave-local: no block barrier needed); the source rows are
-    // contiguous (16 K doubles): batched loads again
+    // own 16 rows -> per-wave LDS slice (wave-local: no block barrier needed).  ROLE 0: 16 rows of C, contiguous
+    // (16 K doubles); ROLE 1: the tile's 16 nodes of mu / var, K runs of nrow contiguous values ([k][q] layout)
     for (int e = lane; e < 16 * LDK; e += 64) ow[e] = 0.0;
     lds_wave_fence();
     if (active) {
       const int orows = (ROLE == 0) ? N : Q;
       const int nrow = (orows - ot * 16 < 16) ? (orows - ot * 16) : 16;
       const int tot = nrow * K;
-      const double* s0 = (ROLE == 0) ? C + (long long)ot * 16 * K : ev.muq + ((long long)r * Q + ot * 16) * K;
-      const double* s1 = (ROLE == 0) ? s0 : ev.varq + ((long long)r * Q + ot * 16) * K;
+      const double* s0 = (ROLE == 0) ? C + (long long)ot * 16 * K : ev.muq + (long long)r * Q * K + ot * 16;
+      const double* s1 = (ROLE == 0) ? s0 : ev.varq + (long long)r * Q * K + ot * 16;
       double v0[8], v1[8];
 #pragma unroll
       for (int u = 0; u < 8; ++u) {
         const int idx = u * 64 + lane;
         const bool ok = idx < tot;
-        v0[u] = ok ? s0[idx] : 0.0;
-        v1[u] = (ROLE == 0) ? v0[u] : (ok ? s1[idx] : 0.0);
+        long long src = idx;
+        if (ROLE == 1) {
+          const int kk = idx / nrow;
+          src = (long long)kk * Q + (idx - kk * nrow);
+        }
+        v0[u] = ok ? s0[src] : 0.0;
+        v1[u] = (ROLE == 0) ? v0[u] : (ok ? s1[src] : 0.0);
       }
 #pragma unroll
       for (int u = 0; u < 8; ++u) {
         const int idx = u * 64 + lane;
         if (idx < tot) {
-          const int row = idx / K, c = idx - row * K;
+          int row, c;
+          if (ROLE == 0) {
+            row = idx / K;
+            c = idx - row * K;
+          } else {
+            c = idx / nrow;
+            row = idx - c * nrow;
+          }
           if (ROLE == 0) {
             ow[row * LDK + c] = v0[u] * L2E;
             ow[row * LDK + K + c] = 0.5 * v0[u] * v0[u] * L2E;
@@ -932,14 +463,14 @@ __device__ __forceinline__ void quad_ell_mfma_body(const EngineView& ev, const d
             if (kk < K2) ev.gCpart[((long long)r * N + oi) * K2 + kk] = acc[t][q];
           }
       } else {
-        const long long gi = ((long long)r * Q + oi) * K;
+        const long long gi = (long long)r * Q * K + oi;        // [r][k][q]: the 16 nodes of the tile are contiguous
 #pragma unroll
         for (int t = 0; t < KKT; ++t)
 #pragma unroll
           for (int q = 0; q < 4; ++q) {
             const int kk = 16 * t + lg + 4 * q;
-            if (kk < K) ev.gmuq[gi + kk] = -acc[t][q] * LN2;
-            else if (kk < K2) ev.gvarq[gi + kk - K] = -acc[t][q] * LN2;
+            if (kk < K) ev.gmuq[gi + (long long)kk * Q] = -acc[t][q] * LN2;
+            else if (kk < K2) ev.gvarq[gi + (long long)(kk - K) * Q] = -acc[t][q] * LN2;
           }
       }
     }

@@ -376,93 +376,6 @@ __global__ void k_mseg(EngineView ev) {
   ev.Mseg[id] = s;
 }
 
-#define SV_FIN_OUT 8   // outputs per block of k_finalize
-#define SV_FIN_GRP 32   // trial groups per block (256 threads): 8 x 32 measured best on cfg3: 16 us (32 x 8: 45, 16 x 16: 24, 4 x 64: 20)
-// ------------------------------------------------------------------------------ k_finalize
-// Fixed-order reductions of the per-trial partials into the `shared` output vector
-// [ELBO, ELL, KL, dC (N*K), dd (N), dtheta].  Block roles by blockIdx:
-//   [0, nbC)            dC : SV_FIN_OUT outputs x SV_FIN_GRP trial groups per block; each thread sums its trials'
-//                            quadrature and spike partials, then the groups are added in order
-//                            through LDS
-//   [nbC, nbC+nbD)      dd, [.., +nbT) dtheta : same scheme
-//   last block          the three scalars
-__global__ __launch_bounds__(256) void k_finalize(EngineView ev, const double* C, const double* d, unsigned mask,
-                                                  double* shared) {
-  __shared__ double red[SV_FIN_GRP * SV_FIN_OUT];
-  const int tid = threadIdx.x, o = tid % SV_FIN_OUT, pg = tid / SV_FIN_OUT;
-  const int NK = ev.N * ev.K, N = ev.N, K = ev.K, R = ev.R;
-  const int nbC = (NK + SV_FIN_OUT - 1) / SV_FIN_OUT, nbD = (N + SV_FIN_OUT - 1) / SV_FIN_OUT,
-            nbT = (ev.nth_total + SV_FIN_OUT - 1) / SV_FIN_OUT;
-  int blk = blockIdx.x;
-  if (blk == nbC + nbD + nbT) {
-    double e = 0.0, kl = 0.0;
-    for (int i = tid; i < ev.nell; i += 256) e += ev.ellq[i];
-    for (int i = tid; i < R * K; i += 256) {
-      e += ev.ells[i];
-      kl += ev.klpart[i];
-    }
-    for (int n = tid; n < N; n += 256) e += ev.spk_cnt[n] * d[n];
-    e = block_sum(e, red);
-    kl = block_sum(kl, red);
-    if (tid == 0) {
-      shared[0] = e - kl;
-      shared[1] = e;
-      shared[2] = kl;
-    }
-    return;
-  }
-  double s = 0.0;
-  int out = -1;
-  if (blk < nbC) {
-    const int id = blk * SV_FIN_OUT + o;
-    if (id < NK) {
-      out = 3 + id;
-      if (mask & 2u) {
-        const int n = id / K, k = id % K;
-        const double cnk = C[id];
-        for (int r = pg; r < R; r += SV_FIN_GRP) s += ev.gCspk[(long long)r * NK + id];
-        for (int b = pg; b < ev.ncd; b += SV_FIN_GRP) {      // dC = -(E^T mu + C . E^T var)
-          const long long o = ((long long)b * N + n) * 2 * K + k;
-          s -= ev.gCpart[o] + cnk * ev.gCpart[o + K];
-        }
-        if (pg == 0)
-          for (int l = 0; l < ev.nsplit; ++l) {
-            const int ch = ev.split_chunks[l];
-            if (ev.chunks[ch].neuron == n) s += ev.splitPart[(long long)ch * K + k];
-          }
-      }
-    }
-  } else if (blk < nbC + nbD) {
-    const int n = (blk - nbC) * SV_FIN_OUT + o;
-    if (n < N) {
-      out = 3 + NK + n;
-      if (mask & 2u) {
-        for (int b = pg; b < ev.ncd; b += SV_FIN_GRP) s += ev.gdpart[(long long)b * N + n];
-        if (pg == 0) s += ev.spk_cnt[n];
-      }
-    }
-  } else {
-    const int ti = (blk - nbC - nbD) * SV_FIN_OUT + o;
-    if (ti < ev.nth_total) {
-      out = 3 + NK + N + ti;
-      if (mask & 4u) {
-        int k = 0;
-        while (k + 1 < K && ev.meta[k + 1].thoff <= ti) ++k;
-        const int t = ti - ev.meta[k].thoff;
-        for (int r = pg; r < R; r += SV_FIN_GRP) s += ev.gthitem[((long long)r * K + k) * 2 + t];
-      }
-    }
-  }
-  red[pg * SV_FIN_OUT + o] = s;
-  __syncthreads();
-  if (pg == 0 && out >= 0) {
-    double t = red[o];
-#pragma unroll
-    for (int g = 1; g < SV_FIN_GRP; ++g) t += red[g * SV_FIN_OUT + o];
-    shared[out] = t;
-  }
-}
-
 // ELL with frozen latent stats (embedding M-step closure): out = [ELL, dC, dd]
 __global__ __launch_bounds__(256) void k_finalize_stats(EngineView ev, const double* C, const double* d,
                                                         int want_grad, double* out) {
@@ -497,11 +410,3 @@ __global__ __launch_bounds__(256) void k_finalize_stats(EngineView ev, const dou
   }
 }
 
-// [K][S] -> [S][K] copy for the stats API
-__global__ void k_transpose_ks(const double* in, double* out, long long S, int K) {
-  long long id = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (id >= S * K) return;
-  long long s = id / K;
-  int k = (int)(id % K);
-  out[id] = in[(long long)k * S + s];
-}

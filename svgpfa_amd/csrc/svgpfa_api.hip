@@ -10,14 +10,15 @@
 #include <vector>
 
 #include "engine_common.h"
+#include "kernels_getters.h"
 #include "kernels_item.h"
+#include "kernels_item_bwd.h"
 #include "kernels_mfma.h"
 #include "kernels_spike.h"
-#include "kernels_times.h"
 
 typedef LatentPtrTable PtrTable;
 
-// k_prep / k_bwd read the caller's per-latent tensors: the pointer table travels by value in
+// k_prep / k_item_bwd read the caller's per-latent tensors: the pointer table travels by value in
 // the kernarg segment, so nothing has to be staged through HBM when the caller's tensors move.
 
 struct svgpfa_engine {
@@ -30,7 +31,7 @@ struct svgpfa_engine {
   int ell_parts = 0, KKT = 1;  // ell_parts > 0: MFMA GEMM form of the quadrature term
   int ell_lc[2] = {0, 0};      // looped tiles resident in LDS per role (fewer than all: streamed in chunks)
   int ell_nw = 4;              // waves per block of the ELL kernels
-  int tile_nw = 4;             // waves per block of k_quad_bwd: 2 when R K >= 2048 and M <= 32 (13 tiles of Q = 200 split
+  int tile_nw = 4;             // waves per block of k_item_bwd: 2 when R K >= 2048 and M <= 32 (13 tiles of Q = 200 split
                                // 7 + 6 instead of 4 + 3 + 3 + 3: 226 -> 203 us on cfg3), else 4 (shorter per-block latency).
                                // k_times_fwd stays at 4 (2 measured slower: 107 vs 101 us)
   long long totM = 0, totMM = 0;  // R*sum M, R*sum M^2
@@ -96,10 +97,7 @@ static size_t lds_times_mfma(int NT) {
   size_t MP = 16 * NT, LD = MP + 2;
   return (2 * MP * LD + 4 * MP) * 8;
 }
-static size_t lds_qbwd_mfma(int NT, int NWB = 4) {
-  size_t MP = 16 * NT, LD = MP + 2, W = NWB;
-  return (2 * MP * LD + 2 * MP + W * 16 * LD + W * 16 + W * 2 * MP + W * 2 + 2 * MP) * 8;
-}
+static size_t lds_item_bwd(int NT, int NWB = 4) { return sv_item_bwd_lds_doubles(NT, NWB) * 8; }
 #define DISPATCH_NT(nt, ...)                                 \
   switch (nt) {                                              \
     case 1: { constexpr int NT_ = 1; __VA_ARGS__; } break;   \
@@ -131,22 +129,9 @@ static size_t lds_qell_mfma(const svgpfa_engine* e, int role) { return lds_qell_
     case 13: { constexpr int KS_ = 13; __VA_ARGS__; } break; case 14: { constexpr int KS_ = 14; __VA_ARGS__; } break; \
     case 15: { constexpr int KS_ = 15; __VA_ARGS__; } break; default: { constexpr int KS_ = 16; __VA_ARGS__; } break; \
   }
-template <int NT>
-__global__ __launch_bounds__(64 * NT) void k_bwd_mfma(EngineView ev, PtrTable pt, unsigned mask) {
-  extern __shared__ double sm[];
-  const int r = blockIdx.x / ev.K, k = blockIdx.x % ev.K;
-  if (ev.meta[k].ktype == SV_RBF)
-    bwd_mfma_body<NT, SV_RBF>(ev, r, k, pt.p[k], mask, sm);
-  else
-    bwd_mfma_body<NT, SV_PERIODIC>(ev, r, k, pt.p[k], mask, sm);
-}
 static size_t lds_prep_mfma(int NT) {
   size_t MP = 16 * NT, LD = MP + 2;
   return (2 * MP * LD + NT) * 8;
-}
-static size_t lds_bwd_mfma(int NT) {
-  size_t MP = 16 * NT, LD = MP + 2;
-  return (3 * MP * LD + 4 * MP + NT * MP + 2 * NT) * 8;
 }
 
 template <typename F>
@@ -214,8 +199,6 @@ int svgpfa_create(const svgpfa_dims* d, int device, svgpfa_engine** out) {
   DALLOC(e, v.a, e->totM); DALLOC(e, v.ut, e->totM); DALLOC(e, v.Vt, e->totMM); DALLOC(e, v.klpart, (size_t)v.R * v.K);
   size_t rqk = (size_t)v.R * v.Q * v.K;
   DALLOC(e, v.muq, rqk); DALLOC(e, v.varq, rqk); DALLOC(e, v.gmuq, rqk); DALLOC(e, v.gvarq, rqk);
-  DALLOC(e, v.gaq, e->totM); DALLOC(e, v.GW, e->totMM); DALLOC(e, v.gZq, e->totM);
-  DALLOC(e, v.gthq, (size_t)v.R * v.K * 2);
   e->KKT = (2 * v.K + 3) / 4;   // KS: k-steps of the h product
   // blocks per trial of the ELL kernels: every block re-stages the trial's looped operand in LDS, so fewer blocks
   // per trial are cheaper as long as the grid still fills the chip (measured on cfg3: 1 -> 151 us, 4 -> 168 us)
@@ -239,10 +222,8 @@ int svgpfa_create(const svgpfa_dims* d, int device, svgpfa_engine** out) {
   DALLOC(e, v.Mseg, (size_t)v.N * v.K);
   DALLOC(e, v.status, 1);
   HIPCHK(e, hipMemset(v.status, 0, sizeof(int)));
-  HIPCHK(e, hipMemset(v.gaq, 0, sizeof(double) * e->totM));
-  HIPCHK(e, hipMemset(v.GW, 0, sizeof(double) * e->totMM));
-  HIPCHK(e, hipMemset(v.gZq, 0, sizeof(double) * e->totM));
-  HIPCHK(e, hipMemset(v.gthq, 0, sizeof(double) * v.R * v.K * 2));
+  DALLOC(e, v.fin_ticket, 1);
+  HIPCHK(e, hipMemset(v.fin_ticket, 0, sizeof(unsigned)));
   HIPCHK(e, hipHostMalloc((void**)&e->status_host, sizeof(int)));
   HIPCHK(e, hipStreamCreateWithFlags(&e->s_side, hipStreamNonBlocking));
   {
@@ -256,10 +237,9 @@ int svgpfa_create(const svgpfa_dims* d, int device, svgpfa_engine** out) {
 
   int rc = 0;
   DISPATCH_NT(e->NT, rc = allow_lds(e, (k_prep_mfma<NT_>), lds_prep_mfma(NT_));
-              if (!rc) rc = allow_lds(e, (k_bwd_mfma<NT_>), lds_bwd_mfma(NT_));
               if (!rc) rc = allow_lds(e, (k_times_fwd_mfma<NT_>), lds_times_mfma(NT_));
-              if (!rc) rc = allow_lds(e, (k_quad_bwd_mfma<NT_, true>), lds_qbwd_mfma(NT_));
-              if (!rc) rc = allow_lds(e, (k_quad_bwd_mfma<NT_, false>), lds_qbwd_mfma(NT_)));
+              if (!rc) rc = allow_lds(e, (k_item_bwd<NT_, true>), lds_item_bwd(NT_));
+              if (!rc) rc = allow_lds(e, (k_item_bwd<NT_, false>), lds_item_bwd(NT_)));
   if (rc) return rc;
   DISPATCH_KS(e->KKT, rc = allow_lds(e, (k_quad_ell_mfma<KS_, 0>), lds_qell_mfma(e, 0));
               if (!rc) rc = allow_lds(e, (k_quad_ell_mfma<KS_, 2>), std::max(lds_qell_mfma(e, 0), lds_qell_mfma(e, 1))));
@@ -504,10 +484,11 @@ static int launch_quad_ell(svgpfa_engine* e, const double* C, const double* d, i
 }
 
 static int launch_times(svgpfa_engine* e, const double* times, const long long* toff, int nper, double* mu,
-                        double* var, long long os_t, long long os_k, int want_var) {
+                        double* var, long long os_r, long long os_t, long long os_k, int want_var) {
   EngineView& v = e->v;
   DISPATCH_NT(e->NT, hipLaunchKernelGGL((k_times_fwd_mfma<NT_>), dim3(v.R * v.K), dim3(256),
-                                        lds_times_mfma(NT_), e->stream, v, times, toff, nper, mu, var, os_t, os_k, want_var));
+                                        lds_times_mfma(NT_), e->stream, v, times, toff, nper, mu, var, os_r, os_t, os_k,
+                                        want_var));
   HIPCHK(e, hipGetLastError());
   return SVGPFA_OK;
 }
@@ -515,6 +496,12 @@ static int launch_times(svgpfa_engine* e, const double* times, const long long* 
 static void launch_prep(svgpfa_engine* e, const PtrTable& pt) {   // one wavefront per 16-column panel
   EngineView& v = e->v;
   DISPATCH_NT(e->NT, hipLaunchKernelGGL(k_prep_mfma<NT_>, dim3(v.R * v.K), dim3(64 * NT_), lds_prep_mfma(NT_), e->stream, v, pt));
+}
+
+// quadrature statistics into the engine's [r][k][q] buffers
+static int launch_times_quad(svgpfa_engine* e) {
+  EngineView& v = e->v;
+  return launch_times(e, v.tq, nullptr, v.Q, v.muq, v.varq, (long long)v.K * v.Q, 1LL, (long long)v.Q, 1);
 }
 
 static int check_ready(svgpfa_engine* e) {
@@ -575,24 +562,18 @@ int svgpfa_elbo(svgpfa_engine* e, const double* const* mean, const double* const
     if (evp) HIPCHK(e, hipEventRecord(evp->second, sk));
     if (side) HIPCHK(e, hipEventRecord(e->ev_spk, sk));
   }
-  // ---- quadrature chain (f64 MFMA): posterior stats -> ELL term -> adjoints
-  if ((rc = launch_times(e, v.tq, nullptr, v.Q, v.muq, v.varq, (long long)v.K, 1LL, 1))) return rc;
+  // ---- quadrature chain (f64 MFMA): posterior stats -> ELL term
+  if ((rc = launch_times_quad(e))) return rc;
   if ((rc = launch_quad_ell(e, C, d, (mask & 2u) ? 1 : 0, want_lat ? 1 : 0))) return rc;
-  if (want_lat) {
-    if (mask & (4u | 8u)) {
-      DISPATCH_NT(e->NT, hipLaunchKernelGGL((k_quad_bwd_mfma<NT_, true>), dim3(v.R * v.K), dim3(64 * e->tile_nw),
-                                            lds_qbwd_mfma(NT_, e->tile_nw), sm, v));
-    } else {
-      DISPATCH_NT(e->NT, hipLaunchKernelGGL((k_quad_bwd_mfma<NT_, false>), dim3(v.R * v.K), dim3(64 * e->tile_nw),
-                                            lds_qbwd_mfma(NT_, e->tile_nw), sm, v));
-    }
-  }
-  // ---- join the spike pass, per-item backward, then the fixed-order reductions
+  // ---- join the spike pass; per-item adjoints + backward + the fixed-order cross-trial reductions in one kernel
   if (side) HIPCHK(e, hipStreamWaitEvent(sm, e->ev_spk, 0));
-  DISPATCH_NT(e->NT, hipLaunchKernelGGL((k_bwd_mfma<NT_>), dim3(v.R * v.K), dim3(64 * NT_), lds_bwd_mfma(NT_), sm, v, pt, mask));
-  int nfin = (v.N * v.K + SV_FIN_OUT - 1) / SV_FIN_OUT + (v.N + SV_FIN_OUT - 1) / SV_FIN_OUT +
-             (v.nth_total + SV_FIN_OUT - 1) / SV_FIN_OUT + 1;
-  hipLaunchKernelGGL(k_finalize, dim3(nfin), dim3(256), 0, e->stream, v, C, d, mask, shared);
+  if (mask & (4u | 8u)) {
+    DISPATCH_NT(e->NT, hipLaunchKernelGGL((k_item_bwd<NT_, true>), dim3(v.R * v.K), dim3(64 * e->tile_nw),
+                                          lds_item_bwd(NT_, e->tile_nw), sm, v, pt, mask, C, d, shared));
+  } else {
+    DISPATCH_NT(e->NT, hipLaunchKernelGGL((k_item_bwd<NT_, false>), dim3(v.R * v.K), dim3(64 * e->tile_nw),
+                                          lds_item_bwd(NT_, e->tile_nw), sm, v, pt, mask, C, d, shared));
+  }
   HIPCHK(e, hipGetLastError());
   return SVGPFA_OK;
 }
@@ -607,12 +588,15 @@ int svgpfa_latent_stats(svgpfa_engine* e, const double* const* mean, const doubl
   PtrTable pt;
   if ((rc = fill_ptrs(e, pt, mean, cholvec, nullptr, nullptr, nullptr, 0))) return rc;
   launch_prep(e, pt);
-  if ((rc = launch_times(e, v.tq, nullptr, v.Q, v.muq, v.varq, (long long)v.K, 1LL, 1))) return rc;
-  if ((rc = launch_times(e, v.spk_t, v.spk_off, 0, v.muspk, v.varspk, 1LL, (long long)v.S, 1))) return rc;
+  if ((rc = launch_times_quad(e))) return rc;
+  if ((rc = launch_times(e, v.spk_t, v.spk_off, 0, v.muspk, v.varspk, 0LL, 1LL, (long long)v.S, 1))) return rc;
   hipLaunchKernelGGL(k_mseg, dim3((v.N * v.K + 255) / 256), dim3(256), 0, e->stream, v);
-  size_t rqk = sizeof(double) * v.R * v.Q * v.K;
-  if (mu_quad) HIPCHK(e, hipMemcpyAsync(mu_quad, v.muq, rqk, hipMemcpyDeviceToDevice, e->stream));
-  if (var_quad) HIPCHK(e, hipMemcpyAsync(var_quad, v.varq, rqk, hipMemcpyDeviceToDevice, e->stream));
+  {   // the engine keeps [r][k][q]; the caller gets the reference's [r][q][k]
+    const long long rqk = (long long)v.R * v.Q * v.K;
+    const unsigned g = (unsigned)((rqk + 255) / 256);
+    if (mu_quad) hipLaunchKernelGGL(k_transpose_rkq, dim3(g), dim3(256), 0, e->stream, v.muq, mu_quad, v.R, v.K, v.Q);
+    if (var_quad) hipLaunchKernelGGL(k_transpose_rkq, dim3(g), dim3(256), 0, e->stream, v.varq, var_quad, v.R, v.K, v.Q);
+  }
   long long tot = (long long)v.S * v.K;
   if (tot > 0) {
     unsigned g = (unsigned)((tot + 255) / 256);
@@ -647,7 +631,9 @@ int svgpfa_predict(svgpfa_engine* e, const double* const* mean, const double* co
   int rc;
   if ((rc = fill_ptrs(e, pt, mean, cholvec, nullptr, nullptr, nullptr, 0))) return rc;
   launch_prep(e, pt);
-  if ((rc = launch_times(e, times, nullptr, (int)T, mu, var ? var : mu, (long long)v.K, 1LL, var ? 1 : 0))) return rc;
+  if ((rc = launch_times(e, times, nullptr, (int)T, mu, var ? var : mu, (long long)T * v.K, (long long)v.K, 1LL,
+                         var ? 1 : 0)))
+    return rc;
   HIPCHK(e, hipGetLastError());
   e->have_stats = false;  // k_prep overwrote a / W with these parameters; stats must be recomputed
   return SVGPFA_OK;
@@ -707,6 +693,7 @@ int svgpfa_enable_timing(svgpfa_engine* e, int on) {
 int svgpfa_spike_kernel_ms(svgpfa_engine* e, double* total_ms, int32_t* launches) {
   if (!e || !total_ms || !launches) return SVGPFA_ERR_INVALID;
   HIPCHK(e, hipStreamSynchronize(e->stream));
+  if (e->s_side) HIPCHK(e, hipStreamSynchronize(e->s_side));   // the event pairs live there when the pass is overlapped
   double tot = 0.0;
   for (size_t i = 0; i < e->ev_used; ++i) {
     float ms = 0.f;
