@@ -7,7 +7,8 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libsvgpfa_hip.so")
+# SVGPFA_LIB: diagnosis builds of the same library (tests/tools), never a different implementation
+LIB_PATH = os.environ.get("SVGPFA_LIB") or os.path.join(_HERE, "csrc", "libsvgpfa_hip.so")
 
 OK, ERR_INVALID, ERR_NOT_PD, ERR_HIP, ERR_STATE, ERR_UNSUPPORTED = range(6)
 KERNEL_RBF, KERNEL_PERIODIC = 0, 1

@@ -93,7 +93,8 @@ struct EngineView {
   double* ells; double* gthitem;                   // [R*K], [R*K*2]
   double* Mseg;                                    // [N][K] sum over spikes of mu_spk per neuron (stats path)
   int* status;
-  unsigned* fin_ticket;       // blocks of k_item_bwd that have finished (the last one does the cross-trial sums)
+  unsigned* fin_ticket;       // k_fin_items: scalar blocks that have finished (zero at rest)
+  double* fin_part;           // [0] ELL terms known before k_item_bwd, [1] KL, [2 + b] spike-ELL partial of scalar block b
 };
 
 // ------------------------------------------------------------------ covariance functions

@@ -3,20 +3,23 @@
 //            Z / theta through kappa(t_q, Z)                       (was k_quad_bwd_mfma)
 //   phase 2  backward through the whitened algebra: gradients wrt m, cholVecs, Z, theta of the item
 //            (derivation: kernels_item.h header)                  (was k_bwd_mfma)
-//   phase 3  the fixed-order reductions of the per-trial partials into the `shared` vector
-//            [ELBO, ELL, KL, dC, dd, dtheta]                      (was k_finalize)
+//   phase 3  the fixed-order reductions of the per-trial dC / dd partials into the `shared` vector
+//            [ELBO, ELL, KL, dC, dd, dtheta]                      (was most of k_finalize; the rest: k_fin_items)
 // Linv, a, ut, Z and the adjoints gt / Gt stay in LDS between phases 1 and 2 (the two-kernel version wrote Gt to HBM and
 // re-staged Linv / Gt: 164 MB and a 34 us fill phase per evaluation at the north-star size).
-// Phase 3: the dC / dd sums only read partials of EARLIER kernels (spike pass, ELL kernel), so they are dealt out over
-// the blocks of this grid; the dtheta sums and the three scalars need this kernel's own per-item results and are done
-// by the block that finishes last (ticket counter; agent-scope release before the ticket, acquire after it).  Every sum
-// keeps a fixed order, so results stay bit-reproducible.
+// Phase 3: the dC / dd sums (and the KL / quadrature-ELL scalars) only read partials of EARLIER kernels (spike pass, ELL
+// kernel, k_prep), so they are dealt out over the blocks of this grid; dtheta and the spike ELL need this kernel's own
+// per-item results and are summed by the small k_fin_items launch behind it.  Every sum keeps a fixed order, so results
+// stay bit-reproducible.
 // Replaces autograd backward of the reference (stats/svEM.py:274-288) for stats/svPosteriorOnLatents.py:185-216,
 // stats/klDivergence.py:18-44, stats/kernelsMatricesStore.py:107-117.
 #pragma once
 #include "engine_common.h"
 #include "kernels_mfma.h"
 
+#ifndef SV_BWD_STOP
+#define SV_BWD_STOP 0   // diagnosis builds only (tests/tools/phase_times.sh): 1 stop after phase 1, 2 after the spike gather, 3 before phase 3
+#endif
 #define SV_FIN_OUT 8   // outputs per reduction group of phase 3 (8 consecutive doubles = one 64-B segment per trial)
 
 // stride (doubles) of the per-wave transpose scratch of phase 1: rows are written with lane -> row (stride LDS2) and
@@ -24,10 +27,12 @@
 // up to one bank (the old stride MP + 2 cost a 2-way conflict on every transposed ds_read_b64)
 __host__ __device__ constexpr int sv_tr_stride(int MP) { return ((MP + 14) / 32) * 32 + 17; }
 
+// LDS of one block (doubles).  The transpose scratch of phase 1 and the Gt / At matrix of phase 2 share one region:
+// at the north-star shape (NT = 2, 2 waves) a block needs 34 KB, so four blocks (8 waves) stay resident per CU.
 __host__ __device__ constexpr size_t sv_item_bwd_lds_doubles(int NT, int NWB) {
   const size_t MP = 16 * NT, LD = MP + 2, L2 = sv_tr_stride(16 * NT);
-  const size_t S = (NWB * 16 * L2 > MP * MP) ? NWB * 16 * L2 : MP * MP;
-  return 3 * MP * LD + S + 9 * MP + NWB * 16 + NWB * 2 * MP + NWB * 2 + NT * MP + 2 * NT + 8;
+  const size_t S = (NWB * 16 * L2 > MP * LD) ? NWB * 16 * L2 : MP * LD;
+  return 2 * MP * LD + S + 9 * MP + NWB * 16 + NWB * 2 * MP + NWB * 2 + NT * MP + 2 * NT + 8;
 }
 
 // ---- phase 3 -------------------------------------------------------------------------------------------------------
@@ -79,60 +84,85 @@ __device__ __forceinline__ void fin_cd_group(const EngineView& ev, const double*
   }
 }
 
-// The last block: dtheta (sums over trials of the per-item values) and [ELBO, ELL, KL].
-__device__ __forceinline__ void fin_last_block(const EngineView& ev, const double* d, unsigned mask, double* shared,
-                                               double* red) {
-  const int tid = threadIdx.x, NTH = blockDim.x, N = ev.N, K = ev.K, R = ev.R, NK = N * K;
+// Scalars that only need EARLIER kernels' partials (KL per item from k_prep, the quadrature ELL per block, sum_n count_n d_n):
+// summed by one designated block of k_item_bwd and left in fin_part[0..1] for k_fin_items (a later launch).
+__device__ __forceinline__ void fin_early_scalars(const EngineView& ev, const double* d, double* red) {
+  const int tid = threadIdx.x, NTH = blockDim.x, RK = ev.R * ev.K;
   double e = 0.0, kl = 0.0;
-  for (int i = tid; i < ev.nell; i += NTH) e += ev.ellq[i];
-  for (int i = tid; i < R * K; i += NTH) {
-    e += ev.ells[i];
-    kl += ev.klpart[i];
+  for (int i0 = 0; i0 < RK; i0 += 8 * NTH) {       // 8 independent loads in flight per thread, fixed order
+    double v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int i = i0 + u * NTH + tid;
+      v[u] = (i < RK) ? ev.klpart[i] : 0.0;
+    }
+    kl += ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
   }
-  for (int n = tid; n < N; n += NTH) e += ev.spk_cnt[n] * d[n];
+  for (int i = tid; i < ev.nell; i += NTH) e += ev.ellq[i];
+  for (int n = tid; n < ev.N; n += NTH) e += ev.spk_cnt[n] * d[n];
   e = block_sum(e, red);
   kl = block_sum(kl, red);
   if (tid == 0) {
-    shared[0] = e - kl;
-    shared[1] = e;
-    shared[2] = kl;
-  }
-  // dtheta: one wavefront per parameter, lanes over trials, fixed-order wave tree
-  const int lane = tid & 63, wave = tid >> 6, NW = NTH >> 6;
-  for (int ti = wave; ti < ev.nth_total; ti += NW) {
-    double s = 0.0;
-    if (mask & 4u) {
-      int k = 0;
-      while (k + 1 < K && ev.meta[k + 1].thoff <= ti) ++k;
-      const int t = ti - ev.meta[k].thoff;
-      for (int r = lane; r < R; r += 64) s += ev.gthitem[((long long)r * K + k) * 2 + t];
-      s = wave_sum(s);
-    }
-    if (lane == 0) shared[3 + NK + N + ti] = s;
+    ev.fin_part[0] = e;
+    ev.fin_part[1] = kl;
   }
 }
 
+// Phase 3 inside k_item_bwd: only sums whose inputs are complete when the kernel starts.
 __device__ __forceinline__ void fin_tail(const EngineView& ev, const double* C, const double* d, unsigned mask,
-                                         double* shared, double* red, int* flag) {
-  const int nbC = (ev.N * ev.K + SV_FIN_OUT - 1) / SV_FIN_OUT, nbD = (ev.N + SV_FIN_OUT - 1) / SV_FIN_OUT;
-  for (int g = blockIdx.x; g < nbC + nbD; g += gridDim.x) fin_cd_group(ev, C, mask, shared, g, red);
-  // hand-off of this block's per-item results (ells, gthitem) to the block that finishes last
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+                                         double* shared, double* red) {
+  const int NK = ev.N * ev.K;
+  const int nbC = (NK + SV_FIN_OUT - 1) / SV_FIN_OUT, nbD = (ev.N + SV_FIN_OUT - 1) / SV_FIN_OUT;
+  const int nblk = gridDim.x;
+  for (int g = blockIdx.x; g < nbC + nbD; g += nblk) fin_cd_group(ev, C, mask, shared, g, red);
+  if ((int)blockIdx.x == (nbC + nbD) % nblk) fin_early_scalars(ev, d, red);
+}
+
+// ---- k_fin_items: the sums that need k_item_bwd's own per-item results -- dtheta (sum over trials of the per-item values)
+// and the spike part of the ELL -- then [ELBO, ELL, KL].  A grid of its own, a few blocks: doing this behind a ticket at
+// the end of k_item_bwd made every one of its blocks wait for its last stores to land plus an atomic round trip
+// (+27..33 us at the north-star size, measured with stop-after-phase builds), a separate launch costs ~6 us.
+//   blocks [0, nth_total)      : one kernel parameter each
+//   blocks [nth_total, +NS)    : 1 / NS of the items' spike ELL each; the last of them to finish (ticket over NS blocks,
+//                                sc1 hand-off as in MI355X_MICROARCH.md) adds the NS partials in order and writes the scalars
+#define SV_FIN_NS 8
+__global__ __launch_bounds__(256) void k_fin_items(EngineView ev, unsigned mask, double* shared) {
+  __shared__ double red[4];
+  const int tid = threadIdx.x, K = ev.K, R = ev.R, RK = R * K, NK = ev.N * K, nth = ev.nth_total;
+  const int b = blockIdx.x;
+  if (b < nth) {
+    double s = 0.0;
+    if (mask & 4u) {
+      int k = 0;
+      while (k + 1 < K && ev.meta[k + 1].thoff <= b) ++k;
+      const int t = b - ev.meta[k].thoff;
+      for (int r = tid; r < R; r += 256) s += ev.gthitem[((long long)r * K + k) * 2 + t];
+    }
+    s = block_sum(s, red);
+    if (tid == 0) shared[3 + NK + ev.N + b] = s;
+    return;
+  }
+  const int part = b - nth;
+  const int i0 = (int)((long long)RK * part / SV_FIN_NS), i1 = (int)((long long)RK * (part + 1) / SV_FIN_NS);
+  double e = 0.0;
+  for (int i = i0 + tid; i < i1; i += 256) e += ev.ells[i];
+  e = block_sum(e, red);
+  if (tid == 0) {
+    __hip_atomic_store(&ev.fin_part[2 + part], e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     const unsigned t = __hip_atomic_fetch_add(ev.fin_ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    const int last = (t == gridDim.x - 1);
+    const int last = (t == SV_FIN_NS - 1);
     if (last) {
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __hip_atomic_store(ev.fin_ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
+      __hip_atomic_store(ev.fin_ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // for the next launch
+      double ell = ev.fin_part[0];                                                          // from k_item_bwd (earlier launch)
+      for (int q = 0; q < SV_FIN_NS; ++q)
+        ell += __hip_atomic_load(&ev.fin_part[2 + q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const double kl = ev.fin_part[1];
+      shared[0] = ell - kl;
+      shared[1] = ell;
+      shared[2] = kl;
     }
-    *flag = last;
   }
-  __syncthreads();
-  if (*flag) fin_last_block(ev, d, mask, shared, red);
 }
 
 // ---- phases 1 + 2 --------------------------------------------------------------------------------------------------
@@ -146,11 +176,11 @@ __device__ void item_bwd_body(const EngineView& ev, const int r, const int k, co
   const int item = r * ev.K + k;
   const LatentMeta m = ev.meta[k];
   const int M = m.M, Q = ev.Q, K = ev.K;
-  const size_t SZ = ((size_t)NWB * 16 * L2S > (size_t)MP * MP) ? (size_t)NWB * 16 * L2S : (size_t)MP * MP;
+  const size_t SZ = ((size_t)NWB * 16 * L2S > (size_t)MP * LD) ? (size_t)NWB * 16 * L2S : (size_t)MP * LD;
   double* Li = sm;                    // MP*LD  Linv
   double* Vl = Li + MP * LD;          // MP*LD  phase 1 (FULL): D = Linv^T (Vt Vt^T - I); phase 2: Vt, later C
-  double* Gl = Vl + MP * LD;          // MP*LD  phase 2: Gt, later At
-  double* S = Gl + MP * LD;           // SZ     phase 1: per-wave transpose scratch, then the MP x MP sum of Gt
+  double* S = Vl + MP * LD;           // SZ     phase 1: per-wave transpose scratch; then Gt summed over the waves
+  double* Gl = S;                     //        (symmetric, rows padded to LD: phase 2's Gt, later At)
   double* ul = S + SZ;                // MP     ut
   double* al = ul + MP;               // MP     a = Linv^T ut
   double* zl = al + MP;               // MP     Z
@@ -349,7 +379,8 @@ __device__ void item_bwd_body(const EngineView& ev, const int r, const int k, co
       tred[wave * 2 + 0] = th0;
       tred[wave * 2 + 1] = th1;
     }
-    __syncthreads();   // all waves done with their scratch (and with D): S becomes the MP x MP sum buffer
+    __syncthreads();   // all waves done with their scratch (and with D): the region becomes Gt, summed over the waves in
+                       // order, both triangles (tile (a, b), a > b, is mirrored into (b, a)), rows padded to LD
     for (int w = 0; w < NWB; ++w) {
       if (wave == w) {
         int t = 0;
@@ -359,11 +390,10 @@ __device__ void item_bwd_body(const EngineView& ev, const int r, const int k, co
           for (int b = 0; b <= a; ++b) {
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-              int row = 16 * a + lg + 4 * q, col = 16 * b + li;
-              if (w == 0)
-                S[row * MP + col] = GW[t][q];
-              else
-                S[row * MP + col] += GW[t][q];
+              const int row = 16 * a + lg + 4 * q, col = 16 * b + li;
+              const double v = (w == 0) ? GW[t][q] : Gl[row * LD + col] + GW[t][q];
+              Gl[row * LD + col] = v;
+              if (a != b) Gl[col * LD + row] = v;
             }
             ++t;
           }
@@ -397,12 +427,12 @@ __device__ void item_bwd_body(const EngineView& ev, const int r, const int k, co
       thq[0] = p.c0 * t0s;
       thq[1] = p.c1 * t1s;
     }
-    // stage Vt (phase 2 needs it; in the FULL variant the buffer held D) and the symmetric Gt in fragment layout
+    // stage Vt (phase 2 needs it; in the FULL variant the buffer held D).  Gt's padding rows / columns are exact zeros:
+    // they are sums of products with zero-padded rows of Linv
     for (int e = tid; e < MP * MP; e += NTHB) {
       const int i = e / MP, j = e % MP;
       const bool in = (i < M) && (j < M);
       Vl[i * LD + j] = in ? ev.Vt[base + i * M + j] : 0.0;
-      Gl[i * LD + j] = in ? (((i >> 4) >= (j >> 4)) ? S[i * MP + j] : S[j * MP + i]) : 0.0;
     }
   } else {
     if (tid < MP) {
@@ -412,6 +442,7 @@ __device__ void item_bwd_body(const EngineView& ev, const int r, const int k, co
     }
   }
 
+  if (SV_BWD_STOP == 1) return;
   // =================================================================== phase 2: per-item backward
   // ---- gather the spike partial sums of this trial (fixed chunk order); thread j < M owns inducing point j
   double p1sum = 0.0, espk = 0.0, a_l = 0.0;
@@ -456,6 +487,7 @@ __device__ void item_bwd_body(const EngineView& ev, const int r, const int k, co
     if (lane == 0) ev.ells[item] = espk;
   }
   if (!want_lat) return;
+  if (SV_BWD_STOP == 2) return;
 
   __syncthreads();
   if (tid < M) {
@@ -639,6 +671,6 @@ __global__ __launch_bounds__(256, (NT <= 2 ? 2 : 1)) void k_item_bwd(EngineView 
     item_bwd_body<NT, SV_RBF, FULL>(ev, r, k, ptab.p[k], mask, sm);
   else
     item_bwd_body<NT, SV_PERIODIC, FULL>(ev, r, k, ptab.p[k], mask, sm);
-  __shared__ int flag;
-  fin_tail(ev, C, d, mask, shared, sm, &flag);    // sm is free again: every wave passes the barriers inside
+  if (SV_BWD_STOP) return;
+  fin_tail(ev, C, d, mask, shared, sm);    // sm is free again: every wave passes the barriers inside
 }

@@ -224,6 +224,7 @@ int svgpfa_create(const svgpfa_dims* d, int device, svgpfa_engine** out) {
   HIPCHK(e, hipMemset(v.status, 0, sizeof(int)));
   DALLOC(e, v.fin_ticket, 1);
   HIPCHK(e, hipMemset(v.fin_ticket, 0, sizeof(unsigned)));
+  DALLOC(e, v.fin_part, 2 + SV_FIN_NS);
   HIPCHK(e, hipHostMalloc((void**)&e->status_host, sizeof(int)));
   HIPCHK(e, hipStreamCreateWithFlags(&e->s_side, hipStreamNonBlocking));
   {
@@ -574,6 +575,7 @@ int svgpfa_elbo(svgpfa_engine* e, const double* const* mean, const double* const
     DISPATCH_NT(e->NT, hipLaunchKernelGGL((k_item_bwd<NT_, false>), dim3(v.R * v.K), dim3(64 * e->tile_nw),
                                           lds_item_bwd(NT_, e->tile_nw), sm, v, pt, mask, C, d, shared));
   }
+  hipLaunchKernelGGL(k_fin_items, dim3(v.nth_total + SV_FIN_NS), dim3(256), 0, sm, v, mask, shared);
   HIPCHK(e, hipGetLastError());
   return SVGPFA_OK;
 }
