@@ -22,7 +22,22 @@ def allreduce_shared(shared, group=None):
     return shared
 
 
+def agree_max(flag, group=None):
+    """Maximum of a small non-negative int over ranks (every rank gets it): used to agree on a rank-local failure
+    (a non positive-definite Kzz of ONE rank's trials) so that all ranks raise together instead of one rank leaving
+    the EM step while the others wait in the next collective."""
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+        import torch
+        dev = "cpu" if dist.get_backend(group) == "gloo" else torch.device("cuda", torch.cuda.current_device())
+        t = torch.tensor([int(flag)], dtype=torch.int32, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
+        return int(t.item())
+    return int(flag)
+
+
 def attach(model, group=None):
-    """Make an svgpfa_amd.stats SVLowerBound (holding this rank's trials) reduce over `group`."""
+    """Make an svgpfa_amd.stats SVLowerBound (holding this rank's trials) reduce over `group`: the shared vector is
+    summed once per evaluation, and a failed Cholesky is agreed on once per kernel rebuild."""
     model._reduce = lambda t: allreduce_shared(t, group)
+    model._agree = lambda flag: agree_max(flag, group)
     return model

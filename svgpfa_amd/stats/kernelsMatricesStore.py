@@ -8,7 +8,8 @@ needed on the hot path (Ktz is never materialised there)."""
 import numpy as np
 import torch
 
-from ..engine import Engine
+from .. import _lib
+from ..engine import Engine, SVGPFAEngineError
 
 
 class KernelsMatricesStore:
@@ -65,8 +66,14 @@ class KernelsMatricesStore:
             n = torch.zeros(int(off[-1]), dtype=torch.int32, device=self._device) if off[-1] else None
             eng.set_spikes(off, t, n)
             self._spike_off = off
-        eng.build_kernels(Z, [self._dev(k.getParams()) for k in self._kernels])
-        eng.sync()
+        try:
+            eng.build_kernels(Z, [self._dev(k.getParams()) for k in self._kernels])
+            eng.sync()
+        except SVGPFAEngineError as e:
+            eng.close()                                        # do not leave the half-built engine to the GC
+            if e.code == _lib.ERR_NOT_PD:                      # the reference raises from torch.linalg.cholesky
+                raise torch.linalg.LinAlgError("linalg.cholesky: " + str(e)) from None
+            raise
         if self._engine is not None:
             self._engine.close()
         self._engine = eng

@@ -41,14 +41,28 @@ def _cubic_min(x1, f1, g1, x2, f2, g2, bounds=None):
 
 class ShardedLBFGS:
     """``local_params``: tensors this rank owns exclusively.  ``shared_params``: tensors replicated on every rank,
-    whose gradients the closure has already summed over ranks (svgpfa_amd.distributed.attach does that)."""
+    whose gradients the closure has already summed over ranks (svgpfa_amd.distributed.attach does that).
 
-    def __init__(self, local_params, shared_params=(), lr=1.0, max_iter=20, max_eval=None, tolerance_grad=1e-7,
-                 tolerance_change=1e-9, history_size=100, line_search_fn=None, group=None):
+    Flat mode (``flat=x``): the whole parameter group is ONE contiguous tensor ``x`` (the model keeps each group in one
+    buffer and hands out views, SVLowerBound.flatParams) and ``closure()`` returns ``(loss, flat_gradient)`` directly
+    (SVLowerBound.evalFlat: no autograd graph, gradients written by the engine straight into a flat buffer).  A trial
+    step is then one axpy and a line-search rollback one copy, instead of one small kernel per parameter tensor (4 K + 2
+    tensors at the north-star size: ~100 launches per closure); ``shared=True`` says the group is replicated on every
+    rank.  Arithmetic and decisions are the same as in list mode."""
+
+    def __init__(self, local_params=(), shared_params=(), lr=1.0, max_iter=20, max_eval=None, tolerance_grad=1e-7,
+                 tolerance_change=1e-9, history_size=100, line_search_fn=None, group=None, flat=None, shared=False):
         if line_search_fn not in (None, "strong_wolfe"):
             raise RuntimeError("only 'strong_wolfe' is supported")
-        self._shared = list(shared_params)
-        self._local = list(local_params)
+        self._flat = flat
+        if flat is not None:
+            if not (flat.dim() == 1 and flat.is_contiguous()):
+                raise ValueError("flat parameter group must be a contiguous 1-D tensor")
+            self._shared = [flat] if shared else []
+            self._local = [] if shared else [flat]
+        else:
+            self._shared = list(shared_params)
+            self._local = list(local_params)
         self._params = self._shared + self._local
         if not self._params:
             raise ValueError("optimizer got an empty parameter list")
@@ -81,8 +95,19 @@ class ShardedLBFGS:
     def _flat_grad(self):
         return torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1) for p in self._params])
 
+    def _eval(self, closure):
+        """-> (loss tensor, flat gradient as a tensor of its own)."""
+        if self._flat is not None:
+            loss, g = closure()
+            return loss, g
+        loss = closure()
+        return loss, self._flat_grad()
+
     @torch.no_grad()
     def _add(self, t, d):
+        if self._flat is not None:
+            self._flat.add_(d, alpha=t)
+            return
         o = 0
         for p in self._params:
             n = p.numel()
@@ -96,6 +121,21 @@ class ShardedLBFGS:
     def _restore(self, saved):
         for p, s in zip(self._params, saved):
             p.copy_(s)
+
+    def _scalars(self, sums=None, maxes=None, extra=()):
+        """Global sums / maxima of local partials plus already-global 0-dim tensors `extra`, as Python floats, with ONE
+        device-to-host transfer (and at most one all-gather)."""
+        rs, rm = self._reduce(sums, maxes)
+        parts = [t.reshape(-1) for t in (rs, rm) if t is not None and t.numel()]
+        dev = parts[0].device if parts else None
+        for x in extra:
+            x = x.detach().reshape(1)
+            parts.append(x if dev is None else x.to(dev, parts[0].dtype))
+            dev = parts[0].device
+        vals = torch.cat(parts).double().cpu().tolist()
+        ns = 0 if sums is None else sums.numel()
+        nm = 0 if maxes is None else maxes.numel()
+        return vals[:ns], vals[ns:ns + nm], vals[ns + nm:]
 
     # ------------------------------------------------------------------ the only communication
     def _reduce(self, sums=None, maxes=None):
@@ -123,13 +163,13 @@ class ShardedLBFGS:
         tg, tc = self.tolerance_grad, self.tolerance_change
         w = self._w
 
-        orig_loss = closure()
-        loss = float(orig_loss.detach()) if torch.is_tensor(orig_loss) else float(orig_loss)
+        orig_loss, g = self._eval(closure)
+        if not torch.is_tensor(orig_loss):
+            orig_loss = torch.as_tensor(float(orig_loss), dtype=g.dtype, device=g.device)
+        _, (gmax0,), (loss,) = self._scalars(None, g.abs().max().reshape(1), (orig_loss,))
         evals = 1
         st["func_evals"] += 1
-        g = self._flat_grad()
-        _, mx = self._reduce(None, g.abs().max().reshape(1))
-        if float(mx[0]) <= tg:
+        if gmax0 <= tg:
             return orig_loss
 
         d, t = st.get("d"), st.get("t")
@@ -143,8 +183,7 @@ class ShardedLBFGS:
             st["n_iter"] += 1
             if st["n_iter"] == 1:
                 part = torch.stack([(g * w).dot(g), (g.abs() * w).sum()])
-                (gg, gabs), _ = self._reduce(part, None)
-                gg, gabs = float(gg), float(gabs)
+                (gg, gabs), _, _ = self._scalars(part, None)
                 d = g.neg()
                 m = 0
                 SY = YY = np.zeros((0, 0))
@@ -211,30 +250,26 @@ class ShardedLBFGS:
             if self.line_search_fn == "strong_wolfe":
                 x0 = self._clone()
 
-                def phi(step):                 # -> (loss, flat gradient, g . d) at x0 + step d; ONE host sync
+                dabs = d.abs().max()
+
+                def phi(step):    # -> (loss, flat gradient, g . d, max |g|, max |d|) at x0 + step d; ONE host sync
                     self._add(step, d)
-                    f = closure()
-                    gn = self._flat_grad()
+                    f, gn = self._eval(closure)
                     self._restore(x0)
-                    part, _ = self._reduce(((gn * w).dot(d)).reshape(1), None)
-                    both = torch.stack([f.detach().reshape(()).to(part.device, part.dtype), part[0]]).cpu()
-                    return float(both[0]), gn, float(both[1])
-                loss, g, t, ls_evals = self._strong_wolfe(phi, t, d, loss, g, gtd)
+                    (gd,), (gm, dm), (fv,) = self._scalars(((gn * w).dot(d)).reshape(1),
+                                                           torch.stack([gn.abs().max(), dabs]), (f,))
+                    return fv, gn, gd, gm, dm
+                loss, g, t, ls_evals, gmax, dmax = self._strong_wolfe(phi, t, d, loss, g, gtd)
                 self._add(t, d)
-                _, mx = self._reduce(None, torch.stack([g.abs().max(), d.abs().max()]))
-                gmax, dmax = float(mx[0]), float(mx[1])
             else:
                 self._add(t, d)
                 gmax = math.inf
                 if n_iter != self.max_iter:
-                    loss = float(closure())
-                    g = self._flat_grad()
+                    f, g = self._eval(closure)
                     ls_evals = 1
-                    _, mx = self._reduce(None, torch.stack([g.abs().max(), d.abs().max()]))
-                    gmax, dmax = float(mx[0]), float(mx[1])
+                    _, (gmax, dmax), (loss,) = self._scalars(None, torch.stack([g.abs().max(), d.abs().max()]), (f,))
                 else:
-                    _, mx = self._reduce(None, d.abs().max().reshape(1))
-                    dmax = float(mx[0])
+                    _, (dmax,), _ = self._scalars(None, d.abs().max().reshape(1))
             evals += ls_evals
             st["func_evals"] += ls_evals
 
@@ -251,33 +286,32 @@ class ShardedLBFGS:
         return orig_loss
 
     def _strong_wolfe(self, phi, t, d, f, g, gtd, c1=1e-4, c2=0.9, max_ls=25):
-        """Bracketing + zoom line search for the strong Wolfe conditions; phi(t) -> (loss, flat grad, grad . d)."""
+        """Bracketing + zoom line search for the strong Wolfe conditions; phi(t) -> (loss, flat grad, grad . d,
+        max |grad|, max |d|).  Returns (loss, grad, step, evaluations, max |grad| at the step, max |d|)."""
         tc = self.tolerance_change
-        _, mx = self._reduce(None, d.abs().max().reshape(1))
-        d_norm = float(mx[0])
-        f_new, g_new, gtd_new = phi(t)
+        f_new, g_new, gtd_new, gm_new, d_norm = phi(t)
         n_eval = 1
-        t_prev, f_prev, g_prev, gtd_prev = 0.0, f, g, gtd
+        t_prev, f_prev, g_prev, gtd_prev, gm_prev = 0.0, f, g, gtd, None
         done = False
         it = 0
         br = None
         while it < max_ls:
             if f_new > f + c1 * t * gtd or (it > 1 and f_new >= f_prev) or (gtd_new >= 0 and abs(gtd_new) > -c2 * gtd):
-                br = [[t_prev, f_prev, g_prev, gtd_prev], [t, f_new, g_new, gtd_new]]
+                br = [[t_prev, f_prev, g_prev, gtd_prev, gm_prev], [t, f_new, g_new, gtd_new, gm_new]]
                 break
             if abs(gtd_new) <= -c2 * gtd:
-                br = [[t, f_new, g_new, gtd_new]]
+                br = [[t, f_new, g_new, gtd_new, gm_new]]
                 done = True
                 break
             lo_step, hi_step = t + 0.01 * (t - t_prev), t * 10.0
             t_next = _cubic_min(t_prev, f_prev, gtd_prev, t, f_new, gtd_new, bounds=(lo_step, hi_step))
-            t_prev, f_prev, g_prev, gtd_prev = t, f_new, g_new, gtd_new
+            t_prev, f_prev, g_prev, gtd_prev, gm_prev = t, f_new, g_new, gtd_new, gm_new
             t = t_next
-            f_new, g_new, gtd_new = phi(t)
+            f_new, g_new, gtd_new, gm_new, _ = phi(t)
             n_eval += 1
             it += 1
         if br is None:                      # ran out of bracketing iterations
-            br = [[0.0, f, g, gtd], [t, f_new, g_new, gtd_new]]
+            br = [[0.0, f, g, gtd, None], [t, f_new, g_new, gtd_new, gm_new]]
 
         insufficient = False
         lo, hi = (0, 1) if br[0][1] <= br[-1][1] else (1, 0)
@@ -295,19 +329,21 @@ class ShardedLBFGS:
                     insufficient = True
             else:
                 insufficient = False
-            f_new, g_new, gtd_new = phi(t)
+            f_new, g_new, gtd_new, gm_new, _ = phi(t)
             n_eval += 1
             it += 1
             if f_new > f + c1 * t * gtd or f_new >= br[lo][1]:
-                br[hi] = [t, f_new, g_new, gtd_new]
+                br[hi] = [t, f_new, g_new, gtd_new, gm_new]
                 lo, hi = (0, 1) if br[0][1] <= br[1][1] else (1, 0)
             else:
                 if abs(gtd_new) <= -c2 * gtd:
                     done = True
                 elif gtd_new * (br[hi][0] - br[lo][0]) >= 0:
                     br[hi] = list(br[lo])
-                br[lo] = [t, f_new, g_new, gtd_new]
+                br[lo] = [t, f_new, g_new, gtd_new, gm_new]
         if len(br) == 1:
             lo = 0
-        t, f_new, g_new = br[lo][0], br[lo][1], br[lo][2]
-        return f_new, g_new, t, n_eval
+        t, f_new, g_new, gm = br[lo][0], br[lo][1], br[lo][2], br[lo][4]
+        if gm is None:                      # the search fell back to the starting point: its gradient is the caller's g
+            _, (gm,), _ = self._scalars(None, g_new.abs().max().reshape(1))
+        return f_new, g_new, t, n_eval, gm, d_norm

@@ -28,6 +28,21 @@ def _to_dev(t, device, dtype=torch.float64):
     return t.detach().to(device=device, dtype=dtype).contiguous()
 
 
+def _pack_group(tensors, device):
+    """One contiguous buffer for a parameter group; returns (flat, views).  The views are what get*Params() hands out:
+    ordinary leaf tensors (in-place updates, requires_grad_ and torch.optim work on them as on any tensor) that happen
+    to be laid out back to back, so that an optimiser step over the whole group can be ONE axpy on `flat`."""
+    ts = [_to_dev(t, device) for t in tensors]
+    flat = torch.empty(sum(t.numel() for t in ts), dtype=torch.float64, device=device)
+    views, o = [], 0
+    for t in ts:
+        v = flat[o:o + t.numel()].view(t.shape)
+        v.copy_(t)
+        views.append(v)
+        o += t.numel()
+    return flat, views
+
+
 class _ELBOFunction(torch.autograd.Function):
     """eval() + hand-derived backward of the engine as one autograd node.
     inputs: K means, K cholVecs, C, d, K kernel-param tensors, K inducing-point tensors."""
@@ -47,12 +62,12 @@ class _ELBOFunction(torch.autograd.Function):
             mask |= _lib.GRAD_INDPOINTS
         eng = model._engine
         # content id of C: torch bumps _version on every in-place update (optimiser steps), a new tensor has a new address
-        C = model._C
-        eng.set_embedding_token((hash((C.data_ptr(), C._version)) & 0x7FFFFFFFFFFFFFFF) | 1)
+        eng.set_embedding_token(model._embedding_token())
         mean_t = [p.detach() for p in params[0:K]]
         chol_t = [p.detach().contiguous() for p in params[K:2 * K]]
+        # nothing here waits for the GPU: the only device status an evaluation can raise (a failed Cholesky) is checked
+        # where the factorisation happens, in buildKernelsMatrices()
         shared, gm, gc, gz = eng.elbo(mean_t, chol_t, model._C, model._d, mask)
-        model._sync()
         if model._reduce is not None:      # trials sharded over ranks: ONE all-reduce of the shared vector
             model._reduce(shared)
         ctx.mask, ctx.K = mask, K
@@ -96,7 +111,6 @@ class _ELLGivenStatsFunction(torch.autograd.Function):
     def forward(ctx, model, C, d):
         want = any(ctx.needs_input_grad[1:])
         out = model._engine.ell_given_stats(C, d, want)
-        model._sync()
         if model._reduce is not None:
             model._reduce(out)
         N, K = model._N, model._K
@@ -130,6 +144,10 @@ class SVLowerBound:
         self._spikes = None
         self._stats_token = None
         self._reduce = None          # optional callable(tensor): in-place sum over ranks (trial sharding)
+        self._agree = None           # optional callable(int) -> int: maximum over ranks (error agreement)
+        self._flat = {}              # parameter group -> its one contiguous buffer (see _pack_group)
+        self._gflat = {}             # per-trial gradient buffers the engine writes into, same layout
+        self._token_salt = 0
         self._last_terms = None
         self._data_version = 0
         self._engine_data_version = -1
@@ -171,19 +189,23 @@ class SVLowerBound:
         kms = initial_params["posterior_on_latents"]["kernels_matrices_store"]
         emb = initial_params["embedding"]
         dev = self._device
-        self._mean = [_to_dev(t, dev) for t in qU["mean"]]
+        self._flat, self._gflat = {}, {}
+        K = len(qU["mean"])
         if self._rank1:
+            self._mean = [_to_dev(t, dev) for t in qU["mean"]]
             self._qSVec = [_to_dev(t, dev) for t in qU["qSVec0"]]
             self._qSDiag = [_to_dev(t, dev) for t in qU["qSDiag0"]]
             self._cholVecs = None
         else:
-            self._cholVecs = [_to_dev(t, dev) for t in qU["cholVecs"]]
-        self._Z = [_to_dev(t, dev) for t in kms["inducing_points_locs0"]]
-        theta = [_to_dev(t, dev) for t in kms["kernels_params0"]]
+            # each optimisation group of the EM loop in ONE buffer, in the order its getter lists the tensors
+            self._flat["var"], v = _pack_group(list(qU["mean"]) + list(qU["cholVecs"]), dev)
+            self._mean, self._cholVecs = v[:K], v[K:]
+        self._flat["Z"], self._Z = _pack_group(kms["inducing_points_locs0"], dev)
+        self._flat["theta"], theta = _pack_group(kms["kernels_params0"], dev)
         for k, kern in enumerate(self._kernels):
             kern.setParams(theta[k])
-        self._C = _to_dev(emb["C0"], dev)
-        self._d = _to_dev(emb["d0"], dev)
+        self._flat["emb"], (self._C, self._d) = _pack_group([emb["C0"], emb["d0"]], dev)
+        self._token_salt += 1        # new embedding tensors: never reuse spike sums of the old ones
 
     def setELLCalculationParams(self, eLLCalculationParams):
         self._quad = (_to_dev(eLLCalculationParams["leg_quad_points"], self._device),
@@ -196,7 +218,16 @@ class SVLowerBound:
             self._engine.set_reg(self._reg)
 
     def setIndPointsLocs(self, locs):
-        self._Z = [_to_dev(t, self._device) for t in locs]
+        self._flat["Z"], self._Z = _pack_group(locs, self._device)
+        self._gflat.pop("Z", None)
+
+    def _embedding_token(self):
+        """Content id of C for the engine's reuse of the spike sums across value-only evaluations: torch bumps _version on
+        every in-place update of C or of the buffer it is a view of (optimiser steps); the salt changes whenever C is
+        re-created, so a new tensor at a recycled address is never mistaken for the old one.  Contract: C is mutated
+        through in-place torch ops (which bump the counter), not through `.data` or raw pointers."""
+        C = self._C
+        return (hash((C.data_ptr(), C._version, self._token_salt)) & 0x7FFFFFFFFFFFFFFF) | 1
 
     # ----------------------------------------------------------------- getters (svLowerBound.py:101-120)
     def getSVPosteriorOnIndPointsParams(self):
@@ -261,14 +292,25 @@ class SVLowerBound:
         self._engine, self._engine_key = eng, key
         self._stats_token = None
 
-    def _sync(self):
+    def _sync(self, agree=False):
+        """Wait for the engine's stream and surface its status word.  agree=True (after a factorisation): with trials
+        sharded over ranks the inducing points are per trial, so a Cholesky can fail on ONE rank only; the ranks
+        exchange their status (one small max-reduction) and raise together -- otherwise the healthy ranks would wait in
+        the next collective for a rank that has already left the EM step through the exception."""
+        err = None
         try:
             self._engine.sync()
         except SVGPFAEngineError as e:
-            if e.code == _lib.ERR_NOT_PD:
-                # the reference raises from torch.linalg.cholesky (utils/miscUtils.py:215)
-                raise torch.linalg.LinAlgError("linalg.cholesky: " + str(e)) from None
-            raise
+            if e.code != _lib.ERR_NOT_PD:
+                raise
+            err = str(e)
+        bad = 1 if err is not None else 0
+        if agree and self._agree is not None:
+            bad = self._agree(bad)
+        if bad:
+            # the reference raises from torch.linalg.cholesky (utils/miscUtils.py:215)
+            raise torch.linalg.LinAlgError("linalg.cholesky: " + (
+                err or "Kzz + eps*I is not positive definite on another rank (trial-sharded run)"))
 
     def _check_live(self, tensors, what):
         for t in tensors:
@@ -283,7 +325,7 @@ class SVLowerBound:
         theta = self._theta()
         self._check_live(self._Z + theta, "inducing point / kernel parameter")
         self._engine.build_kernels(self._Z, theta)
-        self._sync()
+        self._sync(agree=True)
         self._stats_token = None
 
     def eval(self):
@@ -294,9 +336,84 @@ class SVLowerBound:
         self._check_live(self._mean + [c.detach() for c in chol] + [self._C, self._d], "variational / embedding")
         theEval = _ELBOFunction.apply(self, *self._mean, *chol, self._C, self._d,
                                       *self._theta(), *self._Z)
-        if torch.isinf(theEval):
-            warnings.warn("infinity lower bound detected")
+        # the reference warns here when the bound is infinite (svLowerBound.py:51-53); reading the value would stall the
+        # host on every evaluation, so the check is made where the value reaches the host anyway (svEM's histories)
         return theEval
+
+    # ------------------------------------------------------------------------------ flat fast path (EM loop)
+    GROUPS = ("var", "emb", "theta", "Z")
+
+    def _group_tensors(self, group):
+        if group == "var":
+            return None if self._rank1 else self._mean + self._cholVecs
+        if group == "emb":
+            return [self._C, self._d]
+        if group == "theta":
+            return self._theta()
+        return self._Z
+
+    def flatParams(self, group):
+        """The ONE contiguous buffer behind a parameter group ("var": means + cholVecs, "emb": C + d, "theta": kernel
+        parameters, "Z": inducing points), or None when the group is not laid out that way (rank-1 + diagonal q(u), or
+        a caller has rebound one of the tensors, e.g. kernel.setParams(new_tensor))."""
+        flat, tens = self._flat.get(group), self._group_tensors(group)
+        if flat is None or tens is None:
+            return None
+        o = flat.data_ptr()
+        for t in tens:
+            if not (t.is_cuda and t.dtype == torch.float64 and t.is_contiguous() and t.data_ptr() == o):
+                return None
+            o += 8 * t.numel()
+        return flat if o == flat.data_ptr() + 8 * flat.numel() else None
+
+    def _grad_views(self, group):
+        if group not in self._gflat:
+            flat = torch.zeros_like(self._flat[group])
+            tens = (self._mean + self._cholVecs) if group == "var" else self._Z
+            views, o = [], 0
+            for t in tens:
+                views.append(flat[o:o + t.numel()].view(t.shape[0], -1))
+                o += t.numel()
+            self._gflat[group] = (flat, views)
+        return self._gflat[group]
+
+    def evalFlat(self, group):
+        """(value, gradient) of one EM closure without an autograd graph: value = the lower bound (group "emb": the
+        expected log-likelihood with the latent statistics of the latest computeSVPosteriorOnLatentsStats() frozen,
+        svEM.py:225-232), gradient = d value / d flatParams(group), a view of an engine-owned buffer that the NEXT
+        evaluation overwrites (callers copy or negate it).  Groups "theta" and "Z" rebuild the kernel matrices first
+        (svEM.py:238-241, :258-260).  Nothing here waits for the GPU except that rebuild's status check."""
+        if self.flatParams(group) is None:
+            raise ValueError(f"group {group!r} is not available as a flat buffer")
+        if self._engine is None or group in ("theta", "Z"):
+            self.buildKernelsMatrices()
+        eng, K = self._engine, self._K
+        if group == "emb":
+            if self._stats_token is None:
+                raise RuntimeError("computeSVPosteriorOnLatentsStats() must be called before evalFlat('emb')")
+            out = eng.ell_given_stats(self._C, self._d, True)
+            if self._reduce is not None:
+                self._reduce(out)
+            return out[0], out[1:]
+        eng.set_embedding_token(self._embedding_token())
+        mask = {"var": _lib.GRAD_VARIATIONAL, "theta": _lib.GRAD_KERNELS, "Z": _lib.GRAD_INDPOINTS}[group]
+        grads = (None, None, None)
+        if group == "var":
+            flat, v = self._grad_views("var")
+            grads = (v[:K], v[K:], None)
+        elif group == "Z":
+            flat, v = self._grad_views("Z")
+            grads = (None, None, v)
+        if not hasattr(self, "_shared_buf") or self._shared_buf.numel() != eng.shared_len:
+            self._shared_buf = torch.empty(eng.shared_len, dtype=torch.float64, device=self._device)
+        shared = self._shared_buf
+        eng.elbo(self._mean, self._cholVecs, self._C, self._d, mask, out=shared, grads=grads)
+        if self._reduce is not None:
+            self._reduce(shared)
+        self._last_terms = (shared[0], shared[1], shared[2])
+        if group == "theta":
+            flat = shared[3 + self._N * K + self._N:]
+        return shared[0], flat
 
     def computeSVPosteriorOnLatentsStats(self):
         """svLowerBound.py:80-81.  Returns the reference's dict layout; the engine keeps the same numbers
@@ -374,7 +491,28 @@ class SVLowerBound:
         st["_engine_key"] = None
         st["_stats_token"] = None
         st["_reduce"] = None
+        st["_agree"] = None
+        st["_gflat"] = {}
+        st["_flat"] = {}
+        st.pop("_shared_buf", None)
         return st
 
     def __setstate__(self, st):
         self.__dict__.update(st)
+        self._repack()
+
+    def _repack(self):
+        """Lay the parameter groups out contiguously again (pickling stores every tensor on its own)."""
+        if getattr(self, "_C", None) is None:
+            return
+        dev, K = self._device, self._K
+        self._flat = {}
+        if not self._rank1:
+            self._flat["var"], v = _pack_group(self._mean + self._cholVecs, dev)
+            self._mean, self._cholVecs = v[:K], v[K:]
+        self._flat["Z"], self._Z = _pack_group(self._Z, dev)
+        self._flat["theta"], theta = _pack_group(self._theta(), dev)
+        for k, kern in enumerate(self._kernels):
+            kern.setParams(theta[k])
+        self._flat["emb"], (self._C, self._d) = _pack_group([self._C, self._d], dev)
+        self._token_salt += 1

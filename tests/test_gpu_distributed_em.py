@@ -85,3 +85,49 @@ def test_two_rank_em_matches_single_process():
     assert torch.allclose(torch.from_numpy(d), dr.cpu(), rtol=1e-4, atol=1e-6)
     for a, b in zip(theta, model.getKernelsParams()):
         assert torch.allclose(torch.from_numpy(a), b.cpu(), rtol=1e-4, atol=1e-6)
+
+
+def _rank_fail(rank, world, port, q):
+    import torch.distributed as dist
+    sys.path.insert(0, REPO)
+    sys.path.insert(0, os.path.join(REPO, "tests"))
+    from svgpfa_amd import distributed
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    shard = synthetic.shard_trials(_problem(), rank, world)
+    model = distributed.attach(build_model(shard))
+    if rank == 1:        # rank 1 only: two inducing points of one of ITS trials coincide and the jitter is negative
+        Z = model.getIndPointsLocs()[0]
+        Z[0, 2, 0] = Z[0, 1, 0]
+        model.setPriorCovRegParam(-0.5)
+    from svgpfa_amd.stats.svEM import SVEM_PyTorch
+    op = _optim_params()
+    for name in ("estep", "mstep_embedding"):
+        op[f"{name}_estimate"] = False
+    hist, _, info, _ = SVEM_PyTorch().maximize(model=model, optim_params=op, method="ECM", out=io.StringIO(),
+                                               verbose=False, printIterationModelParams=False)
+    q.put((rank, type(info).__name__, str(getattr(info, "error", ""))))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_rank_local_cholesky_failure_is_raised_on_every_rank():
+    """A non positive-definite Kzz on ONE rank's trials (Z is per trial) must end the EM step on EVERY rank with
+    ErrorTerminationInfo (reference rollback path svEM.py:246-253), not leave the healthy rank waiting in the next
+    collective: buildKernelsMatrices() agrees on the status over the ranks before raising."""
+    import torch.multiprocessing as mp
+    world = 2
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_rank_fail, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = sorted(q.get(timeout=300) for _ in range(world))
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    for rank, kind, err in got:
+        assert kind == "ErrorTerminationInfo", got
+        assert "positive definite" in err, got
