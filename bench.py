@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """bench.py -- ELBO+gradient evaluations per second of the HIP engine (BASELINE.json metric).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--config cfg3] [--variant all|estep]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config cfg3] [--variant all|estep] [--dtype f64|mixed]
 
 One "step" = one complete evaluation of the sparse-variational lower bound and its gradients on
 the named synthetic workload (seeded), inputs already resident in HBM:
@@ -50,12 +50,19 @@ HBM_PEAK_GBS = 8000.0
 # the figure is a lower bound of the executed operations, so the fraction cannot exceed 1.
 PAIR_FLOPS = {("exponentialQuadratic", True): 32, ("periodic", True): 38,
               ("exponentialQuadratic", False): 26, ("periodic", False): 29}
+# --dtype mixed (BASELINE config 5): the same pair loop in fp32 with ONE v_exp_f32 (counted as 1 operation) for 2^y:
+#   RBF full: sub, mul, exp, mul, add, 3 FMA = 11;  periodic full: 2 FMA, exp, mul, add, 5 FMA = 17
+#   RBF value: sub, mul, exp, FMA = 5;              periodic value: mul + FMA, FMA, exp, FMA = 8
+PAIR_FLOPS_F32 = {("exponentialQuadratic", True): 11, ("periodic", True): 17,
+                  ("exponentialQuadratic", False): 5, ("periodic", False): 8}
+FP32_PEAK_TFLOPS = 157.3  # MI355X fp32 vector peak (MI355X_MICROARCH.md)
 
 
-def spike_pass_flops(prob, full):
-    """fp64 operations one spike pass must execute (PAIR_FLOPS x pairs), this rank's shard."""
+def spike_pass_flops(prob, full, table=None):
+    """Operations one spike pass must execute (PAIR_FLOPS x pairs), this rank's shard."""
+    table = table or PAIR_FLOPS
     S = int(prob["spike_offsets"][-1])
-    return float(sum(S * M * PAIR_FLOPS[(t, bool(full))] for M, t in zip(prob["Ms"], prob["kernel_types"])))
+    return float(sum(S * M * table[(t, bool(full))] for M, t in zip(prob["Ms"], prob["kernel_types"])))
 
 
 def kernel_source_sha():
@@ -192,7 +199,12 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--config", default="cfg3", choices=["cfg2", "cfg3", "cfg5"])
     ap.add_argument("--variant", default="all", choices=["all", "estep"])
-    ap.add_argument("--cpu-sample-trials", type=int, default=200)
+    ap.add_argument("--dtype", default="f64", choices=["f64", "mixed"],
+                    help="f64: the reference's arithmetic (headline).  mixed: BASELINE config 5's mode, fp32 spike pass and "
+                         "quadrature ELL with fp64 Kzz / Cholesky / whitening / KL")
+    ap.add_argument("--cpu-sample-trials", type=int, default=None,
+                    help="trials of the workload the CPU oracle is timed on (default: 200 for cfg3, all 50 of cfg2, 12 for "
+                         "cfg5: about 10-30 s of CPU work for three repetitions)")
     ap.add_argument("--cpu-reps", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
@@ -202,6 +214,8 @@ def main():
                     help="E-step variant only: let value-only evaluations reuse the spike sums while C, Z, theta are "
                          "unchanged (svgpfa_set_embedding_token), as the closure of a real E-step does")
     args = ap.parse_args()
+    if args.cpu_sample_trials is None:
+        args.cpu_sample_trials = {"cfg2": 50, "cfg3": 200, "cfg5": 12}[args.config]
 
     import torch
     import torch.distributed as dist
@@ -229,7 +243,7 @@ def main():
 
     full = synthetic.make_config(args.config)
     prob = synthetic.shard_trials(full, rank, world) if world > 1 else full
-    eng, P = engine_from_problem(prob, device=local_rank)
+    eng, P = engine_from_problem(prob, device=local_rank, precision="mixed" if args.dtype == "mixed" else "fp64")
     mask = 15 if args.variant == "all" else 1
     shared = torch.empty(eng.shared_len, dtype=torch.float64, device=dev)
     grads = eng.alloc_grads(mask)
@@ -281,17 +295,21 @@ def main():
         work_full = algorithmic_work(full, args.variant)
         ms_per_step = 1e3 * elapsed / args.steps
         full_pass = bool(mask & 14)
-        exec_flops = spike_pass_flops(prob, full_pass)
+        mixed = args.dtype == "mixed"
+        exec_flops = spike_pass_flops(prob, full_pass, PAIR_FLOPS_F32 if mixed else PAIR_FLOPS)
+        peak = FP32_PEAK_TFLOPS if mixed else FP64_PEAK_TFLOPS
         secs = spike_avg_ms * 1e-3
         achieved = exec_flops / secs / 1e12 if spike_avg_ms > 0 else None
         conv = work["flops_spike"] / secs / 1e12 if spike_avg_ms > 0 else None
-        traffic = measured_traffic(args.config, args.variant, full_pass) if world == 1 else None
+        traffic = measured_traffic(args.config, args.variant, full_pass) if (world == 1 and not mixed) else None
         out = {
             "metric": "ELBO+grad evals/sec at (trials,neurons,latents,ind)=(%d,%d,%d,%d)" % (
                 full["R"], full["N"], full["K"], full["Ms"][0]),
             "value": args.steps / elapsed, "unit": "evals/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
-            "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "scaling": "strong", "vs_baseline": None,
+            "dtype": "f32 (spike pass, quadrature ELL) + f64 (Kzz, Cholesky, whitening, KL, sums)" if mixed else "f64",
+            "data": "synthetic",
             "config": {"workload": f"{args.config}: {full['R']} trials x {full['N']} neurons x {full['K']} latents x "
                                    f"{full['Ms'][0]} inducing, {int(full['spike_offsets'][-1])} spikes, Q={full['Q']}",
                        "variant": "ALL (rebuild kernels + ELBO + 4 gradient groups)" if args.variant == "all"
@@ -299,17 +317,18 @@ def main():
                                          + (", spike sums reused across evaluations" if args.estep_cache else "")),
                        "parallelism": f"trials sharded {world}-way by spike count, 1 RCCL all-reduce/step" if world > 1 else "single GPU"},
             "elbo": elbo,
-            "roofline": {"bound": "valu_fp64", "achieved": achieved, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": (achieved / FP64_PEAK_TFLOPS) if achieved else None,
+            "roofline": {"bound": "valu_fp32" if mixed else "valu_fp64", "achieved": achieved, "peak": peak,
+                         "unit": "TFLOP/s", "frac": (achieved / peak) if achieved else None,
                          "traffic": traffic[0] if traffic else None,
                          "traffic_unit": "HBM bytes per spike pass (FETCH_SIZE + WRITE_SIZE of its k_spike launches, separate PMC passes)",
                          "traffic_source": ("profiles/%s @ csrc %s" % (traffic[1], traffic[3])) if traffic
                          else "none: no committed PMC digest was taken on this device code (csrc %s)" % kernel_source_sha(),
                          "algorithmic_bytes_per_launch": work.get("bytes_spike"),
-                         "kernel": "k_spike<%s>" % ("true" if full_pass else "false"),
+                         "kernel": "k_spike<%s%s>" % ("true" if full_pass else "false", ", 8, float" if mixed else ""),
                          "kernel_avg_ms": spike_avg_ms, "kernel_launches": launches,
                          "executed_fp64_flops_per_launch": exec_flops,
-                         "pair_flops": {"%s/%s" % (t[:3], "full" if f else "value"): v for (t, f), v in PAIR_FLOPS.items()},
+                         "pair_flops": {"%s/%s" % (t[:3], "full" if f else "value"): v
+                                        for (t, f), v in (PAIR_FLOPS_F32 if mixed else PAIR_FLOPS).items()},
                          "note": "k_spike issues no MFMA: its work is one software 2^y (rndne, sub, 10 FMA, ldexp, cvt) and 3-7 "
                                  "FMAs per (spike, inducing point) pair on the fp64 VALU.  `achieved` = fp64 operations the "
                                  "kernel must execute (FMA = 2, add / mul / rndne = 1, ldexp / cvt = 0; per-spike set-up not "

@@ -52,6 +52,12 @@ enum {
   SVGPFA_GRAD_INDPOINTS = 8    /* inducing-point locations(_mStepIndPointsLocs) */
 };
 
+/* arithmetic of the ELBO terms (svgpfa_dims.precision).  The reference is fp64 throughout (stats/kernels.py:29,
+   utils/miscUtils.py:136,151,227); MIXED is BASELINE.json configs[4] ("fp32 ELBO with fp64 Cholesky"): the spike-time
+   pass and the quadrature expected-log-likelihood run in fp32, Kzz, its Cholesky factor, the whitened algebra, the KL
+   term and every cross-chunk / cross-trial sum stay fp64.  Tolerances: DESIGN.md section 5. */
+enum { SVGPFA_PRECISION_FP64 = 0, SVGPFA_PRECISION_MIXED = 1 };
+
 #define SVGPFA_MAX_IND 64      /* inducing points per latent handled by one wavefront   */
 #define SVGPFA_MAX_LATENTS 32
 
@@ -65,6 +71,7 @@ typedef struct {
   const double* scale;             /* [K] Kernel._scale            (NULL = 1.0)          */
   const double* lengthscale_scale; /* [K] Kernel._lengthscaleScale (NULL = 1.0)          */
   const double* period_scale;      /* [K] Kernel._periodScale      (NULL = 1.0)          */
+  int32_t precision;           /* SVGPFA_PRECISION_* (0 = fp64, the reference's arithmetic)      */
 } svgpfa_dims;
 
 /* SVGPFAModelFactory.buildModelPyTorch (stats/svGPFAModelFactory.py:40-148), default options. */

@@ -14,6 +14,7 @@ OK, ERR_INVALID, ERR_NOT_PD, ERR_HIP, ERR_STATE, ERR_UNSUPPORTED = range(6)
 KERNEL_RBF, KERNEL_PERIODIC = 0, 1
 GRAD_VARIATIONAL, GRAD_EMBEDDING, GRAD_KERNELS, GRAD_INDPOINTS = 1, 2, 4, 8
 GRAD_ALL = 15
+PRECISION_FP64, PRECISION_MIXED = 0, 1
 
 
 class Dims(ctypes.Structure):
@@ -23,7 +24,8 @@ class Dims(ctypes.Structure):
                 ("kernel_type", ctypes.POINTER(ctypes.c_int32)),
                 ("scale", ctypes.POINTER(ctypes.c_double)),
                 ("lengthscale_scale", ctypes.POINTER(ctypes.c_double)),
-                ("period_scale", ctypes.POINTER(ctypes.c_double))]
+                ("period_scale", ctypes.POINTER(ctypes.c_double)),
+                ("precision", ctypes.c_int32)]
 
 
 _vp = ctypes.c_void_p

@@ -278,10 +278,31 @@ __global__ __launch_bounds__(64 * NT) void k_prep_mfma(EngineView ev, LatentPtrT
 // other matrix sit in a small per-wave LDS slice.  When the looped matrix exceeds the LDS budget (large N K or
 // Q K) it is streamed through LDS in chunks of lc tiles.  grid = R * parts blocks of 64 NW threads (NW = 4 waves; the
 // count is a launch parameter, larger blocks measured slower because fewer of them fit a CU).
-template <int KS, int ROLE>
+// ---- scalar type of the ELL kernel: double, or float in precision mode "mixed" (v_mfma_f32_16x16x4_f32 + v_exp_f32).
+// Operand layouts of the two 16x16x4 MFMAs are the same (A: row = lane & 15, k = lane >> 4; B: k = lane >> 4, col = lane & 15);
+// the ACCUMULATOR layouts differ: f64 register q holds row (lane >> 4) + 4 q, f32 register q holds row 4 (lane >> 4) + q.
+// An accumulator tile is used as the B operand of step q of the next product, so the k index of step q is that row.
+typedef float f4 __attribute__((ext_vector_type(4)));
+template <typename T> struct EllT;
+template <> struct EllT<double> {
+  typedef d4 acc;
+  static __device__ __forceinline__ acc mfma(double a, double b, acc c) { return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0); }
+  static __device__ __forceinline__ int row(int lg, int q) { return lg + 4 * q; }
+  static __device__ __forceinline__ double exp2(double x) { return sv_exp2(x); }
+};
+template <> struct EllT<float> {
+  typedef f4 acc;
+  static __device__ __forceinline__ acc mfma(float a, float b, acc c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
+  static __device__ __forceinline__ int row(int lg, int q) { return 4 * lg + q; }
+  static __device__ __forceinline__ float exp2(float x) { return __builtin_amdgcn_exp2f(x); }   // saturates to 0 / inf
+};
+
+template <int KS, int ROLE, typename T>
 __device__ __forceinline__ void quad_ell_mfma_body(const EngineView& ev, const double* C, const double* d,
                                                    int want_sums, int write_ell, int parts, int lc, int blk,
-                                                   double* sm) {
+                                                   double* sm_d) {
+  typedef EllT<T> X;
+  typedef typename X::acc accT;
   constexpr int KKP = 4 * KS, LDK = KKP + 2, KKT = (KKP + 15) / 16;
   const double L2E = 1.4426950408889634074, LN2 = 0.69314718055994530942;
   const int K = ev.K, N = ev.N, Q = ev.Q, K2 = 2 * K;
@@ -294,17 +315,17 @@ __device__ __forceinline__ void quad_ell_mfma_body(const EngineView& ev, const d
   const int r = blk / parts, part = blk % parts;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 15, lg = lane >> 4;
   const int NTH = blockDim.x, NW = NTH >> 6;   // waves per block (host launch parameter)
-  double* LM = sm;                          // (Lrows + 1) * LDK  looped matrix: ROLE 0 [mu | var], ROLE 1 log2e [C | C^2/2]
-  double* lv = LM + (Lrows + 1) * LDK;      // Lp   looped vector: ROLE 0 w_q, ROLE 1 log2e d_n
-  double* OW = lv + Lp;                     // NW * 16 * LDK  per-wave rows of the other matrix
-  double* red = OW + NW * 16 * LDK;         // 8
+  T* LM = (T*)sm_d;                         // (Lrows + 1) * LDK  looped matrix: ROLE 0 [mu | var], ROLE 1 log2e [C | C^2/2]
+  T* lv = LM + (Lrows + 1) * LDK;           // Lp   looped vector: ROLE 0 w_q, ROLE 1 log2e d_n
+  T* OW = lv + Lp;                          // NW * 16 * LDK  per-wave rows of the other matrix
+  double* red = (double*)(OW + NW * 16 * LDK + ((NW * 16 * LDK + Lp + (Lrows + 1) * LDK) & 1));   // 8 (fp64, 8-B aligned)
   const int lrows_tot = (ROLE == 0) ? Q : N;
 
   // fill rows [row0, row0 + Lrows) of the looped matrix: zero the padding, then batched independent loads
   // (8 in flight per thread).  ROLE 0: the trial's statistics mu / var, stored [k][q] (K runs of nrow contiguous nodes);
   // ROLE 1: C [N x K], contiguous
   auto fill_lm = [&](int row0) {
-    for (int e = tid; e < (Lrows + 1) * LDK; e += NTH) LM[e] = 0.0;
+    for (int e = tid; e < (Lrows + 1) * LDK; e += NTH) LM[e] = (T)0;
     __syncthreads();
     const int nrow = (lrows_tot - row0 < Lrows) ? (lrows_tot - row0) : Lrows;
     const int tot = nrow * K;
@@ -337,11 +358,11 @@ __device__ __forceinline__ void quad_ell_mfma_body(const EngineView& ev, const d
             c = idx - row * K;
           }
           if (ROLE == 0) {
-            LM[row * LDK + c] = v0[u];
-            LM[row * LDK + K + c] = v1[u];
+            LM[row * LDK + c] = (T)v0[u];
+            LM[row * LDK + K + c] = (T)v1[u];
           } else {
-            LM[row * LDK + c] = v0[u] * L2E;
-            LM[row * LDK + K + c] = 0.5 * v0[u] * v0[u] * L2E;
+            LM[row * LDK + c] = (T)(v0[u] * L2E);
+            LM[row * LDK + K + c] = (T)(0.5 * v0[u] * v0[u] * L2E);
           }
         }
       }
@@ -350,18 +371,18 @@ __device__ __forceinline__ void quad_ell_mfma_body(const EngineView& ev, const d
   };
 
   for (int i = tid; i < Lp; i += NTH)
-    lv[i] = (ROLE == 0) ? ((i < Q) ? ev.wq[(long long)r * Q + i] : 0.0) : ((i < N) ? d[i] * L2E : 0.0);
+    lv[i] = (T)((ROLE == 0) ? ((i < Q) ? ev.wq[(long long)r * Q + i] : 0.0) : ((i < N) ? d[i] * L2E : 0.0));
   if (LC == LT) fill_lm(0);     // common case: the whole looped matrix stays resident
   else __syncthreads();
 
   double esum = 0.0;
-  double* ow = OW + wave * 16 * LDK;
+  T* ow = OW + wave * 16 * LDK;
   for (int ot0 = part * NW; ot0 < OT; ot0 += parts * NW) {     // block-uniform rounds; wave `wave` owns tile ot0 + wave
     const int ot = ot0 + wave;
     const bool active = ot < OT;
     // own 16 rows -> per-wave LDS slice (wave-local: no block barrier needed).  ROLE 0: 16 rows of C, contiguous
     // (16 K doubles); ROLE 1: the tile's 16 nodes of mu / var, K runs of nrow contiguous values ([k][q] layout)
-    for (int e = lane; e < 16 * LDK; e += 64) ow[e] = 0.0;
+    for (int e = lane; e < 16 * LDK; e += 64) ow[e] = (T)0;
     lds_wave_fence();
     if (active) {
       const int orows = (ROLE == 0) ? N : Q;
@@ -395,11 +416,11 @@ __device__ __forceinline__ void quad_ell_mfma_body(const EngineView& ev, const d
             row = idx - c * nrow;
           }
           if (ROLE == 0) {
-            ow[row * LDK + c] = v0[u] * L2E;
-            ow[row * LDK + K + c] = 0.5 * v0[u] * v0[u] * L2E;
+            ow[row * LDK + c] = (T)(v0[u] * L2E);
+            ow[row * LDK + K + c] = (T)(0.5 * v0[u] * v0[u] * L2E);
           } else {
-            ow[row * LDK + c] = v0[u];
-            ow[row * LDK + K + c] = v1[u];
+            ow[row * LDK + c] = (T)v0[u];
+            ow[row * LDK + K + c] = (T)v1[u];
           }
         }
       }
@@ -407,60 +428,58 @@ __device__ __forceinline__ void quad_ell_mfma_body(const EngineView& ev, const d
     lds_wave_fence();
     const int oi = ot * 16 + li;              // own index of this lane's column
     const bool ook = active && oi < ((ROLE == 0) ? N : Q);
-    const double ov = !ook ? 0.0 : ((ROLE == 0) ? d[oi] * L2E : ev.wq[(long long)r * Q + oi]);
-    double bfrag[KS];                         // own rows as the B operand of the h product
+    const T ov = (T)(!ook ? 0.0 : ((ROLE == 0) ? d[oi] * L2E : ev.wq[(long long)r * Q + oi]));
+    T bfrag[KS];                              // own rows as the B operand of the h product
 #pragma unroll
     for (int c = 0; c < KS; ++c) bfrag[c] = ow[li * LDK + 4 * c + lg];
-    d4 acc[KKT];
+    accT acc[KKT];
 #pragma unroll
-    for (int t = 0; t < KKT; ++t) acc[t] = (d4){0.0, 0.0, 0.0, 0.0};
-    double colsum = 0.0;
+    for (int t = 0; t < KKT; ++t) acc[t] = (accT){0, 0, 0, 0};
+    T colsum = 0;
     for (int lt0 = 0; lt0 < LT; lt0 += LC) {
       if (LC < LT) fill_lm(lt0 * 16);         // block-uniform: every wave takes part, active or not
       const int lt1 = (lt0 + LC < LT) ? lt0 + LC : LT;
       if (active)
         for (int lt = lt0; lt < lt1; ++lt) {
           const int lr = (lt - lt0) * 16;     // row of this tile inside the resident chunk
-          d4 h = {0.0, 0.0, 0.0, 0.0};
+          accT h = {0, 0, 0, 0};
 #pragma unroll
-          for (int c = 0; c < KS; ++c)
-            h = __builtin_amdgcn_mfma_f64_16x16x4f64(LM[(lr + li) * LDK + 4 * c + lg], bfrag[c], h, 0, 0, 0);
-          double afrag[KKT][4];               // looped rows, transposed, for the sum product (independent of E)
+          for (int c = 0; c < KS; ++c) h = X::mfma(LM[(lr + li) * LDK + 4 * c + lg], bfrag[c], h);
+          T afrag[KKT][4];                    // looped rows, transposed, for the sum product (independent of E)
           if (want_sums) {
 #pragma unroll
             for (int t = 0; t < KKT; ++t)
 #pragma unroll
-              for (int c = 0; c < 4; ++c) afrag[t][c] = LM[(lr + 4 * c + lg) * LDK + 16 * t + li];
+              for (int c = 0; c < 4; ++c) afrag[t][c] = LM[(lr + X::row(lg, c)) * LDK + 16 * t + li];
           }
-          d4 E;
+          accT E;
 #pragma unroll
           for (int q = 0; q < 4; ++q) {
-            const int l = lt * 16 + lg + 4 * q;   // looped index of this element's row
+            const int l = lt * 16 + X::row(lg, q);   // looped index of this element's row
             // ROLE 0: E = w_q 2^(h + d_n) ; ROLE 1: E^T = w_q 2^(h^T + d_n)
-            const double x = (ROLE == 0) ? lv[l] * sv_exp2(h[q] + ov) : ov * sv_exp2(h[q] + lv[l]);
+            const T x = (ROLE == 0) ? lv[l] * X::exp2(h[q] + ov) : ov * X::exp2(h[q] + lv[l]);
             const bool lok = l < lrows_tot;
-            E[q] = (ook && lok) ? x : 0.0;
+            E[q] = (ook && lok) ? x : (T)0;
             colsum += E[q];
           }
           if (want_sums) {
 #pragma unroll
             for (int t = 0; t < KKT; ++t)
 #pragma unroll
-              for (int c = 0; c < 4; ++c)
-                acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(afrag[t][c], E[c], acc[t], 0, 0, 0);
+              for (int c = 0; c < 4; ++c) acc[t] = X::mfma(afrag[t][c], E[c], acc[t]);
           }
         }
       if (LC < LT) __syncthreads();           // all waves done with this chunk before it is overwritten
     }
-    esum += colsum;
+    esum += (double)colsum;
     if (want_sums && ook) {
       if (ROLE == 0) {
 #pragma unroll
         for (int t = 0; t < KKT; ++t)
 #pragma unroll
           for (int q = 0; q < 4; ++q) {
-            const int kk = 16 * t + lg + 4 * q;
-            if (kk < K2) ev.gCpart[((long long)r * N + oi) * K2 + kk] = acc[t][q];
+            const int kk = 16 * t + X::row(lg, q);
+            if (kk < K2) ev.gCpart[((long long)r * N + oi) * K2 + kk] = (double)acc[t][q];
           }
       } else {
         const long long gi = (long long)r * Q * K + oi;        // [r][k][q]: the 16 nodes of the tile are contiguous
@@ -468,15 +487,15 @@ __device__ __forceinline__ void quad_ell_mfma_body(const EngineView& ev, const d
         for (int t = 0; t < KKT; ++t)
 #pragma unroll
           for (int q = 0; q < 4; ++q) {
-            const int kk = 16 * t + lg + 4 * q;
-            if (kk < K) ev.gmuq[gi + (long long)kk * Q] = -acc[t][q] * LN2;
-            else if (kk < K2) ev.gvarq[gi + (long long)(kk - K) * Q] = -acc[t][q] * LN2;
+            const int kk = 16 * t + X::row(lg, q);
+            if (kk < K) ev.gmuq[gi + (long long)kk * Q] = -(double)acc[t][q] * LN2;
+            else if (kk < K2) ev.gvarq[gi + (long long)(kk - K) * Q] = -(double)acc[t][q] * LN2;
           }
       }
     }
     if (ROLE == 0 && want_sums) {
-      colsum = grp4_sum(colsum);
-      if (lg == 0 && ook) ev.gdpart[(long long)r * N + oi] = -colsum;
+      const double cs = grp4_sum((double)colsum);
+      if (lg == 0 && ook) ev.gdpart[(long long)r * N + oi] = -cs;
     }
     lds_wave_fence();
   }
@@ -488,18 +507,18 @@ __device__ __forceinline__ void quad_ell_mfma_body(const EngineView& ev, const d
 
 // ROLE 0: dC / dd / ELL only (no latent-side gradient wanted).  ROLE 2: both roles in one launch (blocks [0, nb) role 0,
 // [nb, 2 nb) role 1): measured faster than two launches at every size.
-template <int KS, int ROLE>
+template <int KS, int ROLE, typename T = double>
 __global__ __launch_bounds__(512) void k_quad_ell_mfma(EngineView ev, const double* C, const double* d,
                                                        int want_sums, int write_ell, int parts, int lc0, int lc1) {
   extern __shared__ double sm[];
   if (ROLE == 2) {
     const int nb = ev.R * parts;
     if ((int)blockIdx.x < nb)
-      quad_ell_mfma_body<KS, 0>(ev, C, d, want_sums, 1, parts, lc0, blockIdx.x, sm);
+      quad_ell_mfma_body<KS, 0, T>(ev, C, d, want_sums, 1, parts, lc0, blockIdx.x, sm);
     else
-      quad_ell_mfma_body<KS, 1>(ev, C, d, 1, 0, parts, lc1, blockIdx.x - nb, sm);
+      quad_ell_mfma_body<KS, 1, T>(ev, C, d, 1, 0, parts, lc1, blockIdx.x - nb, sm);
   } else {
-    quad_ell_mfma_body<KS, (ROLE == 2 ? 0 : ROLE)>(ev, C, d, want_sums, write_ell, parts, ROLE == 0 ? lc0 : lc1,
-                                                    blockIdx.x, sm);
+    quad_ell_mfma_body<KS, (ROLE == 2 ? 0 : ROLE), T>(ev, C, d, want_sums, write_ell, parts, ROLE == 0 ? lc0 : lc1,
+                                                       blockIdx.x, sm);
   }
 }

@@ -49,6 +49,16 @@ __device__ __forceinline__ void seg_emit_lane(const int (&key)[SPL], const doubl
   }
 }
 
+// Scalar type of the pair loop: double (default) or float (precision mode "mixed", BASELINE config 5: fp32 ELBO terms with
+// fp64 Kzz / Cholesky / whitening / KL).  In fp32 the exponential is ONE v_exp_f32 instead of the 14-instruction fp64
+// kernel and every FMA issues at twice the fp64 rate: a (spike, inducing point) pair costs ~11 ns of SIMD time instead of
+// ~44.  Phases, scaled times and embedding weights are formed in fp64 and rounded once; per-lane partial sums (8 spikes)
+// and the 64-lane reduction run in fp32; everything that leaves the wave (P0 / P1 / T partials per chunk, dC per neuron)
+// is fp64, and so is every cross-chunk / cross-trial sum downstream.
+__device__ __forceinline__ float sv_exp2_neg(float y) { return __builtin_amdgcn_exp2f(y); }   // v_exp_f32; underflows to 0
+__device__ __forceinline__ float sv_fma(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+__device__ __forceinline__ double sv_fma(double a, double b, double c) { return fma(a, b, c); }
+
 // Periodic kernel, value + all gradients.  With theta_s = 2 pi t_s / p and phi_j = 2 pi z_j / p every sum over spikes the
 // pass needs is linear in sin / cos of theta_s, so the per-pair work is one exponential and seven FMAs:
 //   y_sj = hh (cos(theta_s - phi_j) - 1) = ct_s (hh cos phi_j) + st_s (hh sin phi_j) - hh        ck = c_s 2^y
@@ -57,9 +67,9 @@ __device__ __forceinline__ void seg_emit_lane(const int (&key)[SPL], const doubl
 //   sum ck cos(theta - phi)   = cos phi QB + sin phi QA            (-> dtheta_lengthscale through sum ck y)
 //   sum ck sin(theta - phi) t = cos phi QC - sin phi QD            (-> dtheta_period, minus z_j times the first)
 // (no sin(theta - phi) per pair, no separate sum of ck y).  Five reduction vectors, reduced four inducing points at a time.
-template <int SPL>
-__device__ void spike_body_periodic_full(const EngineView& ev, const double* __restrict__ C, int ch, int k, double* red) {
-  constexpr int NV = 5, JG = 4;   // 20 rows: 13 KB of LDS per wave, so that three waves per SIMD fit
+template <int SPL, typename T>
+__device__ void spike_body_periodic_full(const EngineView& ev, const double* __restrict__ C, int ch, int k, double* red_d) {
+  constexpr int NV = 5, JG = 4;   // 20 rows: 13 KB of LDS per wave (fp64), so that three waves per SIMD fit
   const int lane = threadIdx.x;
   const SpikeChunk c = ev.chunks[ch];
   const LatentMeta m = ev.meta[k];
@@ -70,23 +80,29 @@ __device__ void spike_body_periodic_full(const EngineView& ev, const double* __r
   const double L2E = 1.4426950408889634074;
   const double sc = 4.0 * p.ip, hh = 0.5 * p.h * L2E;      // phase in quarter turns: (pi/2) (t 4/p)
   const double w2 = -1.0 / (2.0 * hh), w3 = 1.0 / sc;
+  const T hhT = (T)hh;
+  T* red = (T*)red_d;
 
   // (the neuron ids are re-read in the epilogue instead of living in VGPRs through the pair loop: 168 VGPRs = 3 waves / SIMD)
-  double cw[SPL], mu[SPL], st[SPL], ct[SPL], stt[SPL], ctt[SPL];
+  T cw[SPL], mu[SPL], st[SPL], ct[SPL], stt[SPL], ctt[SPL];
 #pragma unroll
   for (int i = 0; i < SPL; ++i) {
     int idx = lane * SPL + i;          // lane owns SPL consecutive spikes
     bool ok = idx < c.count;
     long long gs = c.start + (ok ? idx : 0);
     const double tsc = ev.spk_t[gs] * sc;
-    cw[i] = ok ? C[(long long)ev.spk_n[gs] * K + k] : 0.0;
-    mu[i] = 0.0;
-    sv_sincos_quarter(tsc, st[i], ct[i]);
-    stt[i] = st[i] * tsc;
-    ctt[i] = ct[i] * tsc;
+    cw[i] = ok ? (T)C[(long long)ev.spk_n[gs] * K + k] : (T)0;
+    mu[i] = (T)0;
+    double sd, cd;
+    sv_sincos_quarter(tsc, sd, cd);
+    st[i] = (T)sd;
+    ct[i] = (T)cd;
+    stt[i] = (T)(sd * tsc);
+    ctt[i] = (T)(cd * tsc);
   }
-  double* zsc = red + NV * JG * 65;   // per inducing point: scaled z | sin phi | cos phi | hh sin phi | hh cos phi
-  double* rs = zsc + 5 * 64;          // NV * JG reduced sums of the current group
+  double* zsc = (double*)(red + NV * JG * 65 + ((NV * JG * 65) & 1));   // per inducing point (fp64): scaled z | sin | cos
+  T* hsc = (T*)(zsc + 3 * 64);        // hh sin phi | hh cos phi | a_j   (pair-loop operands, scalar type T)
+  T* rs = hsc + 3 * 64;               // NV * JG reduced sums of the current group
   if (lane < M) {
     const double zq = z[lane] * sc;
     double sz, cz;
@@ -94,8 +110,9 @@ __device__ void spike_body_periodic_full(const EngineView& ev, const double* __r
     zsc[lane] = zq;
     zsc[64 + lane] = sz;
     zsc[128 + lane] = cz;
-    zsc[192 + lane] = hh * sz;
-    zsc[256 + lane] = hh * cz;
+    hsc[lane] = (T)(hh * sz);
+    hsc[64 + lane] = (T)(hh * cz);
+    hsc[128 + lane] = (T)a[lane];
   }
   __syncthreads();
   double t0acc = 0.0, t1acc = 0.0;
@@ -104,20 +121,20 @@ __device__ void spike_body_periodic_full(const EngineView& ev, const double* __r
 #pragma unroll
     for (int jj = 0; jj < JG; ++jj) {
       const int j = jb + jj;
-      double p0 = 0.0, qa = 0.0, qb = 0.0, qc = 0.0, qd = 0.0;
+      T p0 = 0, qa = 0, qb = 0, qc = 0, qd = 0;
       if (j < M) {
-        const double aj = a[j], hs = zsc[192 + j], hc = zsc[256 + j];
+        const T hs = hsc[j], hc = hsc[64 + j], aj = hsc[128 + j];
 #pragma unroll
         for (int i = 0; i < SPL; ++i) {
-          const double y = fma(ct[i], hc, fma(st[i], hs, -hh));
-          const double kt = sv_exp2_neg(y);          // y <= ~1e-16: the kernel only needs |y - rint(y)| <= 1/2
-          const double ck = cw[i] * kt;
+          const T y = sv_fma(ct[i], hc, sv_fma(st[i], hs, -hhT));
+          const T kt = sv_exp2_neg(y);               // y <= ~1e-16: the kernel only needs |y - rint(y)| <= 1/2
+          const T ck = cw[i] * kt;
           p0 += ck;
-          qa = fma(ck, st[i], qa);
-          qb = fma(ck, ct[i], qb);
-          qc = fma(ck, stt[i], qc);
-          qd = fma(ck, ctt[i], qd);
-          mu[i] = fma(kt, aj, mu[i]);
+          qa = sv_fma(ck, st[i], qa);
+          qb = sv_fma(ck, ct[i], qb);
+          qc = sv_fma(ck, stt[i], qc);
+          qd = sv_fma(ck, ctt[i], qd);
+          mu[i] = sv_fma(kt, aj, mu[i]);
         }
       }
       red[(0 * JG + jj) * 65 + lane] = p0;
@@ -131,7 +148,7 @@ __device__ void spike_body_periodic_full(const EngineView& ev, const double* __r
 #pragma unroll
     for (int v0 = 0; v0 < NV * JG; v0 += 16) {
       const int v = v0 + (lane & 15), qd4 = lane >> 4;
-      double s = 0.0;
+      T s = 0;
       if (v < NV * JG) {
 #pragma unroll
         for (int e = 0; e < 16; ++e) s += red[v * 65 + qd4 * 16 + e];
@@ -171,25 +188,28 @@ __device__ void spike_body_periodic_full(const EngineView& ev, const double* __r
     const int idx = lane * SPL + i;
     nid[i] = (idx < c.count) ? ev.spk_n[c.start + idx] : -1;
   }
+  double mud[SPL];
+#pragma unroll
+  for (int i = 0; i < SPL; ++i) mud[i] = (double)mu[i];
   if (c.split) {
     double tot = 0.0;
 #pragma unroll
-    for (int i = 0; i < SPL; ++i) tot += (nid[i] >= 0) ? mu[i] : 0.0;
+    for (int i = 0; i < SPL; ++i) tot += (nid[i] >= 0) ? mud[i] : 0.0;
     tot = wave_sum(tot);
     if (lane == 0) ev.splitPart[(long long)ch * K + k] = p.s2 * tot;
   } else {
     double* out = ev.gCspk + (long long)r * ev.N * K + k;
 #pragma unroll
-    for (int i = 0; i < SPL; ++i) mu[i] *= p.s2;
-    seg_emit_lane<SPL>(nid, mu, out, K, lane);
+    for (int i = 0; i < SPL; ++i) mud[i] *= p.s2;
+    seg_emit_lane<SPL>(nid, mud, out, K, lane);
   }
 }
 
-template <int KT, bool FULL, int SPL>
+template <int KT, bool FULL, int SPL, typename T>
 __device__ void spike_body(const EngineView& ev, const double* __restrict__ C, int ch, int k,
-                           double* red) {
+                           double* red_d) {
   if constexpr (KT == SV_PERIODIC && FULL) {
-    spike_body_periodic_full<SPL>(ev, C, ch, k, red);
+    spike_body_periodic_full<SPL, T>(ev, C, ch, k, red_d);
     return;
   }
   // This body: RBF (value-only or full) and periodic value-only.  NV partial-sum vectors per inducing point: P0 | P0 P1 P2
@@ -202,6 +222,7 @@ __device__ void spike_body(const EngineView& ev, const double* __restrict__ C, i
   const KPar p = make_kpar(m, ev.theta + 2 * k);
   const double* __restrict__ z = ev.Zs + m.offM + (long long)r * M;
   const double* __restrict__ a = ev.a + m.offM + (long long)r * M;
+  T* red = (T*)red_d;
   // Scaled coordinates so that ktil = 2^y with no further multiplies:
   //   RBF      u = (t - z) sc, sc = sqrt(h log2 e):  y = -u^2          bz = u / sc,  b0 = -y / sc^2
   //   periodic w = (t - z) 4/p:  (sn, cs) = sincos(pi/2 w), y = hh (cs - 1), hh = h log2(e) / 2
@@ -219,32 +240,40 @@ __device__ void spike_body(const EngineView& ev, const double* __restrict__ C, i
     w2 = -1.0 / (2.0 * hh);
     w3 = 1.0 / sc;
   }
+  const T hhT = (T)hh;
 
-  double ts[SPL], cw[SPL], mu[SPL];
+  T ts[SPL], cw[SPL], mu[SPL];
   // periodic: sin / cos of the spike phase 2 pi t / p, once per spike; the pair (spike, inducing point)
   // then costs 4 FMAs by angle addition instead of a sincos
-  double st[SPL], ct[SPL];
+  T st[SPL], ct[SPL];
   int nid[SPL];
 #pragma unroll
   for (int i = 0; i < SPL; ++i) {
     int idx = lane * SPL + i;          // lane owns SPL consecutive spikes
     bool ok = idx < c.count;
     long long gs = c.start + (ok ? idx : 0);
-    ts[i] = ev.spk_t[gs] * sc;
+    const double tsd = ev.spk_t[gs] * sc;
+    ts[i] = (T)tsd;
     nid[i] = ok ? ev.spk_n[gs] : -1;
-    cw[i] = ok ? C[(long long)nid[i] * K + k] : 0.0;
-    mu[i] = 0.0;
-    if (KT == SV_PERIODIC) sv_sincos_quarter(ts[i], st[i], ct[i]);
+    cw[i] = ok ? (T)C[(long long)nid[i] * K + k] : (T)0;
+    mu[i] = (T)0;
+    if (KT == SV_PERIODIC) {
+      double sd, cd;
+      sv_sincos_quarter(tsd, sd, cd);
+      st[i] = (T)sd;
+      ct[i] = (T)cd;
+    }
   }
-  double* zsc = red + NV * JG * 65;   // 3 * 64 doubles behind the reduction area: scaled z, sin / cos of its phase
+  T* zsc = red + NV * JG * 65;        // 4 * 64 values behind the reduction area: scaled z, sin / cos of its phase, a_j
   if (lane < M) {
     const double zq = z[lane] * sc;
-    zsc[lane] = zq;
+    zsc[lane] = (T)zq;
+    zsc[192 + lane] = (T)a[lane];
     if (KT == SV_PERIODIC) {
       double sz, cz;
       sv_sincos_quarter(zq, sz, cz);
-      zsc[64 + lane] = sz;
-      zsc[128 + lane] = cz;
+      zsc[64 + lane] = (T)sz;
+      zsc[128 + lane] = (T)cz;
     }
   }
   __syncthreads();
@@ -254,33 +283,33 @@ __device__ void spike_body(const EngineView& ev, const double* __restrict__ C, i
 #pragma unroll
     for (int jj = 0; jj < JG; ++jj) {
       const int j = jb + jj;
-      double p0 = 0.0, p1 = 0.0, p2 = 0.0;
+      T p0 = 0, p1 = 0, p2 = 0;
       if (j < M) {
-        const double zs = zsc[j], aj = a[j];
-        double sz = 0.0, cz = 0.0;
+        const T zs = zsc[j], aj = zsc[192 + j];
+        T sz = 0, cz = 0;
         if (KT == SV_PERIODIC) {
           sz = zsc[64 + j];
           cz = zsc[128 + j];
         }
 #pragma unroll
         for (int i = 0; i < SPL; ++i) {
-          double y, u = 0.0;
+          T y, u = 0;
           if (KT == SV_RBF) {
             u = ts[i] - zs;
             y = -(u * u);
           } else {
-            const double cs = fma(st[i], sz, ct[i] * cz);     // cos(2 pi (t - z) / p)
-            y = fma(cs, hh, -hh);
+            const T cs = sv_fma(st[i], sz, ct[i] * cz);       // cos(2 pi (t - z) / p)
+            y = sv_fma(cs, hhT, -hhT);
           }
-          const double kt = sv_exp2_neg(y);
+          const T kt = sv_exp2_neg(y);
           if (FULL) {                                         // RBF only (periodic: spike_body_periodic_full)
-            const double ck = cw[i] * kt;
+            const T ck = cw[i] * kt;
             p0 += ck;
-            p2 = fma(ck, y, p2);
-            p1 = fma(ck, u, p1);
-            mu[i] = fma(kt, aj, mu[i]);
+            p2 = sv_fma(ck, y, p2);
+            p1 = sv_fma(ck, u, p1);
+            mu[i] = sv_fma(kt, aj, mu[i]);
           } else {
-            p0 = fma(cw[i], kt, p0);
+            p0 = sv_fma(cw[i], kt, p0);
           }
         }
       }
@@ -295,13 +324,14 @@ __device__ void spike_body(const EngineView& ev, const double* __restrict__ C, i
 #pragma unroll
     for (int v0 = 0; v0 < NV * JG; v0 += 16) {
       const int v = v0 + (lane & 15), qd = lane >> 4;
-      double s = 0.0;
+      T sT = 0;
       if (v < NV * JG) {
 #pragma unroll
-        for (int e = 0; e < 16; ++e) s += red[v * 65 + qd * 16 + e];
+        for (int e = 0; e < 16; ++e) sT += red[v * 65 + qd * 16 + e];
       }
-      s += __shfl_xor(s, 16, 64);
-      s += __shfl_xor(s, 32, 64);
+      sT += __shfl_xor(sT, 16, 64);
+      sT += __shfl_xor(sT, 32, 64);
+      const double s = (double)sT;
       const int j = jb + (v % JG);
       if (lane < 16 && v < NV * JG && j < M) {
         const long long o = (long long)ch * ev.sumM + m.colM + j;
@@ -325,17 +355,20 @@ __device__ void spike_body(const EngineView& ev, const double* __restrict__ C, i
       ev.Tpart[((long long)ch * K + k) * 2 + 1] = t1;
     }
     // spike part of dC[n, k]: per-neuron sums of mu_s
+    double mud[SPL];
+#pragma unroll
+    for (int i = 0; i < SPL; ++i) mud[i] = (double)mu[i];
     if (c.split) {
       double tot = 0.0;
 #pragma unroll
-      for (int i = 0; i < SPL; ++i) tot += (nid[i] >= 0) ? mu[i] : 0.0;
+      for (int i = 0; i < SPL; ++i) tot += (nid[i] >= 0) ? mud[i] : 0.0;
       tot = wave_sum(tot);
       if (lane == 0) ev.splitPart[(long long)ch * K + k] = p.s2 * tot;
     } else {
       double* out = ev.gCspk + (long long)r * ev.N * K + k;
 #pragma unroll
-      for (int i = 0; i < SPL; ++i) mu[i] *= p.s2;
-      seg_emit_lane<SPL>(nid, mu, out, K, lane);
+      for (int i = 0; i < SPL; ++i) mud[i] *= p.s2;
+      seg_emit_lane<SPL>(nid, mud, out, K, lane);
     }
   }
 }
@@ -343,21 +376,21 @@ __device__ void spike_body(const EngineView& ev, const double* __restrict__ C, i
 // One launch over all (chunk, latent) work items; the covariance type is resolved per block.  Longest jobs first: all
 // periodic items, then the RBF ones, so that the tail of the grid is filled with the shorter work items (a small shard
 // is only 2-3 occupancy rounds long).  Registers are capped so that 3 waves / SIMD stay resident.
-template <bool FULL, int SPL>
+template <bool FULL, int SPL, typename T = double>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 8))) void k_spike(EngineView ev,
                                                                                          const double* __restrict__ C) {
-  // LDS bounds the waves per CU: RBF full 3 x 8 rows + 3 x 64 (14.0 KB), periodic full 5 x 4 rows + 5 x 64 + 32 (13.2 KB),
-  // value-only 8 rows
-  constexpr int LDS_RBF = 3 * SV_SPIKE_JG * 65 + 3 * 64, LDS_PER = 5 * 4 * 65 + 5 * 64 + 32;
-  __shared__ double red[FULL ? (LDS_RBF > LDS_PER ? LDS_RBF : LDS_PER) : SV_SPIKE_JG * 65 + 3 * 64];
+  // LDS bounds the waves per CU: RBF full 3 x 8 rows + 4 x 64 (14.5 KB in fp64), periodic full 5 x 4 rows + ~7 x 64 (14 KB),
+  // value-only 8 rows; half of that in fp32
+  constexpr int LDS_RBF = 3 * SV_SPIKE_JG * 65 + 4 * 64, LDS_PER = 5 * 4 * 65 + 7 * 64 + 32;
+  __shared__ double red[FULL ? (LDS_RBF > LDS_PER ? LDS_RBF : LDS_PER) : SV_SPIKE_JG * 65 + 4 * 64];
   const int item = blockIdx.x;
   const int nper = ev.ntype[SV_PERIODIC], nrbf = ev.ntype[SV_RBF];
   const int nb_per = ev.nchunks * nper;
   if (item < nb_per) {
-    spike_body<SV_PERIODIC, FULL, SPL>(ev, C, item / nper, ev.klist[SV_PERIODIC][item % nper], red);
+    spike_body<SV_PERIODIC, FULL, SPL, T>(ev, C, item / nper, ev.klist[SV_PERIODIC][item % nper], red);
   } else {
     const int it = item - nb_per;
-    spike_body<SV_RBF, FULL, SPL>(ev, C, it / nrbf, ev.klist[SV_RBF][it % nrbf], red);
+    spike_body<SV_RBF, FULL, SPL, T>(ev, C, it / nrbf, ev.klist[SV_RBF][it % nrbf], red);
   }
 }
 

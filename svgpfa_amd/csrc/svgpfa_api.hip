@@ -28,6 +28,7 @@ struct svgpfa_engine {
   hipStream_t stream = nullptr;
   int device = 0;
   int Mmax = 0, NT = 1;
+  int precision = SVGPFA_PRECISION_FP64;   // MIXED: fp32 spike pass and quadrature ELL (BASELINE config 5)
   int ell_parts = 0, KKT = 1;  // ell_parts > 0: MFMA GEMM form of the quadrature term
   int ell_lc[2] = {0, 0};      // looped tiles resident in LDS per role (fewer than all: streamed in chunks)
   int ell_nw = 4;              // waves per block of the ELL kernels
@@ -109,7 +110,8 @@ static size_t lds_item_bwd(int NT, int NWB = 4) { return sv_item_bwd_lds_doubles
 static size_t lds_qell_mfma_lc(const svgpfa_engine* e, int role, int lc) {
   size_t K2 = 2 * e->v.K, KKP = (K2 + 3) & ~(size_t)3, LDK = KKP + 2;
   size_t Lp = (((role == 0 ? e->v.Q : e->v.N) + 15) / 16) * 16;
-  return (((size_t)lc * 16 + 1) * LDK + Lp + (size_t)e->ell_nw * 16 * LDK + 8) * 8;
+  const size_t elt = e->precision == SVGPFA_PRECISION_MIXED ? 4 : 8;      // operands in LDS: float in mixed precision
+  return (((size_t)lc * 16 + 1) * LDK + Lp + (size_t)e->ell_nw * 16 * LDK + 1) * elt + 9 * 8;
 }
 static int qell_chunk(const svgpfa_engine* e, int role) {
   const int LT = ((role == 0 ? e->v.Q : e->v.N) + 15) / 16;
@@ -154,6 +156,9 @@ int svgpfa_create(const svgpfa_dims* d, int device, svgpfa_engine** out) {
       !d->kernel_type)
     FAIL(e, SVGPFA_ERR_INVALID, "svgpfa_create: non-positive dimension or NULL descriptor array");
   if (d->n_latents > SV_MAX_K) FAIL(e, SVGPFA_ERR_UNSUPPORTED, "n_latents > 32");
+  if (d->precision != SVGPFA_PRECISION_FP64 && d->precision != SVGPFA_PRECISION_MIXED)
+    FAIL(e, SVGPFA_ERR_INVALID, "svgpfa_create: unknown precision mode");
+  e->precision = d->precision;
   HIPCHK(e, hipSetDevice(device));
   EngineView& v = e->v;
   v.R = d->n_trials; v.N = d->n_neurons; v.K = d->n_latents; v.Q = d->n_quad;
@@ -242,8 +247,13 @@ int svgpfa_create(const svgpfa_dims* d, int device, svgpfa_engine** out) {
               if (!rc) rc = allow_lds(e, (k_item_bwd<NT_, true>), lds_item_bwd(NT_));
               if (!rc) rc = allow_lds(e, (k_item_bwd<NT_, false>), lds_item_bwd(NT_)));
   if (rc) return rc;
-  DISPATCH_KS(e->KKT, rc = allow_lds(e, (k_quad_ell_mfma<KS_, 0>), lds_qell_mfma(e, 0));
-              if (!rc) rc = allow_lds(e, (k_quad_ell_mfma<KS_, 2>), std::max(lds_qell_mfma(e, 0), lds_qell_mfma(e, 1))));
+  if (e->precision == SVGPFA_PRECISION_MIXED) {
+    DISPATCH_KS(e->KKT, rc = allow_lds(e, (k_quad_ell_mfma<KS_, 0, float>), lds_qell_mfma(e, 0));
+                if (!rc) rc = allow_lds(e, (k_quad_ell_mfma<KS_, 2, float>), std::max(lds_qell_mfma(e, 0), lds_qell_mfma(e, 1))));
+  } else {
+    DISPATCH_KS(e->KKT, rc = allow_lds(e, (k_quad_ell_mfma<KS_, 0, double>), lds_qell_mfma(e, 0));
+                if (!rc) rc = allow_lds(e, (k_quad_ell_mfma<KS_, 2, double>), std::max(lds_qell_mfma(e, 0), lds_qell_mfma(e, 1))));
+  }
   if (rc) return rc;
   return SVGPFA_OK;
 }
@@ -472,13 +482,24 @@ static int launch_quad_ell(svgpfa_engine* e, const double* C, const double* d, i
   // role 0 (dC, dd and the ELL value) always runs: its column sums give sum E; role 1 (latent adjoints) rides in the
   // same launch when some latent-side gradient is wanted
   dim3 gm(v.R * e->ell_parts), bm(64 * e->ell_nw);
+  const bool f32 = e->precision == SVGPFA_PRECISION_MIXED;
   if (want_lat) {
     const size_t l2 = std::max(lds_qell_mfma(e, 0), lds_qell_mfma(e, 1));
-    DISPATCH_KS(e->KKT, hipLaunchKernelGGL((k_quad_ell_mfma<KS_, 2>), dim3(2 * gm.x), bm, l2, e->stream, v, C, d, want_cd,
-                                           1, e->ell_parts, e->ell_lc[0], e->ell_lc[1]));
+    if (f32) {
+      DISPATCH_KS(e->KKT, hipLaunchKernelGGL((k_quad_ell_mfma<KS_, 2, float>), dim3(2 * gm.x), bm, l2, e->stream, v, C, d,
+                                             want_cd, 1, e->ell_parts, e->ell_lc[0], e->ell_lc[1]));
+    } else {
+      DISPATCH_KS(e->KKT, hipLaunchKernelGGL((k_quad_ell_mfma<KS_, 2, double>), dim3(2 * gm.x), bm, l2, e->stream, v, C, d,
+                                             want_cd, 1, e->ell_parts, e->ell_lc[0], e->ell_lc[1]));
+    }
   } else {
-    DISPATCH_KS(e->KKT, hipLaunchKernelGGL((k_quad_ell_mfma<KS_, 0>), gm, bm, lds_qell_mfma(e, 0), e->stream, v, C, d,
-                                           want_cd, 1, e->ell_parts, e->ell_lc[0], e->ell_lc[1]));
+    if (f32) {
+      DISPATCH_KS(e->KKT, hipLaunchKernelGGL((k_quad_ell_mfma<KS_, 0, float>), gm, bm, lds_qell_mfma(e, 0), e->stream, v, C,
+                                             d, want_cd, 1, e->ell_parts, e->ell_lc[0], e->ell_lc[1]));
+    } else {
+      DISPATCH_KS(e->KKT, hipLaunchKernelGGL((k_quad_ell_mfma<KS_, 0, double>), gm, bm, lds_qell_mfma(e, 0), e->stream, v, C,
+                                             d, want_cd, 1, e->ell_parts, e->ell_lc[0], e->ell_lc[1]));
+    }
   }
   HIPCHK(e, hipGetLastError());
   return SVGPFA_OK;
@@ -553,7 +574,10 @@ int svgpfa_elbo(svgpfa_engine* e, const double* const* mean, const double* const
       HIPCHK(e, hipEventRecord(evp->first, sk));
     }
     const dim3 gs(v.nchunks * v.K), bs(64);
-    if (e->spl == 4) {
+    if (e->precision == SVGPFA_PRECISION_MIXED) {
+      if (full) hipLaunchKernelGGL((k_spike<true, 8, float>), gs, bs, 0, sk, v, C);
+      else hipLaunchKernelGGL((k_spike<false, 8, float>), gs, bs, 0, sk, v, C);
+    } else if (e->spl == 4) {
       if (full) hipLaunchKernelGGL((k_spike<true, 4>), gs, bs, 0, sk, v, C);
       else hipLaunchKernelGGL((k_spike<false, 4>), gs, bs, 0, sk, v, C);
     } else {

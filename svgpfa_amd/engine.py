@@ -25,7 +25,7 @@ class Engine:
     """One engine = one GPU = one contiguous block of trials (see include/svgpfa.h)."""
 
     def __init__(self, n_trials, n_neurons, n_quad, n_ind, kernel_types, scales=None,
-                 lengthscale_scales=None, period_scales=None, device=None):
+                 lengthscale_scales=None, period_scales=None, device=None, precision="fp64"):
         self._h = None
         self.lib = _lib.load()
         if not torch.cuda.is_available():
@@ -41,8 +41,12 @@ class Engine:
         arr_d = lambda xs: (ctypes.c_double * K)(*[float(x) for x in xs]) if xs is not None else None
         self._keep = (arr_i(self.Ms), arr_i(self.ktypes), arr_d(scales), arr_d(lengthscale_scales),
                       arr_d(period_scales))
+        if precision not in ("fp64", "mixed"):
+            raise ValueError("precision must be 'fp64' or 'mixed'")
+        self.precision = precision
         dims = _lib.Dims(self.R, self.N, K, self.Q, self._keep[0], self._keep[1],
-                         self._keep[2], self._keep[3], self._keep[4])
+                         self._keep[2], self._keep[3], self._keep[4],
+                         _lib.PRECISION_MIXED if precision == "mixed" else _lib.PRECISION_FP64)
         h = ctypes.c_void_p()
         rc = self.lib.svgpfa_create(ctypes.byref(dims), self.device.index, ctypes.byref(h))
         self._h = h
@@ -238,14 +242,14 @@ class Engine:
         return tot.value, n.value
 
 
-def engine_from_problem(prob, device=None):
+def engine_from_problem(prob, device=None, precision="fp64"):
     """Build an Engine + device parameter tensors from a numpy problem (svgpfa_amd.utils.synthetic
     layout).  Returns (engine, params) with params = dict(mean, cholVecs, Z, theta, C, d)."""
     from .utils import synthetic
     dev = torch.device("cuda", torch.cuda.current_device() if device is None else device)
     kt = [_lib.KERNEL_RBF if t == synthetic.RBF else _lib.KERNEL_PERIODIC for t in prob["kernel_types"]]
     eng = Engine(prob["R"], prob["N"], prob["Q"], prob["Ms"], kt, prob.get("scales"),
-                 prob.get("lengthscale_scales"), prob.get("period_scales"), device=dev.index)
+                 prob.get("lengthscale_scales"), prob.get("period_scales"), device=dev.index, precision=precision)
     td = lambda a, dt=torch.float64: torch.as_tensor(np.ascontiguousarray(a), dtype=dt).to(dev).contiguous()
     eng.set_reg(prob["reg"])
     eng.set_quad(td(prob["quad_points"]), td(prob["quad_weights"]))

@@ -32,7 +32,9 @@ class SVGPFAModelFactory:
     @staticmethod
     def buildModelPyTorch(kernels, conditionalDist=PointProcess, linkFunction=ExponentialLink,
                           embeddingType=LinearEmbedding, kernelMatrixInvMethod=kernelMatrixInvChol,
-                          indPointsCovRep=indPointsCovChol, device=None):
+                          indPointsCovRep=indPointsCovChol, device=None, precision="fp64"):
+        """precision (extension, not in the reference's signature): "fp64" (the reference's arithmetic) or "mixed"
+        (fp32 spike pass and quadrature ELL with fp64 Kzz / Cholesky / KL: BASELINE config 5)."""
         if conditionalDist != PointProcess:
             raise ValueError("Invalid conditionalDist=%s (only PointProcess is built by the HIP engine)"
                              % repr(conditionalDist))
@@ -44,6 +46,7 @@ class SVGPFAModelFactory:
             raise ValueError("Invalid indPointsCovRep")
         if kernelMatrixInvMethod != kernelMatrixInvChol:
             raise ValueError("Invalid kernelMatrixInvMethod (HIP engine: kernelMatrixInvChol only)")
-        model = svLowerBound.SVLowerBound(device=device, rank1_plus_diag=(indPointsCovRep == indPointsCovRank1PlusDiag))
+        model = svLowerBound.SVLowerBound(device=device, rank1_plus_diag=(indPointsCovRep == indPointsCovRank1PlusDiag),
+                                          precision=precision)
         model.setKernels(kernels=kernels)
         return model

@@ -128,7 +128,7 @@ class _ELLGivenStatsFunction(torch.autograd.Function):
 
 class SVLowerBound:
 
-    def __init__(self, device=None, rank1_plus_diag=False):
+    def __init__(self, device=None, rank1_plus_diag=False, precision="fp64"):
         if not torch.cuda.is_available():
             raise RuntimeError("svgpfa_amd.stats.SVLowerBound needs a ROCm GPU; there is no CPU fallback")
         self._device = torch.device("cuda", torch.cuda.current_device() if device is None else device)
@@ -137,6 +137,11 @@ class SVLowerBound:
         # q(u) covariance representation: Cholesky vectors (default) or S = q q^T + diag(d^2)
         # (reference svPosteriorOnIndPoints.py:86-119, factory switch indPointsCovRank1PlusDiag)
         self._rank1 = bool(rank1_plus_diag)
+        # "fp64" = the reference's arithmetic; "mixed" = fp32 spike pass and quadrature ELL, fp64 Kzz / Cholesky / KL
+        # (BASELINE config 5; include/svgpfa.h SVGPFA_PRECISION_MIXED)
+        if precision not in ("fp64", "mixed"):
+            raise ValueError("precision must be 'fp64' or 'mixed'")
+        self._precision = precision
         self._qSVec = self._qSDiag = None
         self._kernels = None
         self._reg = None
@@ -276,14 +281,16 @@ class SVLowerBound:
         key = (R, self._N, Q, Ms, tuple(k._engine_type for k in self._kernels),
                tuple(float(k._scale) for k in self._kernels),
                tuple(float(k._lengthscaleScale) for k in self._kernels),
-               tuple(float(getattr(k, "_periodScale", 1.0)) for k in self._kernels), self._data_version)
+               tuple(float(getattr(k, "_periodScale", 1.0)) for k in self._kernels), self._data_version,
+               getattr(self, "_precision", "fp64"))
         if self._engine is not None and key == self._engine_key:
             return
         if self._R_data != R or self._quad[0].shape[0] != R:
             raise ValueError("number of trials differs between measurements, quadrature and parameters")
         if self._engine is not None:
             self._engine.close()
-        eng = Engine(R, self._N, Q, Ms, key[4], key[5], key[6], key[7], device=self._device.index)
+        eng = Engine(R, self._N, Q, Ms, key[4], key[5], key[6], key[7], device=self._device.index,
+                     precision=getattr(self, "_precision", "fp64"))
         eng.set_reg(self._reg)
         eng.set_quad(self._quad[0], self._quad[1])
         off, t, n = self._spikes

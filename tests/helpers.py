@@ -51,7 +51,7 @@ def build_kernels(prob):
     return out
 
 
-def build_model(prob):
+def build_model(prob, **factory_kw):
     """Build the model exactly as a reference caller would (CPU tensors in, nested spike lists)."""
     from svgpfa_amd.stats.svGPFAModelFactory import SVGPFAModelFactory
     t = lambda a: torch.from_numpy(np.array(a, dtype=np.float64, copy=True, order="C"))
@@ -69,7 +69,7 @@ def build_model(prob):
         "embedding": {"C0": t(prob["C"]), "d0": t(prob["d"])}}
     ell = {"leg_quad_points": t(prob["quad_points"]).unsqueeze(-1),
            "leg_quad_weights": t(prob["quad_weights"]).unsqueeze(-1)}
-    model = SVGPFAModelFactory.buildModelPyTorch(kernels=build_kernels(prob))
+    model = SVGPFAModelFactory.buildModelPyTorch(kernels=build_kernels(prob), **factory_kw)
     model.setParamsAndData(measurements=measurements, initial_params=initial_params,
                            eLLCalculationParams=ell, priorCovRegParam=prob["reg"])
     return model
