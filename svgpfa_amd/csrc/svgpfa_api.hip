@@ -333,6 +333,10 @@ int svgpfa_set_spikes(svgpfa_engine* e, const int64_t* off, const double* times,
   v.S = (int)S;
   // granularity of the spike pass: optional half-size chunks for small shards (off by default: measured slower)
   e->spl = ((S + 459) / 460) * v.K < e->small_spike_waves ? 4 : 8;
+  if (e->precision == SVGPFA_PRECISION_MIXED) {      // fp32 pair loop: per-item overheads weigh more, larger work items
+    e->spl = 16;
+    if (getenv("SVGPFA_SPL_F32")) e->spl = atoi(getenv("SVGPFA_SPL_F32")) == 8 ? 8 : 16;
+  }
   const long long CHUNK = 64LL * e->spl;
   std::vector<int32_t> nh((size_t)S);
   if (S) HIPCHK(e, hipMemcpy(nh.data(), neuron, sizeof(int32_t) * S, hipMemcpyDeviceToHost));
@@ -575,8 +579,13 @@ int svgpfa_elbo(svgpfa_engine* e, const double* const* mean, const double* const
     }
     const dim3 gs(v.nchunks * v.K), bs(64);
     if (e->precision == SVGPFA_PRECISION_MIXED) {
-      if (full) hipLaunchKernelGGL((k_spike<true, 8, float>), gs, bs, 0, sk, v, C);
-      else hipLaunchKernelGGL((k_spike<false, 8, float>), gs, bs, 0, sk, v, C);
+      if (e->spl == 16) {
+        if (full) hipLaunchKernelGGL((k_spike<true, 16, float>), gs, bs, 0, sk, v, C);
+        else hipLaunchKernelGGL((k_spike<false, 16, float>), gs, bs, 0, sk, v, C);
+      } else {
+        if (full) hipLaunchKernelGGL((k_spike<true, 8, float>), gs, bs, 0, sk, v, C);
+        else hipLaunchKernelGGL((k_spike<false, 8, float>), gs, bs, 0, sk, v, C);
+      }
     } else if (e->spl == 4) {
       if (full) hipLaunchKernelGGL((k_spike<true, 4>), gs, bs, 0, sk, v, C);
       else hipLaunchKernelGGL((k_spike<false, 4>), gs, bs, 0, sk, v, C);
