@@ -132,6 +132,25 @@ int svgpfa_latent_stats(svgpfa_engine* e,
                         const double* const* mean, const double* const* cholvec,
                         double* mu_quad, double* var_quad, double* mu_spk, double* var_spk);
 
+/* Backward of svgpfa_latent_stats plus the KL term: given the adjoints of a caller-defined expected log-likelihood wrt
+ * the statistics (g_mu_quad / g_var_quad R x Q x K, g_mu_spk / g_var_spk S x K: d ELL / d mean and variance of every latent
+ * at every quadrature node and spike), the gradients of  ELL - KL  wrt the groups in grad_mask (VARIATIONAL, KERNELS,
+ * INDPOINTS; the embedding is the caller's).  This is what autograd does for the reference when the likelihood is not
+ * the exponential-link point process, e.g. the Gauss-Hermite link of stats/expectedLogLikelihood.py:215-255, whose
+ * spike term has no a-priori adjoint: the GP algebra (whitened chain, Kzz path, KL) stays in HIP, the link in the
+ * caller.  shared (svgpfa_shared_len doubles): [2] = KL and the trailing dtheta entries are written; the per-trial
+ * gradients go to g_mean / g_cholvec / g_Z as in svgpfa_elbo. */
+int svgpfa_latent_stats_backward(svgpfa_engine* e,
+                                 const double* const* mean, const double* const* cholvec,
+                                 const double* g_mu_quad, const double* g_var_quad,
+                                 const double* g_mu_spk, const double* g_var_spk,
+                                 unsigned grad_mask, double* shared,
+                                 double* const* g_mean, double* const* g_cholvec, double* const* g_Z);
+
+/* KL divergence term alone (stats/klDivergence.py:18-44) of the parameters of the latest svgpfa_elbo /
+ * svgpfa_latent_stats / svgpfa_predict call: out[0]. */
+int svgpfa_kl(svgpfa_engine* e, double* out);
+
 /* SVLowerBound.evalELLSumAcrossTrialsAndNeurons(svPosteriorOnLatentsStats=...)
  * (stats/svLowerBound.py:72-75): ELL with the stats of the last svgpfa_latent_stats call frozen.
  * out: [0] ELL, then dELL/dC (N x K), dELL/dd (N)  -- length 1 + N*K + N. */

@@ -89,6 +89,7 @@ struct EngineView {
   double* splitPart;                               // [nchunks][K] spike part of dC of split chunks
   double* muspk;                                   // [K][S] (stats API only)
   double* varspk;                                  // [K][S] (stats API only)
+  double* gmuspk; double* gvarspk;                 // [K][S] adjoints at the spikes (svgpfa_latent_stats_backward only)
   double* gCpart; double* gdpart; double* ellq;    // [ncd][N][2K] raw sums (E^T mu | E^T var), [ncd][N], [nell]
   double* ells; double* gthitem;                   // [R*K], [R*K*2]
   double* Mseg;                                    // [N][K] sum over spikes of mu_spk per neuron (stats path)

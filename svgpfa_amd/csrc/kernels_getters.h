@@ -1,8 +1,8 @@
 // Kernels behind the KernelsMatricesStore getters and the statistics API (tests, plots, the embedding M-step): none
 // of them is on the ELBO hot path.
 //   k_ktz           : materialise a Ktz block (reference kernelsMatricesStore.py:186-195, :208-221)
-//   k_transpose_ks  : [K][S] -> [S][K] (spike-time statistics as the reference lays them out)
-//   k_transpose_rkq : [R][K][Q] -> [R][Q][K] (quadrature statistics as the reference lays them out)
+//   k_transpose_b   : batched 2-D transpose ([R][K][Q] <-> [R][Q][K], [K][S] <-> [S][K])
+//   k_sum_kl        : the KL term alone
 #pragma once
 #include "engine_common.h"
 
@@ -29,20 +29,20 @@ __global__ void k_ktz(EngineView ev, int k, const double* times, const long long
   out[id] = p.s2 * (m.ktype == SV_RBF ? kern_val<SV_RBF>(d, p) : kern_val<SV_PERIODIC>(d, p));
 }
 
-__global__ void k_transpose_ks(const double* in, double* out, long long S, int K) {
+// out[b][c][r] = in[b][r][c]: layout conversions between the engine's buffers ([R][K][Q], [K][S]) and the reference's
+// ([R][Q][K], [S][K]) for the statistics API.
+__global__ void k_transpose_b(const double* in, double* out, long long B, long long rows, long long cols) {
   long long id = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (id >= S * K) return;
-  long long s = id / K;
-  int k = (int)(id % K);
-  out[id] = in[(long long)k * S + s];
+  if (id >= B * rows * cols) return;
+  const long long r = id % rows, bc = id / rows, c = bc % cols, b = bc / cols;
+  out[id] = in[(b * rows + r) * cols + c];
 }
 
-__global__ void k_transpose_rkq(const double* in, double* out, int R, int K, int Q) {
-  long long id = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (id >= (long long)R * K * Q) return;
-  const int k = (int)(id % K);
-  const long long rq = id / K;
-  const int q = (int)(rq % Q);
-  const long long r = rq / Q;
-  out[id] = in[(r * K + k) * Q + q];
+// KL = sum of the per-item terms k_prep left in klpart (statistics API; fixed order)
+__global__ __launch_bounds__(256) void k_sum_kl(EngineView ev, double* out) {
+  __shared__ double red[4];
+  double s = 0.0;
+  for (int i = threadIdx.x; i < ev.R * ev.K; i += 256) s += ev.klpart[i];
+  s = block_sum(s, red);
+  if (threadIdx.x == 0) out[0] = s;
 }

@@ -20,6 +20,7 @@
 #ifndef SV_BWD_STOP
 #define SV_BWD_STOP 0   // diagnosis builds only (tests/tools/phase_times.sh): 1 stop after phase 1, 2 after the spike gather, 3 before phase 3
 #endif
+#define SV_MASK_STATS 16u   // internal mask bit: svgpfa_latent_stats_backward (adjoints at quadrature nodes AND spikes given)
 #define SV_FIN_OUT 8   // outputs per reduction group of phase 3 (8 consecutive doubles = one 64-B segment per trial)
 
 // stride (doubles) of the per-wave transpose scratch of phase 1: rows are written with lane -> row (stride LDS2) and
@@ -99,7 +100,8 @@ __device__ __forceinline__ void fin_early_scalars(const EngineView& ev, const do
     kl += ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
   }
   for (int i = tid; i < ev.nell; i += NTH) e += ev.ellq[i];
-  for (int n = tid; n < ev.N; n += NTH) e += ev.spk_cnt[n] * d[n];
+  if (d)
+    for (int n = tid; n < ev.N; n += NTH) e += ev.spk_cnt[n] * d[n];
   e = block_sum(e, red);
   kl = block_sum(kl, red);
   if (tid == 0) {
@@ -252,26 +254,34 @@ __device__ void item_bwd_body(const EngineView& ev, const int r, const int k, co
     // points' (szl, czl) by angle addition (no per-pair sincos, no second exp).  Per-j constants are read
     // from LDS at their use sites (jo is an opaque 0: it keeps them out of long-lived registers).
     const double inv_s2 = 1.0 / p.s2;
-    const double* gmq = ev.gmuq + ((long long)r * K + k) * Q;     // [r][k][q]: this item's nodes are contiguous
-    const double* gvq = ev.gvarq + ((long long)r * K + k) * Q;
-    const double* tqr = ev.tq + (long long)r * Q;
+    // Node lists of the item.  Segment 0: the trial's Q quadrature nodes with the adjoints the ELL kernel left in
+    // [r][k][q] (contiguous for this item).  Segment 1 (statistics mode only, mask bit SV_MASK_STATS): the trial's spike
+    // times with caller-given adjoints of the posterior mean / variance at the spikes, [k][S] -- the general form of the
+    // spike term's backward, for likelihoods whose spike adjoint is not known a priori (svgpfa_latent_stats_backward).
+    const int nseg = (mask & SV_MASK_STATS) ? 2 : 1;
+    for (int seg = 0; seg < nseg; ++seg) {
+    const long long s0 = seg ? ev.spk_off[r] : 0;
+    const int Qs = seg ? (int)(ev.spk_off[r + 1] - s0) : Q;
+    const double* gmq = seg ? ev.gmuspk + (long long)k * ev.S + s0 : ev.gmuq + ((long long)r * K + k) * Q;
+    const double* gvq = seg ? ev.gvarspk + (long long)k * ev.S + s0 : ev.gvarq + ((long long)r * K + k) * Q;
+    const double* tqr = seg ? ev.spk_t + s0 : ev.tq + (long long)r * Q;
 
-    const int ntiles = (Q + 15) >> 4;
+    const int ntiles = (Qs + 15) >> 4;
     // inputs of the NEXT tile are fetched one iteration ahead (global latency hidden behind the MFMA chain)
     double tq_n = 0.0, gm_n = 0.0, gv_n = 0.0;
     if (wave < ntiles) {
       const int nn = 16 * wave + li;
-      tq_n = tqr[(nn < Q) ? nn : 0];
-      gm_n = (nn < Q) ? gmq[nn] : 0.0;
-      gv_n = (nn < Q) ? gvq[nn] : 0.0;
+      tq_n = tqr[(nn < Qs) ? nn : 0];
+      gm_n = (nn < Qs) ? gmq[nn] : 0.0;
+      gv_n = (nn < Qs) ? gvq[nn] : 0.0;
     }
     for (int tile = wave; tile < ntiles; tile += NWB) {
       const double tq = tq_n, gm = gm_n, gvv = gv_n;
       if (tile + NWB < ntiles) {
         const int nn = 16 * (tile + NWB) + li;
-        tq_n = tqr[(nn < Q) ? nn : 0];
-        gm_n = (nn < Q) ? gmq[nn] : 0.0;
-        gv_n = (nn < Q) ? gvq[nn] : 0.0;
+        tq_n = tqr[(nn < Qs) ? nn : 0];
+        gm_n = (nn < Qs) ? gmq[nn] : 0.0;
+        gv_n = (nn < Qs) ? gvq[nn] : 0.0;
       }
       double stq = 0.0, ctq = 0.0;
       if (KT == SV_PERIODIC) sv_sincos_quarter(tq * p.q4, stq, ctq);
@@ -360,6 +370,7 @@ __device__ void item_bwd_body(const EngineView& ev, const int r, const int k, co
       }
       lds_wave_fence();
     }
+    }   // node segments
 
     // ---- reductions: over the 16 time lanes, then over the wavefronts (fixed order)
 #pragma unroll
@@ -451,7 +462,8 @@ __device__ void item_bwd_body(const EngineView& ev, const int r, const int k, co
     gt[tid] = 0.0;
   }
   __syncthreads();
-  const int c0 = ev.chunk_first[r], c1 = ev.chunk_first[r + 1];
+  // statistics mode: the spike term arrived through the segment-1 adjoints, there are no a-priori spike sums to gather
+  const int c0 = ev.chunk_first[r], c1 = (mask & SV_MASK_STATS) ? c0 : ev.chunk_first[r + 1];
   if (tid < M) {
     double p0 = 0.0;
     for (int ch = c0; ch < c1; ch += 4) {          // 4 chunks per step: independent loads in flight, fixed order

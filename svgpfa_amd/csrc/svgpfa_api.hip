@@ -629,17 +629,71 @@ int svgpfa_latent_stats(svgpfa_engine* e, const double* const* mean, const doubl
   {   // the engine keeps [r][k][q]; the caller gets the reference's [r][q][k]
     const long long rqk = (long long)v.R * v.Q * v.K;
     const unsigned g = (unsigned)((rqk + 255) / 256);
-    if (mu_quad) hipLaunchKernelGGL(k_transpose_rkq, dim3(g), dim3(256), 0, e->stream, v.muq, mu_quad, v.R, v.K, v.Q);
-    if (var_quad) hipLaunchKernelGGL(k_transpose_rkq, dim3(g), dim3(256), 0, e->stream, v.varq, var_quad, v.R, v.K, v.Q);
+    if (mu_quad) hipLaunchKernelGGL(k_transpose_b, dim3(g), dim3(256), 0, e->stream, v.muq, mu_quad, (long long)v.R, (long long)v.K, (long long)v.Q);
+    if (var_quad) hipLaunchKernelGGL(k_transpose_b, dim3(g), dim3(256), 0, e->stream, v.varq, var_quad, (long long)v.R, (long long)v.K, (long long)v.Q);
   }
   long long tot = (long long)v.S * v.K;
-  if (tot > 0) {
+  if (tot > 0) {   // [K][S] -> [S][K]
     unsigned g = (unsigned)((tot + 255) / 256);
-    if (mu_spk) hipLaunchKernelGGL(k_transpose_ks, dim3(g), dim3(256), 0, e->stream, v.muspk, mu_spk, (long long)v.S, v.K);
-    if (var_spk) hipLaunchKernelGGL(k_transpose_ks, dim3(g), dim3(256), 0, e->stream, v.varspk, var_spk, (long long)v.S, v.K);
+    if (mu_spk) hipLaunchKernelGGL(k_transpose_b, dim3(g), dim3(256), 0, e->stream, v.muspk, mu_spk, 1LL, (long long)v.K, (long long)v.S);
+    if (var_spk) hipLaunchKernelGGL(k_transpose_b, dim3(g), dim3(256), 0, e->stream, v.varspk, var_spk, 1LL, (long long)v.K, (long long)v.S);
   }
   HIPCHK(e, hipGetLastError());
   e->have_stats = true;
+  return SVGPFA_OK;
+}
+
+int svgpfa_kl(svgpfa_engine* e, double* out) {
+  if (!e || !out) return SVGPFA_ERR_INVALID;
+  HIPCHK(e, hipSetDevice(e->device));
+  if (!e->have_kernels) FAIL(e, SVGPFA_ERR_STATE, "svgpfa_build_kernels has not been called");
+  hipLaunchKernelGGL(k_sum_kl, dim3(1), dim3(256), 0, e->stream, e->v, out);
+  HIPCHK(e, hipGetLastError());
+  return SVGPFA_OK;
+}
+
+int svgpfa_latent_stats_backward(svgpfa_engine* e, const double* const* mean, const double* const* cholvec,
+                                 const double* g_mu_quad, const double* g_var_quad, const double* g_mu_spk,
+                                 const double* g_var_spk, unsigned mask, double* shared, double* const* g_mean,
+                                 double* const* g_cholvec, double* const* g_Z) {
+  if (!e || !g_mu_quad || !g_var_quad || !shared) return SVGPFA_ERR_INVALID;
+  HIPCHK(e, hipSetDevice(e->device));
+  int rc;
+  if ((rc = check_ready(e))) return rc;
+  EngineView& v = e->v;
+  if (v.S > 0 && (!g_mu_spk || !g_var_spk)) FAIL(e, SVGPFA_ERR_INVALID, "spike adjoints missing");
+  mask &= (1u | 4u | 8u);
+  PtrTable pt;
+  if ((rc = fill_ptrs(e, pt, mean, cholvec, g_mean, g_cholvec, g_Z, mask))) return rc;
+  if (!v.gmuspk) {   // first use: [K][S] adjoint buffers
+    DALLOC(e, v.gmuspk, (size_t)v.K * std::max(v.S, 1));
+    DALLOC(e, v.gvarspk, (size_t)v.K * std::max(v.S, 1));
+  }
+  launch_prep(e, pt);
+  {   // the caller's adjoints in the reference's layouts -> the engine's ([R][Q][K] -> [R][K][Q], [S][K] -> [K][S])
+    const long long rqk = (long long)v.R * v.Q * v.K, sk = (long long)v.S * v.K;
+    const unsigned g = (unsigned)((rqk + 255) / 256);
+    hipLaunchKernelGGL(k_transpose_b, dim3(g), dim3(256), 0, e->stream, g_mu_quad, v.gmuq, (long long)v.R, (long long)v.Q, (long long)v.K);
+    hipLaunchKernelGGL(k_transpose_b, dim3(g), dim3(256), 0, e->stream, g_var_quad, v.gvarq, (long long)v.R, (long long)v.Q, (long long)v.K);
+    if (sk > 0) {
+      const unsigned gs = (unsigned)((sk + 255) / 256);
+      hipLaunchKernelGGL(k_transpose_b, dim3(gs), dim3(256), 0, e->stream, g_mu_spk, v.gmuspk, 1LL, (long long)v.S, (long long)v.K);
+      hipLaunchKernelGGL(k_transpose_b, dim3(gs), dim3(256), 0, e->stream, g_var_spk, v.gvarspk, 1LL, (long long)v.S, (long long)v.K);
+    }
+  }
+  const unsigned m2 = mask | SV_MASK_STATS;
+  if (mask & (4u | 8u)) {
+    DISPATCH_NT(e->NT, hipLaunchKernelGGL((k_item_bwd<NT_, true>), dim3(v.R * v.K), dim3(64 * e->tile_nw),
+                                          lds_item_bwd(NT_, e->tile_nw), e->stream, v, pt, m2, (const double*)nullptr,
+                                          (const double*)nullptr, shared));
+  } else {
+    DISPATCH_NT(e->NT, hipLaunchKernelGGL((k_item_bwd<NT_, false>), dim3(v.R * v.K), dim3(64 * e->tile_nw),
+                                          lds_item_bwd(NT_, e->tile_nw), e->stream, v, pt, m2, (const double*)nullptr,
+                                          (const double*)nullptr, shared));
+  }
+  hipLaunchKernelGGL(k_fin_items, dim3(v.nth_total + SV_FIN_NS), dim3(256), 0, e->stream, v, m2, shared);
+  HIPCHK(e, hipGetLastError());
+  e->p0_token = 0;
   return SVGPFA_OK;
 }
 

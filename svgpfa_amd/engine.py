@@ -184,6 +184,35 @@ class Engine:
         self._check(self.lib.svgpfa_latent_stats(self._h, mt, ct, *[_ptr(o) for o in outs]))
         return outs
 
+    def kl(self):
+        """KL term of the parameters of the latest elbo / latent_stats / predict call (0-dim tensor)."""
+        self._use_current_stream()
+        out = torch.empty(1, dtype=torch.float64, device=self.device)
+        self._check(self.lib.svgpfa_kl(self._h, _ptr(out)))
+        return out[0]
+
+    def latent_stats_backward(self, mean, cholvec, g_mu_quad, g_var_quad, g_mu_spk, g_var_spk, grad_mask):
+        """Gradients of (caller's ELL) - KL given d ELL / d statistics (include/svgpfa.h).  Returns
+        (shared, g_mean, g_cholvec, g_Z): shared[2] = KL, shared's trailing entries = dtheta."""
+        self._use_current_stream()
+        mt = self._table(mean, [self.R * m for m in self.Ms])
+        ct = self._table(cholvec, [self.R * p for p in self.Ps])
+        for t, n in ((g_mu_quad, self.R * self.Q * self.K), (g_var_quad, self.R * self.Q * self.K),
+                     (g_mu_spk, self.S * self.K), (g_var_spk, self.S * self.K)):
+            if n:
+                self._dev(t)
+                if t.numel() != n:
+                    raise ValueError("adjoint tensor of the wrong size")
+        grad_mask = int(grad_mask) & (_lib.GRAD_VARIATIONAL | _lib.GRAD_KERNELS | _lib.GRAD_INDPOINTS)
+        shared = torch.zeros(self.shared_len, dtype=torch.float64, device=self.device)
+        g_mean, g_chol, g_Z = self.alloc_grads(grad_mask)
+        self._check(self.lib.svgpfa_latent_stats_backward(
+            self._h, mt, ct, _ptr(g_mu_quad), _ptr(g_var_quad), _ptr(g_mu_spk if self.S else None),
+            _ptr(g_var_spk if self.S else None), grad_mask, _ptr(shared),
+            self._table(g_mean, [self.R * m for m in self.Ms]), self._table(g_chol, [self.R * p for p in self.Ps]),
+            self._table(g_Z, [self.R * m for m in self.Ms])))
+        return shared, g_mean, g_chol, g_Z
+
     def ell_given_stats(self, C, d, want_grad=True):
         self._use_current_stream()
         self._dev(C), self._dev(d)

@@ -106,6 +106,44 @@ class IndPointsLocsKMS_Chol(KernelsMatricesStore):
         return torch.cholesky_solve(input, self._Kzz_inv[latentIndex][trialIndex, :, :])
 
 
+class IndPointsLocsKMS_PInv(KernelsMatricesStore):
+    """kernelsMatricesStore.py:146-165: Kzz + eps I and its Moore-Penrose pseudo-inverse (utils/miscUtils.py:218-223,
+    rcond = 1e-15), solves by multiplication.  Stand-alone store for tests / plots: Kzz comes from the kernel objects'
+    own buildKernelMatrix on the GPU and the pseudo-inverse from torch.linalg.pinv (batched over trials) -- no Cholesky
+    factor is involved, so a singular Kzz is handled as in the reference.  (Inside a model, kernelMatrixInvPInv runs the
+    engine's Cholesky-based whitened algebra: for a positive definite Kzz the pseudo-inverse IS the inverse, see
+    SVGPFAModelFactory.)"""
+
+    def setRegParam(self, reg_param):
+        self._reg_param = reg_param
+
+    def getRegParam(self):
+        return self._reg_param
+
+    def buildKernelsMatrices(self):
+        self._Kzz, self._Kzz_inv = [], []
+        for k, kern in enumerate(self._kernels):
+            Z = self._dev(self._ind_points_locs[k])
+            saved = kern.getParams()
+            kern.setParams(self._dev(saved))
+            try:
+                Kzz = kern.buildKernelMatrix(X1=Z) + float(self._reg_param) * torch.eye(
+                    Z.shape[1], dtype=Z.dtype, device=Z.device)
+            finally:
+                kern.setParams(saved)
+            self._Kzz.append(Kzz)
+            self._Kzz_inv.append(torch.linalg.pinv(Kzz, rcond=1e-15))
+
+    def getKzz(self):
+        return self._Kzz
+
+    def solveForLatent(self, input, latentIndex):
+        return torch.matmul(self._Kzz_inv[latentIndex], input)
+
+    def solveForLatentAndTrial(self, input, latentIndex, trialIndex):
+        return torch.matmul(self._Kzz_inv[latentIndex][trialIndex, :, :], input)
+
+
 class IndPointsLocsAndTimesKMS(KernelsMatricesStore):
 
     def setTimes(self, times):

@@ -126,9 +126,57 @@ class _ELLGivenStatsFunction(torch.autograd.Function):
         return None, gC, gd
 
 
+class _LatentStatsFunction(torch.autograd.Function):
+    """Posterior mean / variance of every latent at the quadrature nodes and at the spikes, and the KL term, as ONE
+    autograd node whose forward (svgpfa_latent_stats) and backward (svgpfa_latent_stats_backward: whitened chain, Kzz
+    path, KL) run in the engine.  A likelihood that the engine does not fuse -- the Gauss-Hermite link -- is written on
+    top of it in torch; autograd supplies d ELL / d statistics and this node carries them to the parameters.
+    inputs: K means, K cholVecs, K kernel-param tensors, K inducing-point tensors.
+    outputs: mu_quad, var_quad (R x Q x K), mu_spk, var_spk (S x K), KL (0-dim)."""
+
+    @staticmethod
+    def forward(ctx, model, *params):
+        K, eng = model._K, model._engine
+        ctx.model, ctx.K = model, K
+        ctx.shapes = [p.shape for p in params]
+        ctx.mean_t = [p.detach() for p in params[0:K]]
+        ctx.chol_t = [p.detach().contiguous() for p in params[K:2 * K]]
+        muq, varq, mus, vars_ = eng.latent_stats(ctx.mean_t, ctx.chol_t)
+        return muq, varq, mus, vars_, eng.kl()
+
+    @staticmethod
+    def backward(ctx, g_muq, g_varq, g_mus, g_vars, g_kl):
+        K, eng = ctx.K, ctx.model._engine
+        need = ctx.needs_input_grad[1:]
+        mask = 0
+        if any(need[0:2 * K]):
+            mask |= _lib.GRAD_VARIATIONAL
+        if any(need[2 * K:3 * K]):
+            mask |= _lib.GRAD_KERNELS
+        if any(need[3 * K:4 * K]):
+            mask |= _lib.GRAD_INDPOINTS
+        # the engine returns J^T g_stats - dKL; the node needs J^T g_stats + g_kl dKL = s (J^T (g_stats / s) - dKL), s = -g_kl
+        s = -g_kl
+        z = lambda g, like: (torch.zeros_like(like) if g is None else g) / s
+        muq, varq, mus, vars_ = (torch.empty(eng.R, eng.Q, K, dtype=torch.float64, device=eng.device),) * 2 + \
+                                (torch.empty(eng.S, K, dtype=torch.float64, device=eng.device),) * 2
+        shared, gm, gc, gz = eng.latent_stats_backward(
+            ctx.mean_t, ctx.chol_t, z(g_muq, muq).contiguous(), z(g_varq, varq).contiguous(),
+            z(g_mus, mus).contiguous(), z(g_vars, vars_).contiguous(), mask)
+        gth = eng.split_shared(shared)[5]
+        out = [None]
+        for i in range(4 * K):
+            g = None
+            if need[i]:
+                g = (gm[i] if i < K else gc[i - K] if i < 2 * K else gth[i - 2 * K] if i < 3 * K else gz[i - 3 * K])
+                g = (s * g).reshape(ctx.shapes[i])
+            out.append(g)
+        return tuple(out)
+
+
 class SVLowerBound:
 
-    def __init__(self, device=None, rank1_plus_diag=False, precision="fp64"):
+    def __init__(self, device=None, rank1_plus_diag=False, precision="fp64", link=None):
         if not torch.cuda.is_available():
             raise RuntimeError("svgpfa_amd.stats.SVLowerBound needs a ROCm GPU; there is no CPU fallback")
         self._device = torch.device("cuda", torch.cuda.current_device() if device is None else device)
@@ -142,6 +190,11 @@ class SVLowerBound:
         if precision not in ("fp64", "mixed"):
             raise ValueError("precision must be 'fp64' or 'mixed'")
         self._precision = precision
+        # link = None: exponential link, everything fused in the engine.  A callable: the point-process ELL with
+        # Gauss-Hermite quadrature over the embedding's posterior (reference expectedLogLikelihood.py:215-255,
+        # PointProcessELLQuad), written in torch on top of the engine's latent statistics (_LatentStatsFunction)
+        self._link = link
+        self._herm = None
         self._qSVec = self._qSDiag = None
         self._kernels = None
         self._reg = None
@@ -215,6 +268,9 @@ class SVLowerBound:
     def setELLCalculationParams(self, eLLCalculationParams):
         self._quad = (_to_dev(eLLCalculationParams["leg_quad_points"], self._device),
                       _to_dev(eLLCalculationParams["leg_quad_weights"], self._device))
+        if "hermQuadPoints" in eLLCalculationParams:        # expectedLogLikelihood.py:224-225
+            self._herm = (_to_dev(eLLCalculationParams["hermQuadPoints"], self._device).reshape(-1),
+                          _to_dev(eLLCalculationParams["hermQuadWeights"], self._device).reshape(-1))
         self._data_version += 1
 
     def setPriorCovRegParam(self, priorCovRegParam):
@@ -341,11 +397,48 @@ class SVLowerBound:
             self.buildKernelsMatrices()
         chol = self._chol_vecs()
         self._check_live(self._mean + [c.detach() for c in chol] + [self._C, self._d], "variational / embedding")
+        if getattr(self, "_link", None) is not None:
+            return self._eval_gauss_hermite(chol)
         theEval = _ELBOFunction.apply(self, *self._mean, *chol, self._C, self._d,
                                       *self._theta(), *self._Z)
         # the reference warns here when the bound is infinite (svLowerBound.py:51-53); reading the value would stall the
         # host on every evaluation, so the check is made where the value reaches the host anyway (svEM's histories)
         return theEval
+
+    def _eval_gauss_hermite(self, chol):
+        """ELBO with a caller-supplied link function g and Gauss-Hermite quadrature over the Gaussian posterior of the
+        embedding h ~ N(m, v) (reference PointProcessELLQuad, expectedLogLikelihood.py:215-255):
+            E[g(h)]     at the quadrature nodes = sum_l w_l g(m + sqrt(2 v) x_l)                     (:229-239)
+            E[log g(h)] at the spikes           = sum_l w_l log g(m + (2 v) x_l)                     (:243-252)
+        The spike term scales the Hermite abscissae by 2 v where the node term (and the Gauss-Hermite rule) has
+        sqrt(2 v); that is what the reference computes and what its golden vector pins, so it is replicated here as is.
+        Latent statistics and their backward are the engine's; embedding and link are torch on the same GPU."""
+        if self._herm is None:
+            raise RuntimeError("eLLCalculationParams must hold hermQuadPoints / hermQuadWeights for a non-exponential link")
+        if self._reduce is not None:
+            raise NotImplementedError("the Gauss-Hermite link is not available with trials sharded over ranks")
+        muq, varq, mus, vars_, kl = _LatentStatsFunction.apply(self, *self._mean, *chol, *self._theta(), *self._Z)
+        self._stats_token = None
+        C, d = self._C, self._d.reshape(-1)
+        x, w = self._herm
+        link = self._link
+        eMean = torch.matmul(muq, C.T) + d                       # svEmbedding.py:80-84
+        eVar = torch.matmul(varq, C.T ** 2)
+        sd = torch.sqrt(2.0 * eVar)
+        eLink = torch.zeros_like(eMean)
+        for l in range(x.numel()):                               # one Hermite node at a time: R x Q x N temporaries only
+            eLink = eLink + w[l] * link(eMean + sd * x[l])
+        term1 = torch.sum(self._quad[1].reshape(eMean.shape[0], -1, 1) * eLink)
+        nid = torch.as_tensor(self._spikes[2], device=self._device).long()
+        Cn = C[nid]                                              # svEmbedding.py:137-144
+        mS = torch.sum(mus * Cn, dim=1) + d[nid]
+        vS = torch.sum(vars_ * Cn ** 2, dim=1)
+        eLog = torch.zeros_like(mS)
+        for l in range(x.numel()):
+            eLog = eLog + w[l] * torch.log(link(mS + 2.0 * vS * x[l]))
+        ell = -term1 + torch.sum(eLog)
+        self._last_terms = ((ell - kl).detach(), ell.detach(), kl.detach())
+        return ell - kl
 
     # ------------------------------------------------------------------------------ flat fast path (EM loop)
     GROUPS = ("var", "emb", "theta", "Z")
@@ -364,7 +457,7 @@ class SVLowerBound:
         parameters, "Z": inducing points), or None when the group is not laid out that way (rank-1 + diagonal q(u), or
         a caller has rebound one of the tensors, e.g. kernel.setParams(new_tensor))."""
         flat, tens = self._flat.get(group), self._group_tensors(group)
-        if flat is None or tens is None:
+        if flat is None or tens is None or getattr(self, "_link", None) is not None:
             return None
         o = flat.data_ptr()
         for t in tens:

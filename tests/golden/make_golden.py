@@ -28,6 +28,10 @@ What is written (all float64 numpy arrays, inputs AND reference outputs):
   rank1_small.npz   - the rank-1 + diagonal representation of the variational covariances
                       (indPointsCovRep = indPointsCovRank1PlusDiag, stats/svPosteriorOnIndPoints.py:86-119)
                       on the ragged case: ELBO / ELL / KL and gradients wrt mean, qSVec, qSDiag.
+  pinv_small.npz    - the pseudo-inverse Kzz model (kernelMatrixInvMethod = kernelMatrixInvPInv,
+                      stats/kernelsMatricesStore.py:146-165) on the ragged case: ELBO / ELL / KL and all gradients.
+  gh_small.npz      - the Gauss-Hermite (non-exponential link) point-process ELL of stats/expectedLogLikelihood.py:215-255
+                      with a softplus link on the ragged case: ELBO / ELL / KL and all gradients.
   cfg3_shape.npz    - the north-star geometry (BASELINE config 3: 200 neurons, 10 latents RBF + periodic, 32 inducing
                       points, Q = 200, ~4000 spikes per trial) on the first 6 trials of the SURVEY 8(d) inputs:
                       scalars + gradients of all four groups (inputs are regenerated from the seed in the tests).
@@ -380,6 +384,94 @@ def cfg3_shape():
                         spike_times_sum=prob["spike_times"].sum(), C_sum=prob["C"].sum(), **out)
 
 
+def pinv_small():
+    """Non-default Kzz inversion: kernelMatrixInvPInv (kernelsMatricesStore.py:146-165) on the ragged case."""
+    prob = ragged_problem()
+    F = svGPFA.stats.svGPFAModelFactory
+    model0, params = ref_model_from_problem(prob)
+    K, R, N = prob["K"], prob["R"], prob["N"]
+    model = F.SVGPFAModelFactory.buildModelPyTorch(kernels=model0.getKernels(),
+                                                   kernelMatrixInvMethod=F.kernelMatrixInvPInv)
+    t = lambda a: torch.from_numpy(np.array(a, dtype=np.float64, copy=True, order="C"))
+    off, times, neuron = prob["spike_offsets"], prob["spike_times"], prob["spike_neuron"]
+    measurements = []
+    for r in range(R):
+        tr_t, tr_n = times[off[r]:off[r + 1]], neuron[off[r]:off[r + 1]]
+        measurements.append([t(tr_t[tr_n == n]) for n in range(N)])
+    initial_params = {
+        "posterior_on_latents": {
+            "posterior_on_ind_points": {"mean": params["mean"], "cholVecs": params["cholVecs"]},
+            "kernels_matrices_store": {"kernels_params0": params["theta"], "inducing_points_locs0": params["Z"]}},
+        "embedding": {"C0": params["C"], "d0": params["d"]}}
+    ell_params = {"leg_quad_points": t(prob["quad_points"]).unsqueeze(-1),
+                  "leg_quad_weights": t(prob["quad_weights"]).unsqueeze(-1)}
+    model.setParamsAndData(measurements=measurements, initial_params=initial_params,
+                           eLLCalculationParams=ell_params, priorCovRegParam=prob["reg"])
+    out = ref_outputs(model, params, intermediates=False)
+    print("pinv: ref elbo %.10f ell %.10f kl %.10f" % (out["ref_elbo"], out["ref_ell"], out["ref_kl"]))
+    np.savez_compressed(os.path.join(HERE, "pinv_small.npz"), **problem_inputs(prob), **out)
+
+
+def _softplus(input=None, x=None):
+    """Link function for the Gauss-Hermite golden; the reference calls its link with `input=` at the quadrature nodes
+    (expectedLogLikelihood.py:235) and with `x=` at the spikes (:249)."""
+    return torch.nn.functional.softplus(input if input is not None else x)
+
+
+def gh_small():
+    """Non-exponential link with Gauss-Hermite quadrature (PointProcessELLQuad, expectedLogLikelihood.py:215-255).  The
+    reference's factory never builds this model (svGPFAModelFactory.py:96-98 raises), so the object graph is assembled by
+    hand, as the reference's own test does (stats/tests/test_expectedLogLikelihood.py:106-198), here with a softplus
+    link on the ragged case: ELBO / ELL / KL and autograd gradients of every group."""
+    import svGPFA.stats.expectedLogLikelihood
+    import svGPFA.stats.kernelsMatricesStore
+    import svGPFA.stats.klDivergence
+    import svGPFA.stats.svEmbedding
+    import svGPFA.stats.svLowerBound
+    import svGPFA.stats.svPosteriorOnIndPoints
+    import svGPFA.stats.svPosteriorOnLatents
+    prob = ragged_problem()
+    model0, params = ref_model_from_problem(prob)
+    K, R, N = prob["K"], prob["R"], prob["N"]
+    S = svGPFA.stats
+    qU = S.svPosteriorOnIndPoints.SVPosteriorOnIndPointsChol()
+    kmsZ = S.kernelsMatricesStore.IndPointsLocsKMS_Chol()
+    kmsAll = S.kernelsMatricesStore.IndPointsLocsAndAllTimesKMS()
+    kmsAssoc = S.kernelsMatricesStore.IndPointsLocsAndAssocTimesKMS()
+    qKAll = S.svPosteriorOnLatents.SVPosteriorOnLatentsAllTimes(
+        svPosteriorOnIndPoints=qU, indPointsLocsKMS=kmsZ, indPointsLocsAndTimesKMS=kmsAll)
+    qKAssoc = S.svPosteriorOnLatents.SVPosteriorOnLatentsAssocTimes(
+        svPosteriorOnIndPoints=qU, indPointsLocsKMS=kmsZ, indPointsLocsAndTimesKMS=kmsAssoc)
+    qHAll = S.svEmbedding.LinearSVEmbeddingAllTimes(svPosteriorOnLatents=qKAll)
+    qHAssoc = S.svEmbedding.LinearSVEmbeddingAssocTimes(svPosteriorOnLatents=qKAssoc)
+    eLL = S.expectedLogLikelihood.PointProcessELLQuad(svEmbeddingAllTimes=qHAll, svEmbeddingAssocTimes=qHAssoc,
+                                                      linkFunction=_softplus)
+    klDiv = S.klDivergence.KLDivergence(indPointsLocsKMS=kmsZ, svPosteriorOnIndPoints=qU)
+    model = S.svLowerBound.SVLowerBound(eLL=eLL, klDiv=klDiv)
+    model.setKernels(kernels=model0.getKernels())
+    t = lambda a: torch.from_numpy(np.array(a, dtype=np.float64, copy=True, order="C"))
+    off, times, neuron = prob["spike_offsets"], prob["spike_times"], prob["spike_neuron"]
+    measurements = []
+    for r in range(R):
+        tr_t, tr_n = times[off[r]:off[r + 1]], neuron[off[r]:off[r + 1]]
+        measurements.append([t(tr_t[tr_n == n]) for n in range(N)])
+    xh, wh = np.polynomial.hermite.hermgauss(20)
+    herm_x, herm_w = xh.reshape(-1, 1), (wh / np.sqrt(np.pi)).reshape(-1, 1)
+    initial_params = {
+        "posterior_on_latents": {
+            "posterior_on_ind_points": {"mean": params["mean"], "cholVecs": params["cholVecs"]},
+            "kernels_matrices_store": {"kernels_params0": params["theta"], "inducing_points_locs0": params["Z"]}},
+        "embedding": {"C0": params["C"], "d0": params["d"]}}
+    ell_params = {"leg_quad_points": t(prob["quad_points"]).unsqueeze(-1),
+                  "leg_quad_weights": t(prob["quad_weights"]).unsqueeze(-1),
+                  "hermQuadPoints": t(herm_x), "hermQuadWeights": t(herm_w)}
+    model.setParamsAndData(measurements=measurements, initial_params=initial_params,
+                           eLLCalculationParams=ell_params, priorCovRegParam=prob["reg"])
+    out = ref_outputs(model, params, intermediates=False)
+    print("gh: ref elbo %.10f ell %.10f kl %.10f" % (out["ref_elbo"], out["ref_ell"], out["ref_kl"]))
+    np.savez_compressed(os.path.join(HERE, "gh_small.npz"), **problem_inputs(prob), herm_x=herm_x, herm_w=herm_w, **out)
+
+
 def rank1_small():
     """Non-default q(u) covariance: S = q q^T + diag(d^2) (svPosteriorOnIndPoints.py:104-119)."""
     prob = ragged_problem()
@@ -438,6 +530,10 @@ def rank1_small():
 if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "rank1":
         rank1_small()
+    elif len(sys.argv) > 1 and sys.argv[1] == "gh":
+        gh_small()
+    elif len(sys.argv) > 1 and sys.argv[1] == "pinv":
+        pinv_small()
     elif len(sys.argv) > 1 and sys.argv[1] == "cfg3":
         cfg3_shape()
     elif len(sys.argv) > 1 and sys.argv[1] == "em":
@@ -449,3 +545,5 @@ if __name__ == "__main__":
         cfg1_bundled()
         rank1_small()
         cfg3_shape()
+        pinv_small()
+        gh_small()

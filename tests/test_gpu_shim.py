@@ -317,3 +317,110 @@ def test_kms_not_positive_definite_raises_linalgerror():
     kms.setRegParam(-0.5)
     with pytest.raises(torch.linalg.LinAlgError):
         kms.buildKernelsMatrices()
+
+
+def test_pinv_model_against_the_reference_pinv_model():
+    """kernelMatrixInvPInv (reference kernelsMatricesStore.py:146-165) through the factory: the engine's whitened
+    algebra against the reference's own pseudo-inverse model (tests/golden/pinv_small.npz), value and every gradient."""
+    from svgpfa_amd.stats import svGPFAModelFactory as F
+    prob, ref = load_golden("pinv_small")
+    model = _model(prob, kernelMatrixInvMethod=F.kernelMatrixInvPInv)
+    K = prob["K"]
+    groups = (model.getSVPosteriorOnIndPointsParams() + model.getSVEmbeddingParams() + model.getKernelsParams()
+              + model.getIndPointsLocs())
+    for t in groups:
+        t.requires_grad_(True)
+    model.buildKernelsMatrices()
+    val = model.eval()
+    val.backward()
+    assert abs(float(val) - float(ref["ref_elbo"])) <= 1e-9 * abs(float(ref["ref_elbo"]))
+    names = ([f"g_mean_{k}" for k in range(K)] + [f"g_cholVecs_{k}" for k in range(K)] + ["g_C", "g_d"]
+             + [f"g_theta_{k}" for k in range(K)] + [f"g_Z_{k}" for k in range(K)])
+    for t, nme in zip(groups, names):
+        assert rel_err(t.grad.cpu().numpy().reshape(ref[nme].shape), ref[nme]) < 1e-8, nme
+
+
+def test_pinv_kms_store():
+    """The stand-alone pseudo-inverse store: Kzz as the Cholesky store builds it, solves by multiplication, and a
+    singular Kzz (duplicated inducing point, no jitter) is handled instead of raising."""
+    from svgpfa_amd.stats import kernelsMatricesStore as kms_mod
+    prob, ref = load_golden("ragged_small")
+    Z = [torch.from_numpy(np.array(z)).unsqueeze(-1) for z in prob["Z"]]
+    kms = kms_mod.IndPointsLocsKMS_PInv()
+    kms.setKernels(_kernels(prob))
+    kms.setKernelsParams([torch.from_numpy(np.array(t)) for t in prob["theta"]])
+    kms.setIndPointsLocs(Z)
+    kms.setRegParam(prob["reg"])
+    kms.buildKernelsMatrices()
+    for k in range(prob["K"]):
+        Kzz = kms.getKzz()[k]
+        assert rel_err(Kzz.cpu().numpy(), ref[f"Kzz_{k}"]) < 1e-12
+        x = torch.randn(Kzz.shape[0], Kzz.shape[1], 2, dtype=torch.float64, device=Kzz.device)
+        assert torch.allclose(Kzz @ kms.solveForLatent(x, k), x, rtol=1e-7, atol=1e-8)
+    Z[0][1, 2, 0] = Z[0][1, 1, 0]
+    kms.setIndPointsLocs(Z)
+    kms.setRegParam(0.0)
+    kms.buildKernelsMatrices()                      # singular Kzz: the pseudo-inverse still exists
+    P = kms._Kzz_inv[0][1]
+    Kz = kms.getKzz()[0][1]
+    assert torch.allclose(Kz @ P @ Kz, Kz, rtol=1e-6, atol=1e-8)
+
+
+def _build_gh_model(prob, ref, link):
+    from svgpfa_amd.stats import svGPFAModelFactory as F
+    from svgpfa_amd.stats.svGPFAModelFactory import SVGPFAModelFactory
+    t = lambda a: torch.from_numpy(np.array(a, dtype=np.float64, copy=True, order="C"))
+    off, times, neuron = prob["spike_offsets"], prob["spike_times"], prob["spike_neuron"]
+    measurements = []
+    for r in range(prob["R"]):
+        tt, nn = times[off[r]:off[r + 1]], neuron[off[r]:off[r + 1]]
+        measurements.append([t(tt[nn == n]) for n in range(prob["N"])])
+    initial_params = {
+        "posterior_on_latents": {
+            "posterior_on_ind_points": {"mean": [t(a).unsqueeze(-1) for a in prob["mean"]],
+                                        "cholVecs": [t(a).unsqueeze(-1) for a in prob["cholVecs"]]},
+            "kernels_matrices_store": {"kernels_params0": [t(a) for a in prob["theta"]],
+                                       "inducing_points_locs0": [t(a).unsqueeze(-1) for a in prob["Z"]]}},
+        "embedding": {"C0": t(prob["C"]), "d0": t(prob["d"])}}
+    ell = {"leg_quad_points": t(prob["quad_points"]).unsqueeze(-1), "leg_quad_weights": t(prob["quad_weights"]).unsqueeze(-1),
+           "hermQuadPoints": t(ref["herm_x"]), "hermQuadWeights": t(ref["herm_w"])}
+    model = SVGPFAModelFactory.buildModelPyTorch(kernels=_kernels(prob), linkFunction=F.NonExponentialLink,
+                                                 linkFunctionCallable=link)
+    model.setParamsAndData(measurements=measurements, initial_params=initial_params, eLLCalculationParams=ell,
+                           priorCovRegParam=prob["reg"])
+    return model
+
+
+def test_gauss_hermite_link_against_the_reference():
+    """Non-exponential link (reference PointProcessELLQuad, expectedLogLikelihood.py:215-255) with a softplus link: value
+    and the gradients of all four groups against the reference's own outputs (tests/golden/gh_small.npz).  The latent
+    statistics, their backward (quadrature AND spike adjoints) and the KL term are the engine's."""
+    prob, ref = load_golden("gh_small")
+    model = _build_gh_model(prob, ref, torch.nn.functional.softplus)
+    K = prob["K"]
+    groups = (model.getSVPosteriorOnIndPointsParams() + model.getSVEmbeddingParams() + model.getKernelsParams()
+              + model.getIndPointsLocs())
+    for t in groups:
+        t.requires_grad_(True)
+    model.buildKernelsMatrices()
+    val = model.eval()
+    elbo, ell, kl = model.lastTerms()
+    assert abs(float(val) - float(ref["ref_elbo"])) <= 1e-9 * abs(float(ref["ref_elbo"]))
+    assert abs(float(ell) - float(ref["ref_ell"])) <= 1e-9 * abs(float(ref["ref_ell"]))
+    assert abs(float(kl) - float(ref["ref_kl"])) <= 1e-9 * abs(float(ref["ref_kl"]))
+    (-val).backward()                       # the EM loop minimises the negative bound: exercises the scaling path
+    names = ([f"g_mean_{k}" for k in range(K)] + [f"g_cholVecs_{k}" for k in range(K)] + ["g_C", "g_d"]
+             + [f"g_theta_{k}" for k in range(K)] + [f"g_Z_{k}" for k in range(K)])
+    for t, nme in zip(groups, names):
+        assert rel_err(-t.grad.cpu().numpy().reshape(ref[nme].shape), ref[nme]) < 1e-8, (nme, rel_err(-t.grad.cpu().numpy().reshape(ref[nme].shape), ref[nme]))
+
+
+def test_gauss_hermite_with_exp_link_equals_the_fused_model():
+    """With g = exp the Gauss-Hermite ELL equals the closed form the engine fuses (the reference's own check,
+    stats/tests/test_expectedLogLikelihood.py:106-198): 20 Hermite nodes reproduce E[exp(h)] to quadrature accuracy, and
+    the (2 v) scaling of the spike term cancels for log(exp(.))."""
+    prob, ref = load_golden("gh_small")
+    gh = _build_gh_model(prob, ref, torch.exp)
+    fused = _model(prob)
+    a, b = float(gh.eval()), float(fused.eval())
+    assert abs(a - b) <= 1e-6 * abs(b), (a, b)
