@@ -27,6 +27,8 @@ class Engine:
     def __init__(self, n_trials, n_neurons, n_quad, n_ind, kernel_types, scales=None,
                  lengthscale_scales=None, period_scales=None, device=None, precision="fp64"):
         self._h = None
+        self._tables = {}
+        self._stream = None
         self.lib = _lib.load()
         if not torch.cuda.is_available():
             raise RuntimeError("svgpfa_amd needs a ROCm GPU (MI355X); no CPU fallback exists")
@@ -37,6 +39,8 @@ class Engine:
         self.Ps = [m * (m + 1) // 2 for m in self.Ms]
         self.ktypes = [int(t) for t in kernel_types]
         self.nth = [1 if t == _lib.KERNEL_RBF else 2 for t in self.ktypes]
+        self._szM = [self.R * m for m in self.Ms]
+        self._szP = [self.R * p for p in self.Ps]
         arr_i = lambda xs: (ctypes.c_int32 * K)(*[int(x) for x in xs])
         arr_d = lambda xs: (ctypes.c_double * K)(*[float(x) for x in xs]) if xs is not None else None
         self._keep = (arr_i(self.Ms), arr_i(self.ktypes), arr_d(scales), arr_d(lengthscale_scales),
@@ -63,7 +67,9 @@ class Engine:
 
     def _use_current_stream(self):
         s = torch.cuda.current_stream(self.device).cuda_stream
-        self._check(self.lib.svgpfa_set_stream(self._h, ctypes.c_void_p(s)))
+        if s != self._stream:
+            self._check(self.lib.svgpfa_set_stream(self._h, ctypes.c_void_p(s)))
+            self._stream = s
 
     def _dev(self, t, dtype=torch.float64):
         if not (isinstance(t, torch.Tensor) and t.is_cuda and t.dtype == dtype and t.is_contiguous()
@@ -72,16 +78,27 @@ class Engine:
                              f"{type(t).__name__} {getattr(t, 'dtype', None)} {getattr(t, 'device', None)}")
         return t
 
-    def _table(self, tensors, sizes=None):
+    def _table(self, tensors, sizes=None, slot=None):
+        """Host array of K device pointers.  `slot` names the argument: the array built for the same tensors (same
+        addresses) on the previous call is reused without re-validating them -- an EM closure passes the same parameter
+        tensors thousands of times, and on small problems the marshalling was longer than the kernels."""
         if tensors is None:
             return None
         if len(tensors) != self.K:
             raise ValueError("expected one tensor per latent")
+        ptrs = tuple(t.data_ptr() for t in tensors)
+        if slot is not None:
+            hit = self._tables.get(slot)
+            if hit is not None and hit[0] == ptrs:
+                return hit[1]
         for k, t in enumerate(tensors):
             self._dev(t)
             if sizes is not None and t.numel() != sizes[k]:
                 raise ValueError(f"latent {k}: expected {sizes[k]} elements, got {t.numel()}")
-        return (ctypes.c_void_p * self.K)(*[t.data_ptr() for t in tensors])
+        arr = (ctypes.c_void_p * self.K)(*ptrs)
+        if slot is not None:
+            self._tables[slot] = (ptrs, arr)
+        return arr
 
     def close(self):
         if self._h:
@@ -126,8 +143,8 @@ class Engine:
     # ------------------------------------------------------------------- compute
     def build_kernels(self, Z, theta):
         self._use_current_stream()
-        zt = self._table(Z, [self.R * m for m in self.Ms])
-        tt = self._table(theta, self.nth)
+        zt = self._table(Z, self._szM, "Z")
+        tt = self._table(theta, self.nth, "theta")
         self._check(self.lib.svgpfa_build_kernels(self._h, zt, tt))
 
     def alloc_grads(self, grad_mask):
@@ -145,17 +162,20 @@ class Engine:
         """Enqueue one ELBO(+grad) evaluation.  Returns (shared, g_mean, g_cholvec, g_Z); the
         lists are None for groups not in grad_mask.  Call sync() before trusting the numbers."""
         self._use_current_stream()
-        mt = self._table(mean, [self.R * m for m in self.Ms])
-        ct = self._table(cholvec, [self.R * p for p in self.Ps])
-        self._dev(C), self._dev(d)
-        if C.numel() != self.N * self.K or d.numel() != self.N:
-            raise ValueError("C must be N x K and d must have N entries")
+        mt = self._table(mean, self._szM, "mean")
+        ct = self._table(cholvec, self._szP, "chol")
+        cd = (C.data_ptr(), d.data_ptr())
+        if self._tables.get("Cd") != cd:
+            self._dev(C), self._dev(d)
+            if C.numel() != self.N * self.K or d.numel() != self.N:
+                raise ValueError("C must be N x K and d must have N entries")
+            self._tables["Cd"] = cd
         shared = out if out is not None else torch.empty(self.shared_len, dtype=torch.float64, device=self.device)
         g_mean, g_chol, g_Z = grads if grads is not None else self.alloc_grads(grad_mask)
-        self._check(self.lib.svgpfa_elbo(self._h, mt, ct, _ptr(C), _ptr(d), int(grad_mask), _ptr(shared),
-                                         self._table(g_mean, [self.R * m for m in self.Ms]),
-                                         self._table(g_chol, [self.R * p for p in self.Ps]),
-                                         self._table(g_Z, [self.R * m for m in self.Ms])))
+        self._check(self.lib.svgpfa_elbo(self._h, mt, ct, cd[0], cd[1], int(grad_mask), _ptr(shared),
+                                         self._table(g_mean, self._szM, "g_mean"),
+                                         self._table(g_chol, self._szP, "g_chol"),
+                                         self._table(g_Z, self._szM, "g_Z")))
         return shared, g_mean, g_chol, g_Z
 
     def set_embedding_token(self, token):
