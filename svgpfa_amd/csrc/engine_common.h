@@ -43,10 +43,12 @@ struct LatentPtrs {
   double* g_Z;
 };
 
-// A chunk holds <= SV_SPIKE_CHUNK consecutive spikes of one trial.  Normal chunks contain WHOLE
-// (trial, neuron) segments, so the wavefront that owns the chunk is the only writer of those
-// neurons' spike sums.  A neuron with more than SV_SPIKE_CHUNK spikes in a trial gets dedicated
-// chunks (split = 1, all spikes of that one neuron); their sums are added in chunk order later.
+// A chunk holds <= 64 * spl consecutive spikes of one trial; chunks are packed densely (every chunk of a trial but the
+// last is full), so a (trial, neuron) segment may be cut by a chunk boundary -- at most once.  The chunk that holds the
+// segment's start writes its partial sum to gCspk, the chunk that holds the continuation (split bit 1: "head
+// continuation") writes its first per-neuron sum to gCspkB: every dC partial keeps exactly one writer and the two
+// halves are added in the fixed-order reduction.  A neuron with more spikes in a trial than a chunk holds gets dedicated
+// chunks (split bit 0, all spikes of that one neuron); their sums are added in chunk order later.
 struct LatentPtrTable {
   LatentPtrs p[SV_MAX_K];
 };
@@ -55,7 +57,7 @@ struct SpikeChunk {
   int trial;
   int count;
   long long start;  // global spike index of the first spike of the chunk
-  int split;        // 1: piece of an oversize (trial, neuron) segment
+  int split;        // bit 0: piece of an oversize (trial, neuron) segment; bit 1: the first segment continues the previous chunk's last
   int neuron;       // that neuron (split chunks only)
 };
 
@@ -85,7 +87,8 @@ struct EngineView {
   double* a; double* ut; double* Vt; double* klpart;   // klpart [R*K]
   double* muq; double* varq; double* gmuq; double* gvarq;
   double* P0; double* P1; double* Tpart;           // spike partials
-  double* gCspk;                                   // [R][N][K] spike part of dC per trial (whole segments)
+  double* gCspk;                                   // [R][N][K] spike part of dC per trial (segment, or its first part)
+  double* gCspkB;                                  // [R][N][K] second part of segments cut by a chunk boundary (else 0)
   double* splitPart;                               // [nchunks][K] spike part of dC of split chunks
   double* muspk;                                   // [K][S] (stats API only)
   double* varspk;                                  // [K][S] (stats API only)

@@ -53,7 +53,7 @@ __device__ __forceinline__ void fin_cd_group(const EngineView& ev, const double*
       if (mask & 2u) {
         const int n = id / K, k = id % K;
         const double cnk = C[id];
-        for (int r = pg; r < R; r += NG) s += ev.gCspk[(long long)r * NK + id];
+        for (int r = pg; r < R; r += NG) s += ev.gCspk[(long long)r * NK + id] + ev.gCspkB[(long long)r * NK + id];
         for (int b = pg; b < ev.ncd; b += NG) {      // dC = -(E^T mu + C . E^T var)
           const long long o2 = ((long long)b * N + n) * 2 * K + k;
           s -= ev.gCpart[o2] + cnk * ev.gCpart[o2 + K];

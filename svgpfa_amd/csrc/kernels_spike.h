@@ -24,8 +24,10 @@
 // ids, non-decreasing over the chunk, < 0 = padding at the end): a serial segmented sum inside the lane, ONE wave scan
 // over the lanes' tail partials (sorted keys: the lanes before l whose tail key equals l's head key are exactly those
 // that continue its head segment), then every segment end stores its total -- each neuron has exactly one writer.
+// out2 != nullptr: the chunk's FIRST segment continues a segment of the previous chunk; its sum goes to out2.
 template <int SPL>
-__device__ __forceinline__ void seg_emit_lane(const int (&key)[SPL], const double (&v)[SPL], double* out, int K, int lane) {
+__device__ __forceinline__ void seg_emit_lane(const int (&key)[SPL], const double (&v)[SPL], double* out, double* out2,
+                                              int K, int lane) {
   double run[SPL];
   run[0] = v[0];
 #pragma unroll
@@ -42,10 +44,12 @@ __device__ __forceinline__ void seg_emit_lane(const int (&key)[SPL], const doubl
   const int kprev = __shfl_up(kt, 1, 64);
   const double carry = (lane > 0 && kprev == key[0]) ? tprev : 0.0;
   const int knext = __shfl_down(key[0], 1, 64);
+  const int kfirst = out2 ? __shfl(key[0], 0, 64) : -2;
 #pragma unroll
   for (int i = 0; i < SPL; ++i) {
     const int kn = (i + 1 < SPL) ? key[i + 1] : ((lane < 63) ? knext : -1);
-    if (key[i] >= 0 && key[i] != kn) out[(long long)key[i] * K] = run[i] + ((key[i] == key[0]) ? carry : 0.0);
+    if (key[i] >= 0 && key[i] != kn)
+      ((key[i] == kfirst) ? out2 : out)[(long long)key[i] * K] = run[i] + ((key[i] == key[0]) ? carry : 0.0);
   }
 }
 
@@ -191,17 +195,17 @@ __device__ void spike_body_periodic_full(const EngineView& ev, const double* __r
   double mud[SPL];
 #pragma unroll
   for (int i = 0; i < SPL; ++i) mud[i] = (double)mu[i];
-  if (c.split) {
+  if (c.split & 1) {
     double tot = 0.0;
 #pragma unroll
     for (int i = 0; i < SPL; ++i) tot += (nid[i] >= 0) ? mud[i] : 0.0;
     tot = wave_sum(tot);
     if (lane == 0) ev.splitPart[(long long)ch * K + k] = p.s2 * tot;
   } else {
-    double* out = ev.gCspk + (long long)r * ev.N * K + k;
+    const long long ob = (long long)r * ev.N * K + k;
 #pragma unroll
     for (int i = 0; i < SPL; ++i) mud[i] *= p.s2;
-    seg_emit_lane<SPL>(nid, mud, out, K, lane);
+    seg_emit_lane<SPL>(nid, mud, ev.gCspk + ob, (c.split & 2) ? ev.gCspkB + ob : nullptr, K, lane);
   }
 }
 
@@ -358,17 +362,17 @@ __device__ void spike_body(const EngineView& ev, const double* __restrict__ C, i
     double mud[SPL];
 #pragma unroll
     for (int i = 0; i < SPL; ++i) mud[i] = (double)mu[i];
-    if (c.split) {
+    if (c.split & 1) {
       double tot = 0.0;
 #pragma unroll
       for (int i = 0; i < SPL; ++i) tot += (nid[i] >= 0) ? mud[i] : 0.0;
       tot = wave_sum(tot);
       if (lane == 0) ev.splitPart[(long long)ch * K + k] = p.s2 * tot;
     } else {
-      double* out = ev.gCspk + (long long)r * ev.N * K + k;
+      const long long ob = (long long)r * ev.N * K + k;
 #pragma unroll
       for (int i = 0; i < SPL; ++i) mud[i] *= p.s2;
-      seg_emit_lane<SPL>(nid, mud, out, K, lane);
+      seg_emit_lane<SPL>(nid, mud, ev.gCspk + ob, (c.split & 2) ? ev.gCspkB + ob : nullptr, K, lane);
     }
   }
 }

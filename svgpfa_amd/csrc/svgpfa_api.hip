@@ -352,6 +352,7 @@ int svgpfa_set_spikes(svgpfa_engine* e, const int64_t* off, const double* times,
     auto flush = [&]() {
       if (cur.count > 0) chunks.push_back(cur);
       cur.count = 0;
+      cur.split = 0;
     };
     for (int n = 0; n < v.N; ++n) {
       seg[(size_t)r * v.N + n] = i;
@@ -368,9 +369,19 @@ int svgpfa_set_spikes(svgpfa_engine* e, const int64_t* off, const double* times,
         }
         cur.start = i;
       } else {
-        if (cur.count + len > CHUNK) flush();
+        // dense packing: chunks are filled to CHUNK spikes; a segment that does not fit is CUT -- its tail opens the next
+        // chunk, marked as a head continuation (bit 1 of `split`): that chunk's first per-neuron sum goes to gCspkB, so
+        // every dC partial still has exactly one writer.  A segment of <= CHUNK spikes is cut at most once.
         if (cur.count == 0) cur.start = b;
-        cur.count += (int)len;
+        const long long room = CHUNK - cur.count;
+        if (len <= room) {
+          cur.count += (int)len;
+          if (cur.count == CHUNK) flush();
+        } else {
+          cur.count += (int)room;
+          flush();
+          cur = SpikeChunk{r, (int)(len - room), b + room, 2, -1};
+        }
       }
     }
     flush();
@@ -405,7 +416,9 @@ int svgpfa_set_spikes(svgpfa_engine* e, const int64_t* off, const double* times,
   DALLOC(e, v.Tpart, (size_t)v.nchunks * v.K * 2);
   DALLOC(e, v.muspk, (size_t)v.K * S); DALLOC(e, v.varspk, (size_t)v.K * S);
   DALLOC(e, v.gCspk, (size_t)v.R * v.N * v.K); DALLOC(e, v.splitPart, (size_t)v.nchunks * v.K);
+  DALLOC(e, v.gCspkB, (size_t)v.R * v.N * v.K);
   HIPCHK(e, hipMemset(v.gCspk, 0, sizeof(double) * (size_t)v.R * v.N * v.K));
+  HIPCHK(e, hipMemset(v.gCspkB, 0, sizeof(double) * (size_t)v.R * v.N * v.K));
   HIPCHK(e, hipMemset(v.splitPart, 0, sizeof(double) * std::max<size_t>(1, (size_t)v.nchunks * v.K)));
   HIPCHK(e, hipMemset(v.P1, 0, sizeof(double) * std::max<size_t>(1, (size_t)v.nchunks * v.sumM)));
   HIPCHK(e, hipMemset(v.Tpart, 0, sizeof(double) * std::max<size_t>(1, (size_t)v.nchunks * v.K * 2)));
