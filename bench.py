@@ -58,11 +58,22 @@ PAIR_FLOPS_F32 = {("exponentialQuadratic", True): 11, ("periodic", True): 17,
 FP32_PEAK_TFLOPS = 157.3  # MI355X fp32 vector peak (MI355X_MICROARCH.md)
 
 
-def spike_pass_flops(prob, full, table=None):
-    """Operations one spike pass must execute (PAIR_FLOPS x pairs), this rank's shard."""
+# Periodic latents whose kernel the pass evaluates through its cosine series (svgpfa_get_series_harmonics: H >= 0): per
+# (spike, harmonic) 4 FMA for the moments + 2 FMA for mu + a rotation (2 mul + 2 FMA) = 18 flops with gradients, 2 FMA +
+# rotation = 10 value-only, for H + 1 harmonics -- instead of M pairs.
+SERIES_FLOPS = {True: 18, False: 10}
+
+
+def spike_pass_flops(prob, full, table=None, harmonics=None):
+    """Operations one spike pass must execute, this rank's shard: PAIR_FLOPS x (spike, inducing point) pairs, or
+    SERIES_FLOPS x (spike, harmonic) for the latents evaluated through the cosine series."""
     table = table or PAIR_FLOPS
     S = int(prob["spike_offsets"][-1])
-    return float(sum(S * M * table[(t, bool(full))] for M, t in zip(prob["Ms"], prob["kernel_types"])))
+    tot = 0.0
+    for k, (M, t) in enumerate(zip(prob["Ms"], prob["kernel_types"])):
+        H = harmonics[k] if harmonics is not None else -1
+        tot += S * (H + 1) * SERIES_FLOPS[bool(full)] if H >= 0 else S * M * table[(t, bool(full))]
+    return float(tot)
 
 
 def kernel_source_sha():
@@ -296,7 +307,8 @@ def main():
         ms_per_step = 1e3 * elapsed / args.steps
         full_pass = bool(mask & 14)
         mixed = args.dtype == "mixed"
-        exec_flops = spike_pass_flops(prob, full_pass, PAIR_FLOPS_F32 if mixed else PAIR_FLOPS)
+        harmonics = None if mixed else eng.series_harmonics()      # the fp32 pass always works pair by pair
+        exec_flops = spike_pass_flops(prob, full_pass, PAIR_FLOPS_F32 if mixed else PAIR_FLOPS, harmonics)
         peak = FP32_PEAK_TFLOPS if mixed else FP64_PEAK_TFLOPS
         secs = spike_avg_ms * 1e-3
         achieved = exec_flops / secs / 1e12 if spike_avg_ms > 0 else None
@@ -327,10 +339,12 @@ def main():
                          "kernel": "k_spike<%s%s>" % ("true" if full_pass else "false", ", 8, float" if mixed else ""),
                          "kernel_avg_ms": spike_avg_ms, "kernel_launches": launches,
                          "executed_fp64_flops_per_launch": exec_flops,
+                         "series_harmonics": harmonics,
                          "pair_flops": {"%s/%s" % (t[:3], "full" if f else "value"): v
                                         for (t, f), v in (PAIR_FLOPS_F32 if mixed else PAIR_FLOPS).items()},
                          "note": "k_spike issues no MFMA: its work is one software 2^y (rndne, sub, 10 FMA, ldexp, cvt) and 3-7 "
-                                 "FMAs per (spike, inducing point) pair on the fp64 VALU.  `achieved` = fp64 operations the "
+                                 "FMAs per (spike, inducing point) pair on the fp64 VALU; periodic latents with a short "
+                                 "cosine series (series_harmonics[k] = H >= 0) cost 18 flops per (spike, harmonic) instead.  `achieved` = fp64 operations the "
                                  "kernel must execute (FMA = 2, add / mul / rndne = 1, ldexp / cvt = 0; per-spike set-up not "
                                  "counted) / its hipEvent time; peak = 78.6 TFLOP/s fp64 vector.  survey_convention_* prices a "
                                  "kernel evaluation at 24 flop-EQUIVALENTS (x3 with gradients) as SURVEY 8(d) does; it is not "

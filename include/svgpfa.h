@@ -147,6 +147,12 @@ int svgpfa_latent_stats_backward(svgpfa_engine* e,
                                  unsigned grad_mask, double* shared,
                                  double* const* g_mean, double* const* g_cholvec, double* const* g_Z);
 
+/* Diagnostics: how the spike-time pass evaluates each latent's kernel since the last svgpfa_build_kernels.
+ * out_host[k] (HOST array of n_latents) = H >= 0: periodic kernel through the first H + 1 terms of its cosine series
+ * exp(beta (cos x - 1)) = sum_n c_n cos(n x) (terms below 1e-18 dropped); -1: one kernel evaluation per (spike,
+ * inducing point) pair (every RBF latent; periodic latents with a short lengthscale or few inducing points). */
+int svgpfa_get_series_harmonics(svgpfa_engine* e, int32_t* out_host);
+
 /* KL divergence term alone (stats/klDivergence.py:18-44) of the parameters of the latest svgpfa_elbo /
  * svgpfa_latent_stats / svgpfa_predict call: out[0]. */
 int svgpfa_kl(svgpfa_engine* e, double* out);

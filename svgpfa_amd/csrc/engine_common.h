@@ -24,6 +24,8 @@
 #define SV_MAX_M 64
 #define SV_MAX_K 32
 
+#define SV_FH 64                      // most harmonics of the periodic kernel's Fourier series used by the spike pass
+#define SV_FROWS 3                    // rows of the per-latent series table: c_n | dc_n / dbeta | n c_n / beta
 #define SV_SPL 8                      // spikes per lane in the spike pass (optionally 4, engine::spl)
 #define SV_SPIKE_CHUNK (64 * SV_SPL)  // largest number of spikes per wavefront work item
 
@@ -83,6 +85,8 @@ struct EngineView {
   int nsplit;
   double* Zs;
   double* theta;              // K x 2 snapshot
+  double* four;               // [K][SV_FROWS][SV_FH + 2] series of the periodic kernels (periodic_series), made by k_build_reg
+  int* fourH;                 // [K] harmonics used (n = 0 .. H), or -1: evaluate the kernel pair by pair
   double* Kzz; double* L; double* Linv;
   double* a; double* ut; double* Vt; double* klpart;   // klpart [R*K]
   double* muq; double* varq; double* gmuq; double* gvarq;
@@ -180,6 +184,51 @@ __device__ __forceinline__ void kern_eval(double delta, const KPar& p, double& k
     b0 = 0.5 - 0.5 * cs;
     b1 = delta * sn;
   }
+}
+
+// Periodic kernel as a cosine series (Jacobi-Anger).  With beta = 1 / l^2 and x = 2 pi delta / p
+//     ktil(delta) = exp(-2 sin^2(pi delta / p) / l^2) = exp(beta (cos x - 1)) = sum_{n >= 0} c_n cos(n x),
+//     c_0 = e^-beta I_0(beta),   c_n = 2 e^-beta I_n(beta)
+// the coefficients fall super-exponentially (beta = 0.44: c_13 ~ 1e-19), so sums over spikes of ktil and of its
+// derivatives follow from 4 (H + 1) trigonometric moments of the spikes instead of one exponential per (spike,
+// inducing point) pair (kernels_spike.h).  Scaled Bessel functions e^-beta I_n(beta) by Miller's downward recurrence,
+// normalised with e^-beta (I_0 + 2 sum I_n) = 1; rows: c_n, dc_n / dbeta = e^-beta ((I_{n-1} + I_{n+1}) / 2 - I_n) (x 2 for
+// n > 0), n c_n / beta.  Returns the last harmonic H with n c_n >= 1e-18 (every kernel value is <= 1), or -1 when more
+// than SV_FH harmonics would be needed (short lengthscales) or the pair-by-pair evaluation is cheaper (few inducing
+// points).  One lane per latent, once per kernel build.
+// f: workspace of SV_FH + 3 doubles (LDS of the caller: a private array would put the whole kernel on scratch memory).
+__device__ inline int periodic_series(double beta, int M, double* tab, double* f) {
+  constexpr int NS = SV_FH + 48;        // start of the downward recurrence, far inside the decaying tail for beta <= 45
+  if (!(beta > 0.0) || beta > 45.0) return -1;
+  double fp = 0.0, fc = 1e-280, sum = 0.0;       // f_{n+1}, f_n
+  const double tb = 2.0 / beta;
+  for (int n = NS; n >= 1; --n) {
+    if (n <= SV_FH + 2) f[n] = fc;
+    sum += 2.0 * fc;
+    const double fm = fma(tb * n, fc, fp);       // f_{n-1} = f_{n+1} + (2 n / beta) f_n
+    fp = fc;
+    fc = fm;
+    if (fc > 1e200) {                            // small beta: the recurrence grows by 2 n / beta per step
+      const double sc = 1e-200;
+      fc *= sc; fp *= sc; sum *= sc;
+      for (int q = n; q <= SV_FH + 2 && q <= NS; ++q) f[q] *= sc;
+    }
+  }
+  f[0] = fc;
+  sum += fc;
+  const double inv = 1.0 / sum;
+  int H = 0;
+  for (int n = 0; n <= SV_FH + 1; ++n) {
+    const double ive = f[n] * inv, ivep = f[n + 1] * inv, ivem = (n ? f[n - 1] : f[1]) * inv;
+    const double cn = (n ? 2.0 : 1.0) * ive;
+    tab[n] = cn;
+    tab[(SV_FH + 2) + n] = (n ? 2.0 : 1.0) * (0.5 * (ivem + ivep) - ive);
+    tab[2 * (SV_FH + 2) + n] = n * cn / beta;
+    if (n * cn >= 1e-18 || n == 0) H = n;
+  }
+  if (H > SV_FH) return -1;
+  if (12 * (H + 2) > 23 * M) return -1;          // per-spike cost of the series against M kernel evaluations
+  return H;
 }
 
 __device__ __forceinline__ double wave_sum(double x) {

@@ -48,6 +48,10 @@ __global__ __launch_bounds__(64) void k_build_reg(EngineView ev, int write_aux, 
   if (snap) {
     if (active && rowok) ev.Zs[m.offM + (long long)r * M + i] = zi;
     if (blockIdx.x % rp == 0 && lane < m.nth) ev.theta[2 * k + lane] = st.theta[k][lane];
+    if (blockIdx.x % rp == 0 && lane == 0)     // the periodic kernel's cosine series for the spike pass (engine_common.h)
+      ev.fourH[k] = (m.ktype == SV_PERIODIC)
+                        ? periodic_series(0.5 * p.h, M, ev.four + (size_t)k * SV_FROWS * (SV_FH + 2), &Lt[0][0][0])
+                        : -1;     // (Lt is free until the factorisation starts; one wavefront, program order)
   }
 
   double a[MP];

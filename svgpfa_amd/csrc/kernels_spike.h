@@ -209,9 +209,191 @@ __device__ void spike_body_periodic_full(const EngineView& ev, const double* __r
   }
 }
 
+// Periodic kernel through its cosine series (engine_common.h periodic_series): with theta_s = 2 pi t_s / p,
+// phi_j = 2 pi z_j / p and ktil(delta) = sum_n c_n cos(n x), every sum over spikes the pass needs follows from the
+// trigonometric moments of the chunk's spikes
+//     A_n = sum_s c_s cos(n theta_s)   B_n = sum_s c_s sin(n theta_s)   At_n = sum_s c_s t_s cos(n theta_s)   Bt_n = ... sin
+// (with Cc_nj = cos(n phi_j) A_n + sin(n phi_j) B_n,  Ss_nj = cos(n phi_j) B_n - sin(n phi_j) A_n):
+//     P0_j = sum_s c_s ktil            = sum_n c_n Cc_nj
+//     P1_j = sum_s c_s ktil sin x      = sum_n (n c_n / beta) Ss_nj              (ktil sin x = -(1 / beta) d ktil / dx)
+//     T0   = sum_j a_j sum_s c_s ktil sin^2(x / 2) = -1/2 sum_j a_j sum_n (dc_n / dbeta) Cc_nj
+//     T1   = sum_j a_j sum_s c_s ktil sin x (t_s - z_j) = sum_j a_j sum_n (n c_n / beta) [cos(n phi_j) Bt_n - sin(n phi_j) At_n - z_j Ss_nj]
+//     mu_s = s2 sum_j a_j ktil_sj      = s2 sum_n c_n [cos(n theta_s) Abar_n + sin(n theta_s) Bbar_n],  Abar_n = sum_j a_j cos(n phi_j)
+// A spike costs 10 (H + 1) fp64 operations (4 for the moments, 2 for mu, 4 to rotate (cos, sin) to the next harmonic)
+// instead of M exponentials: H = 13 at the north-star lengthscale against 32 x 23 instructions.  cos / sin of the
+// multiples come from rotations by theta (error ~ n ulp), not from the three-term recurrence (~ n^2 ulp).
+template <bool FULL, int SPL>
+__device__ void spike_body_periodic_series(const EngineView& ev, const double* __restrict__ C, int ch, int k, double* red,
+                                           const int H) {
+  constexpr int NV = FULL ? 4 : 2, JG = 4, NF = SV_FH + 2;
+  const int lane = threadIdx.x;
+  const SpikeChunk c = ev.chunks[ch];
+  const LatentMeta m = ev.meta[k];
+  const int M = m.M, K = ev.K, r = c.trial;
+  const KPar p = make_kpar(m, ev.theta + 2 * k);
+  const double* __restrict__ z = ev.Zs + m.offM + (long long)r * M;
+  const double* __restrict__ a = ev.a + m.offM + (long long)r * M;
+  const double* __restrict__ tab = ev.four + (size_t)k * SV_FROWS * NF;    // c_n | dc_n / dbeta | n c_n / beta
+  const double sc = 4.0 * p.ip;                  // phase in quarter turns
+  double* Fs = red + NV * JG * 65;               // [SV_FH + 1][NV] moments of the chunk
+  double* AB = Fs + (SV_FH + 1) * NV;            // [SV_FH + 1][2] c_n Abar_n, c_n Bbar_n   (FULL)
+  double* zph = AB + (SV_FH + 1) * 2;            // z_j | sin phi_j | cos phi_j
+  double* rs = zph + 3 * 64;                     // 16 reduced values of the current group
+
+  double cw[SPL], tw[SPL], c1[SPL], s1[SPL], cn[SPL], sn[SPL], mu[SPL];
+#pragma unroll
+  for (int i = 0; i < SPL; ++i) {
+    const int idx = lane * SPL + i;              // lane owns SPL consecutive spikes
+    const bool ok = idx < c.count;
+    const long long gs = c.start + (ok ? idx : 0);
+    const double t = ev.spk_t[gs];
+    cw[i] = ok ? C[(long long)ev.spk_n[gs] * K + k] : 0.0;
+    tw[i] = cw[i] * t;
+    sv_sincos_quarter(t * sc, s1[i], c1[i]);
+    cn[i] = 1.0;
+    sn[i] = 0.0;
+    mu[i] = 0.0;
+  }
+  double zj = 0.0, aj = 0.0, sphi = 0.0, cphi = 1.0;
+  if (lane < M) {
+    zj = z[lane];
+    aj = a[lane];
+    sv_sincos_quarter(zj * sc, sphi, cphi);
+  }
+  // transposed reduction of `rows` LDS rows of 64 lane-partials (rows <= 16): lane (v, quarter) sums 16 entries, the
+  // quarters are added by shuffles, lanes < rows hold the totals
+  auto reduce_rows = [&](int rows) -> double {
+    const int v = lane & 15, qd = lane >> 4;
+    double sum = 0.0;
+    if (v < rows) {
+#pragma unroll
+      for (int e = 0; e < 16; ++e) sum += red[v * 65 + qd * 16 + e];
+    }
+    sum += __shfl_xor(sum, 16, 64);
+    sum += __shfl_xor(sum, 32, 64);
+    return sum;
+  };
+  if (FULL) {
+    // Abar_n, Bbar_n (times c_n): the posterior-mean weights a_j projected on the harmonics of the inducing points
+    double cj = 1.0, sj = 0.0;
+    for (int nb = 0; nb <= H; nb += 8) {
+#pragma unroll
+      for (int jj = 0; jj < 8; ++jj) {
+        red[(2 * jj + 0) * 65 + lane] = aj * cj;
+        red[(2 * jj + 1) * 65 + lane] = aj * sj;
+        const double tq = cj * cphi - sj * sphi;
+        sj = fma(sj, cphi, cj * sphi);
+        cj = tq;
+      }
+      __syncthreads();
+      const double tot = reduce_rows(16);
+      const int n = nb + ((lane & 15) >> 1);
+      if (lane < 16 && n <= H) AB[2 * n + (lane & 1)] = tab[n] * tot;
+      __syncthreads();
+    }
+  }
+
+  for (int nb = 0; nb <= H; nb += JG) {
+#pragma unroll
+    for (int jj = 0; jj < JG; ++jj) {
+      const int n = nb + jj;
+      double sa = 0.0, sb = 0.0, sat = 0.0, sbt = 0.0;
+      if (n <= H) {
+        double cA = 0.0, cB = 0.0;
+        if (FULL) {
+          cA = AB[2 * n];
+          cB = AB[2 * n + 1];
+        }
+#pragma unroll
+        for (int i = 0; i < SPL; ++i) {
+          sa = fma(cw[i], cn[i], sa);
+          sb = fma(cw[i], sn[i], sb);
+          if (FULL) {
+            sat = fma(tw[i], cn[i], sat);
+            sbt = fma(tw[i], sn[i], sbt);
+            mu[i] = fma(cn[i], cA, fma(sn[i], cB, mu[i]));
+          }
+          const double tq = cn[i] * c1[i] - sn[i] * s1[i];     // (cos, sin) of (n + 1) theta: rotation by theta
+          sn[i] = fma(sn[i], c1[i], cn[i] * s1[i]);
+          cn[i] = tq;
+        }
+      }
+      red[(NV * jj + 0) * 65 + lane] = sa;
+      red[(NV * jj + 1) * 65 + lane] = sb;
+      if (FULL) {
+        red[(NV * jj + 2) * 65 + lane] = sat;
+        red[(NV * jj + 3) * 65 + lane] = sbt;
+      }
+    }
+    __syncthreads();
+    const double tot = reduce_rows(NV * JG);
+    if (lane < NV * JG && nb + lane / NV <= H) Fs[nb * NV + lane] = tot;
+    __syncthreads();
+  }
+
+  // per inducing point: combine the moments with the harmonics of its own phase
+  double t0acc = 0.0, t1acc = 0.0;
+  if (lane < M) {
+    double cj = 1.0, sj = 0.0, P0 = 0.0, P1 = 0.0, d0 = 0.0, d1 = 0.0;
+    for (int n = 0; n <= H; ++n) {
+      const double An = Fs[n * NV + 0], Bn = Fs[n * NV + 1];
+      const double Cc = fma(cj, An, sj * Bn), Ss = fma(cj, Bn, -(sj * An));
+      P0 = fma(tab[n], Cc, P0);
+      if (FULL) {
+        const double en = tab[2 * NF + n];
+        P1 = fma(en, Ss, P1);
+        d0 = fma(tab[NF + n], Cc, d0);
+        d1 = fma(en, fma(cj, Fs[n * NV + 3], -(sj * Fs[n * NV + 2])) - zj * Ss, d1);
+      }
+      const double tq = cj * cphi - sj * sphi;
+      sj = fma(sj, cphi, cj * sphi);
+      cj = tq;
+    }
+    const long long o = (long long)ch * ev.sumM + m.colM + lane;
+    ev.P0[o] = P0;
+    if (FULL) {
+      ev.P1[o] = P1;
+      t0acc = -0.5 * aj * d0;
+      t1acc = aj * d1;
+    }
+  }
+  if (!FULL) return;
+  const double t0 = wave_sum(t0acc), t1 = wave_sum(t1acc);
+  if (lane == 0) {
+    ev.Tpart[((long long)ch * K + k) * 2 + 0] = t0;
+    ev.Tpart[((long long)ch * K + k) * 2 + 1] = t1;
+  }
+  // spike part of dC[n, k]: per-neuron sums of mu_s
+  int nid[SPL];
+#pragma unroll
+  for (int i = 0; i < SPL; ++i) {
+    const int idx = lane * SPL + i;
+    nid[i] = (idx < c.count) ? ev.spk_n[c.start + idx] : -1;
+  }
+  if (c.split & 1) {
+    double tot = 0.0;
+#pragma unroll
+    for (int i = 0; i < SPL; ++i) tot += (nid[i] >= 0) ? mu[i] : 0.0;
+    tot = wave_sum(tot);
+    if (lane == 0) ev.splitPart[(long long)ch * K + k] = p.s2 * tot;
+  } else {
+    const long long ob = (long long)r * ev.N * K + k;
+#pragma unroll
+    for (int i = 0; i < SPL; ++i) mu[i] *= p.s2;
+    seg_emit_lane<SPL>(nid, mu, ev.gCspk + ob, (c.split & 2) ? ev.gCspkB + ob : nullptr, K, lane);
+  }
+}
+
 template <int KT, bool FULL, int SPL, typename T>
 __device__ void spike_body(const EngineView& ev, const double* __restrict__ C, int ch, int k,
                            double* red_d) {
+  if constexpr (KT == SV_PERIODIC && sizeof(T) == 8) {
+    const int H = ev.fourH[k];               // >= 0: the kernel's cosine series is short enough (periodic_series)
+    if (H >= 0) {
+      spike_body_periodic_series<FULL, SPL>(ev, C, ch, k, red_d, H);
+      return;
+    }
+  }
   if constexpr (KT == SV_PERIODIC && FULL) {
     spike_body_periodic_full<SPL, T>(ev, C, ch, k, red_d);
     return;
@@ -386,7 +568,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 8))) void
   // LDS bounds the waves per CU: RBF full 3 x 8 rows + 4 x 64 (14.5 KB in fp64), periodic full 5 x 4 rows + ~7 x 64 (14 KB),
   // value-only 8 rows; half of that in fp32
   constexpr int LDS_RBF = 3 * SV_SPIKE_JG * 65 + 4 * 64, LDS_PER = 5 * 4 * 65 + 7 * 64 + 32;
-  __shared__ double red[FULL ? (LDS_RBF > LDS_PER ? LDS_RBF : LDS_PER) : SV_SPIKE_JG * 65 + 4 * 64];
+  constexpr int LDS_SER = (FULL ? 16 : 8) * 65 + (SV_FH + 1) * (FULL ? 6 : 4) + 3 * 64 + 16;   // cosine-series body
+  constexpr int LDS_FULL = LDS_RBF > LDS_PER ? (LDS_RBF > LDS_SER ? LDS_RBF : LDS_SER) : (LDS_PER > LDS_SER ? LDS_PER : LDS_SER);
+  constexpr int LDS_VAL = SV_SPIKE_JG * 65 + 4 * 64 > LDS_SER ? SV_SPIKE_JG * 65 + 4 * 64 : LDS_SER;
+  __shared__ double red[FULL ? LDS_FULL : LDS_VAL];
   const int item = blockIdx.x;
   const int nper = ev.ntype[SV_PERIODIC], nrbf = ev.ntype[SV_RBF];
   const int nb_per = ev.nchunks * nper;

@@ -200,6 +200,8 @@ int svgpfa_create(const svgpfa_dims* d, int device, svgpfa_engine** out) {
   double* tq; double* wq; DALLOC(e, tq, (size_t)v.R * v.Q); DALLOC(e, wq, (size_t)v.R * v.Q);
   v.tq = tq; v.wq = wq;
   DALLOC(e, v.Zs, e->totM); DALLOC(e, v.theta, 2 * v.K);
+  DALLOC(e, v.four, (size_t)v.K * SV_FROWS * (SV_FH + 2)); DALLOC(e, v.fourH, v.K);
+  HIPCHK(e, hipMemset(v.fourH, 0xff, sizeof(int) * v.K));
   DALLOC(e, v.Kzz, e->totMM); DALLOC(e, v.L, e->totMM); DALLOC(e, v.Linv, e->totMM);
   DALLOC(e, v.a, e->totM); DALLOC(e, v.ut, e->totM); DALLOC(e, v.Vt, e->totMM); DALLOC(e, v.klpart, (size_t)v.R * v.K);
   size_t rqk = (size_t)v.R * v.Q * v.K;
@@ -776,6 +778,15 @@ int svgpfa_get_ktz_spikes(svgpfa_engine* e, int32_t k, double* out) {
   hipLaunchKernelGGL(k_ktz, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, e->stream, v, (int)k, v.spk_t,
                      v.spk_off, 0, ntot, out);
   HIPCHK(e, hipGetLastError());
+  return SVGPFA_OK;
+}
+
+int svgpfa_get_series_harmonics(svgpfa_engine* e, int32_t* out_host) {
+  if (!e || !out_host) return SVGPFA_ERR_INVALID;
+  HIPCHK(e, hipSetDevice(e->device));
+  if (!e->have_kernels) FAIL(e, SVGPFA_ERR_STATE, "svgpfa_build_kernels has not been called");
+  HIPCHK(e, hipMemcpyAsync(out_host, e->v.fourH, sizeof(int32_t) * e->v.K, hipMemcpyDeviceToHost, e->stream));
+  HIPCHK(e, hipStreamSynchronize(e->stream));
   return SVGPFA_OK;
 }
 

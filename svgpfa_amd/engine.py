@@ -204,6 +204,13 @@ class Engine:
         self._check(self.lib.svgpfa_latent_stats(self._h, mt, ct, *[_ptr(o) for o in outs]))
         return outs
 
+    def series_harmonics(self):
+        """Per latent: H >= 0 if the spike pass evaluates the (periodic) kernel through H + 1 terms of its cosine series,
+        -1 if pair by pair (include/svgpfa.h).  Waits for the stream."""
+        out = (ctypes.c_int32 * self.K)()
+        self._check(self.lib.svgpfa_get_series_harmonics(self._h, out))
+        return list(out)
+
     def kl(self):
         """KL term of the parameters of the latest elbo / latent_stats / predict call (0-dim tensor)."""
         self._use_current_stream()

@@ -483,3 +483,48 @@ def test_cfg5_properties():
     assert abs(acc[0] - full[0]) <= 1e-11 * abs(full[0])
     assert rel_err(acc[3:], full[3:]) < 1e-10
 
+
+
+@pytest.mark.parametrize("ls,M,expect", [(1.5, 32, "series"), (0.5, 32, "series"), (0.25, 48, "series"),
+                                         (0.12, 32, "pairs"), (1.5, 4, "pairs")])
+def test_periodic_series_and_pairwise_paths(ls, M, expect):
+    """The spike pass evaluates a periodic kernel through its cosine series when that is short (long lengthscale, enough
+    inducing points) and pair by pair otherwise (svgpfa_get_series_harmonics).  Both paths against the oracle, all
+    gradient groups and the value-only mask, over 7 periods per trial."""
+    from oracle import svgpfa_oracle as orc
+    prob = synthetic.make_problem(R=3, N=7, K=2, M=[M, M], kernels="periodic", seed=41, n_quad=60, rate=25.0, jitter=1.0,
+                                  trial_len=2.0)
+    prob["theta"] = [np.array([ls, 0.3]), np.array([ls * 1.1, 0.27])]
+    eng, P = _engine(prob)
+    H = eng.series_harmonics()
+    assert all((h >= 0) == (expect == "series") for h in H), H
+    ref = orc.elbo_and_grads(orc.from_numpy_problem(prob), 15)
+    for mask in (15, 1, 0):
+        out = _eval(eng, P, mask)
+        assert _close(out["elbo"], float(ref["elbo"]), TOL_S), (mask, out["elbo"], float(ref["elbo"]))
+        if mask & 1:
+            for k in range(prob["K"]):
+                assert rel_err(out["g_mean"][k], ref["g_mean"][k].numpy()[:, :, 0]) < TOL_A
+                assert rel_err(out["g_cholVecs"][k], ref["g_cholVecs"][k].numpy()[:, :, 0]) < TOL_A
+        if mask == 15:
+            assert rel_err(out["g_C"], ref["g_C"].numpy()) < TOL_A
+            assert rel_err(out["g_d"], ref["g_d"].numpy()) < TOL_A
+            for k in range(prob["K"]):
+                assert rel_err(out["g_theta"][k], ref["g_theta"][k].numpy()) < TOL_A, (k, out["g_theta"][k], ref["g_theta"][k])
+                assert rel_err(out["g_Z"][k], ref["g_Z"][k].numpy()[:, :, 0]) < TOL_A
+
+
+def test_periodic_series_coefficients():
+    """The device's scaled Bessel coefficients (Miller recurrence in k_build_reg) against scipy: through the harmonics
+    count they imply for a range of lengthscales, 2 e^-b I_n(b) n < 1e-18 beyond H."""
+    from scipy.special import ive
+    for ls in (3.0, 1.5, 0.8, 0.4, 0.2):
+        prob = synthetic.make_problem(R=1, N=2, K=1, M=[64], kernels="periodic", seed=43, n_quad=16, rate=5.0)
+        prob["theta"] = [np.array([ls, 0.5])]
+        eng, P = _engine(prob)
+        H = eng.series_harmonics()[0]
+        beta = 1.0 / ls ** 2
+        n = np.arange(1, 200)
+        want = int(n[2.0 * ive(n, beta) * n >= 1e-18].max())
+        assert H == want, (ls, H, want)
+        eng.close()
