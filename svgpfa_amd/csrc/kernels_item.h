@@ -34,8 +34,24 @@ __global__ __launch_bounds__(64) void k_build_reg(EngineView ev, int write_aux, 
   __shared__ double Lt[IPW][MP][MP];       // Lt[item][q][i] = L[i][q]  (column-major: conflict-free writes)
   const int lane = threadIdx.x, sub = lane / MP, i = lane % MP, lbase = lane - i;
   const int rp = (ev.R + IPW - 1) / IPW;
-  const int k = blockIdx.x / rp;
-  int r = (blockIdx.x % rp) * IPW + sub;
+  const int nx = snap ? ev.K : 0;
+  if ((int)blockIdx.x < nx) {
+    // K extra blocks in front of the item blocks (snap launches only): the cosine series of latent k's periodic kernel
+    // for the spike pass (engine_common.h periodic_series) -- a serial recurrence on one lane that runs beside the item
+    // blocks instead of lengthening one of them
+    const int ks = blockIdx.x;
+    if (lane == 0) {
+      const LatentMeta ms = ev.meta[ks];
+      const KPar ps = make_kpar(ms, st.theta[ks]);
+      ev.fourH[ks] = (ms.ktype == SV_PERIODIC)
+                         ? periodic_series(0.5 * ps.h, ms.M, ev.four + (size_t)ks * SV_FROWS * (SV_FH + 2), &Lt[0][0][0])
+                         : -1;
+    }
+    return;
+  }
+  const int bid = blockIdx.x - nx;
+  const int k = bid / rp;
+  int r = (bid % rp) * IPW + sub;
   const bool active = r < ev.R;
   if (!active) r = ev.R - 1;
   const LatentMeta m = ev.meta[k];
@@ -47,11 +63,7 @@ __global__ __launch_bounds__(64) void k_build_reg(EngineView ev, int write_aux, 
   const double zi = rowok ? z[i] : 0.0;
   if (snap) {
     if (active && rowok) ev.Zs[m.offM + (long long)r * M + i] = zi;
-    if (blockIdx.x % rp == 0 && lane < m.nth) ev.theta[2 * k + lane] = st.theta[k][lane];
-    if (blockIdx.x % rp == 0 && lane == 0)     // the periodic kernel's cosine series for the spike pass (engine_common.h)
-      ev.fourH[k] = (m.ktype == SV_PERIODIC)
-                        ? periodic_series(0.5 * p.h, M, ev.four + (size_t)k * SV_FROWS * (SV_FH + 2), &Lt[0][0][0])
-                        : -1;     // (Lt is free until the factorisation starts; one wavefront, program order)
+    if (bid % rp == 0 && lane < m.nth) ev.theta[2 * k + lane] = st.theta[k][lane];
   }
 
   double a[MP];

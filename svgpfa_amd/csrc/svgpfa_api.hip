@@ -436,14 +436,15 @@ static void launch_build(svgpfa_engine* e, int write_aux, const SnapTable* snap)
   EngineView& v = e->v;
   SnapTable none;
   memset(&none, 0, sizeof none);
+  const int extra = snap ? v.K : 0;     // K blocks in front of the item blocks compute the periodic kernels' cosine series
   if (e->Mmax <= 16) {
-    hipLaunchKernelGGL(k_build_reg<16>, dim3(v.K * ((v.R + 3) / 4)), dim3(64), 0, e->stream, v, write_aux, snap ? 1 : 0,
-                       snap ? *snap : none);
+    hipLaunchKernelGGL(k_build_reg<16>, dim3(v.K * ((v.R + 3) / 4) + extra), dim3(64), 0, e->stream, v, write_aux,
+                       snap ? 1 : 0, snap ? *snap : none);
   } else if (e->Mmax <= 32) {
-    hipLaunchKernelGGL(k_build_reg<32>, dim3(v.K * ((v.R + 1) / 2)), dim3(64), 0, e->stream, v, write_aux, snap ? 1 : 0,
-                       snap ? *snap : none);
+    hipLaunchKernelGGL(k_build_reg<32>, dim3(v.K * ((v.R + 1) / 2) + extra), dim3(64), 0, e->stream, v, write_aux,
+                       snap ? 1 : 0, snap ? *snap : none);
   } else {   // M <= 64 (checked at creation): one item per wave, 64 rows, 256 VGPRs of matrix data
-    hipLaunchKernelGGL(k_build_reg<64>, dim3(v.K * v.R), dim3(64), 0, e->stream, v, write_aux, snap ? 1 : 0,
+    hipLaunchKernelGGL(k_build_reg<64>, dim3(v.K * v.R + extra), dim3(64), 0, e->stream, v, write_aux, snap ? 1 : 0,
                        snap ? *snap : none);
   }
 }

@@ -7,7 +7,7 @@ cd "$root"
 python bench.py > "$out/bench_all.json" 2> "$out/bench_all.err"
 python bench.py --variant estep --no-cpu-baseline > "$out/bench_estep.json" 2>/dev/null
 python bench.py --variant estep --estep-cache --no-cpu-baseline > "$out/bench_estep_cached.json" 2>/dev/null
-python bench.py --config cfg2 --no-cpu-baseline --steps 200 > "$out/bench_cfg2.json" 2>/dev/null
+python bench.py --config cfg2 --no-cpu-baseline > "$out/bench_cfg2.json" 2>/dev/null
 python bench.py --dtype mixed --no-cpu-baseline > "$out/bench_cfg3_mixed.json" 2>/dev/null
 python bench.py --config cfg5 --steps 10 --warmup 2 --no-cpu-baseline > "$out/bench_cfg5.json" 2>/dev/null
 python bench.py --config cfg5 --dtype mixed --steps 10 --warmup 2 --no-cpu-baseline > "$out/bench_cfg5_mixed.json" 2>/dev/null
