@@ -14,12 +14,14 @@ spike count across ranks (total work fixed: "strong" scaling) and every step end
 all-reduce of the shared vector [ELBO, ELL, KL, dC, dd, dtheta].
 
 Rank 0 prints one JSON line.  Extra objects:
-  roofline     : the dominant kernel (k_spike, fp64 VALU bound): fp64 operations the kernel must
-                 execute per launch -- counted from its instruction mix per (spike, inducing point)
-                 pair, FMA = 2, other fp64 arithmetic = 1, ldexp / cvt = 0 (PAIR_FLOPS below,
-                 DESIGN.md section 4) -- over its mean device time from hipEvents recorded inside
-                 the timed region, against the 78.6 TFLOP/s fp64 vector peak; frac <= 1 by
-                 construction.  SURVEY 8(d)'s flop-EQUIVALENT convention (24 per kernel evaluation,
+  roofline     : the kernel with the largest device time in this run -- the spike pass k_spike (fp64
+                 VALU bound) or k_item_bwd (f64 MFMA + VALU), within a few per cent of each other at
+                 cfg3; the other one follows as `roofline_second`.  fp64 operations the kernel must
+                 execute per launch -- counted from its instruction mix (PAIR_FLOPS / SERIES_FLOPS /
+                 item_bwd_flops below, FMA = 2, other fp64 arithmetic = 1, ldexp / cvt = 0; DESIGN.md
+                 section 6) -- over its mean device time from hipEvents recorded inside the timed
+                 region on the stream it is launched on, against the 78.6 TFLOP/s fp64 peak; frac <= 1
+                 by construction.  SURVEY 8(d)'s flop-EQUIVALENT convention (24 per kernel evaluation,
                  x3 for value + gradients) is reported beside it as `survey_convention_*`, never
                  as `frac`.
   cpu_baseline : the CPU oracle (oracle/svgpfa_oracle.py, PyTorch-CPU fp64, the reference's
@@ -28,6 +30,7 @@ Rank 0 prints one JSON line.  Extra objects:
 """
 import argparse
 import json
+import math
 import os
 import sys
 import time
@@ -62,6 +65,29 @@ FP32_PEAK_TFLOPS = 157.3  # MI355X fp32 vector peak (MI355X_MICROARCH.md)
 # (spike, harmonic) 4 FMA for the moments + 2 FMA for mu + a rotation (2 mul + 2 FMA) = 18 flops with gradients, 2 FMA +
 # rotation = 10 value-only, for H + 1 harmonics -- instead of M pairs.
 SERIES_FLOPS = {True: 18, False: 10}
+# RBF latents (series_harmonics[k] = -2): the same through the cosine series of the periodised Gaussian, no time-weighted
+# moments: 2 FMA moments + 2 FMA mu + rotation = 14 flops per (spike, harmonic), 10 value-only.
+SERIES_FLOPS_RBF = {True: 14, False: 10}
+
+
+def rbf_series_terms(prob, k, r):
+    """Harmonics (H + 1) of the RBF series for trial r of latent k, by the device's rule (kernels_spike.h
+    rbf_series_setup); 0 where the pass falls back to the pair loop."""
+    import numpy as np
+    off = prob["spike_offsets"]
+    if off[r + 1] == off[r]:
+        return 0
+    t = prob["spike_times"][off[r]:off[r + 1]]
+    z = prob["Z"][k][r]
+    ls = float(prob["theta"][k][0]) / float(prob.get("lengthscale_scales", [1.0] * prob["K"])[k])
+    h = 0.5 / ls ** 2
+    L = (max(t.max(), z.max()) - min(t.min(), z.min())) + math.sqrt(41.5 / h)
+    q = math.pi ** 2 / (h * L * L)
+    nmax = math.sqrt(46.0 / q)
+    H = int(nmax) + 1
+    if not (nmax < 64) or H > 64 or 10 * (H + 2) > 21 * prob["Ms"][k]:
+        return 0
+    return H + 1
 
 
 def spike_pass_flops(prob, full, table=None, harmonics=None):
@@ -70,10 +96,49 @@ def spike_pass_flops(prob, full, table=None, harmonics=None):
     table = table or PAIR_FLOPS
     S = int(prob["spike_offsets"][-1])
     tot = 0.0
+    off = prob["spike_offsets"]
     for k, (M, t) in enumerate(zip(prob["Ms"], prob["kernel_types"])):
         H = harmonics[k] if harmonics is not None else -1
-        tot += S * (H + 1) * SERIES_FLOPS[bool(full)] if H >= 0 else S * M * table[(t, bool(full))]
+        if H >= 0:
+            tot += S * (H + 1) * SERIES_FLOPS[bool(full)]
+        elif H == -2:
+            for r in range(prob["R"]):
+                nt, Sr = rbf_series_terms(prob, k, r), int(off[r + 1] - off[r])
+                tot += Sr * nt * SERIES_FLOPS_RBF[bool(full)] if nt else Sr * M * table[(t, bool(full))]
+        else:
+            tot += S * M * table[(t, bool(full))]
     return float(tot)
+
+
+# k_item_bwd (kernels_item_bwd.h): fp64 operations per (quadrature node, inducing point) of phase 1 on the VALU, from its
+# instruction mix -- kernel value (difference / angle addition, 2^y = 22, scale) + the adjoint accumulations:
+#   RBF 28 (value, gu) + 11 with Z / theta gradients (Gk, gk ktil, delta, dz, th0);  periodic 30 + 21 (cos / sin of the
+#   difference again, dz, th0, th1)
+ITEM_VALU_FLOPS = {("exponentialQuadratic", True): 39, ("exponentialQuadratic", False): 28,
+                   ("periodic", True): 51, ("periodic", False): 30}
+
+
+def item_bwd_flops(prob, mask):
+    """fp64 operations one k_item_bwd launch must execute: its v_mfma_f64_16x16x4_f64 (2 048 flops each, counted from the
+    tile structure: NT = ceil(M / 16) tiles per side, triangular factors skip the zero tiles) plus the kernel
+    evaluations and adjoint accumulations of phase 1 on the VALU (ITEM_VALU_FLOPS).  Phase 2's and phase 3's VALU work is
+    not counted: a lower bound, so the fraction cannot exceed 1."""
+    R, K, Q = prob["R"], prob["K"], prob["Q"]
+    if not (mask & 13):
+        return 0.0
+    full, var = bool(mask & 12), bool(mask & 1)
+    NT = (max(prob["Ms"]) + 15) // 16
+    tri = lambda n: n * (n + 1) // 2
+    tiles = (Q + 15) // 16
+    tp = tiles * (2 * tri(NT) + (NT * NT if full else 0))            # per node tile: Linv k, [D kt], Gt += kt gv kt^T
+    if full:
+        tp += NT * 2 * tri(NT)                                         # D = Linv^T (Vt Vt^T - I), one panel per wave
+        tp += 3 * tri(NT) * NT + NT * tri(NT) + tri(NT) * NT           # C, Vt Vt^T; At Linv; Linv^T (At Linv)
+    if var:
+        tp += sum((NT - c) ** 2 for c in range(NT)) + sum(tri(NT - c) for c in range(NT))   # dL_S
+    mfma = tp * 4 * 2048.0 * R * K
+    valu = sum(R * Q * M * ITEM_VALU_FLOPS[(t, full)] for M, t in zip(prob["Ms"], prob["kernel_types"]))
+    return mfma + float(valu)
 
 
 def kernel_source_sha():
@@ -173,8 +238,8 @@ def _cpu_model():
     return "unknown"
 
 
-def measured_traffic(config, variant, full_mask):
-    """HBM bytes per k_spike launch from a committed PMC digest (profiles/*_pmc.json, made by
+def measured_traffic(config, variant, full_mask, prefix="k_spike<"):
+    """HBM bytes per launch of the kernel `prefix` from a committed PMC digest (profiles/*_pmc.json, made by
     tests/tools/collect_profiles.sh + digest_profiles.py in separate rocprofv3 --pmc passes of this same
     command).  Counters cannot be read inside the timed run, so the figure comes from a digest -- and only from one
     taken on THESE kernels: the digest records the content hash of svgpfa_amd/csrc at collection time and is
@@ -193,7 +258,7 @@ def measured_traffic(config, variant, full_mask):
         tot, n = 0.0, 0     # the spike pass of one evaluation = the k_spike launches of all covariance types
         insts = 0.0
         for k, e in d.get("kernels", {}).items():
-            if k.startswith("k_spike<") and (("true" in k) == bool(full_mask)) \
+            if k.startswith(prefix) and (("true" in k) == bool(full_mask)) \
                     and "hbm_read_bytes_raw" in e and "hbm_write_bytes" in e:
                 tot += e["hbm_read_bytes_raw"] + e["hbm_write_bytes"]
                 insts += e.get("SQ_INSTS_VALU", 0.0)
@@ -288,18 +353,20 @@ def main():
     if use_dist:
         dist.barrier()
     elapsed = time.perf_counter() - t0
-    spike_ms, launches = eng.spike_kernel_ms()
+    spike_ms, launches = eng.kernel_ms(0)
+    item_ms, item_launches = eng.kernel_ms(1)
     eng.enable_timing(False)
     eng.sync()
     elbo = float(shared[0])
 
     if use_dist:
-        t = torch.tensor([elapsed, spike_ms / max(launches, 1)], dtype=torch.float64,
+        t = torch.tensor([elapsed, spike_ms / max(launches, 1), item_ms / max(item_launches, 1)], dtype=torch.float64,
                          device=dev if args.backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed, spike_avg_ms = float(t[0]), float(t[1])
+        elapsed, spike_avg_ms, item_avg_ms = float(t[0]), float(t[1]), float(t[2])
     else:
         spike_avg_ms = spike_ms / max(launches, 1)
+        item_avg_ms = item_ms / max(item_launches, 1)
 
     if rank == 0:
         work = algorithmic_work(prob, args.variant)      # this rank's shard (what one launch processes)
@@ -314,6 +381,22 @@ def main():
         achieved = exec_flops / secs / 1e12 if spike_avg_ms > 0 else None
         conv = work["flops_spike"] / secs / 1e12 if spike_avg_ms > 0 else None
         traffic = measured_traffic(args.config, args.variant, full_pass) if (world == 1 and not mixed) else None
+        item_flops = item_bwd_flops(prob, mask)
+        item_ach = item_flops / (item_avg_ms * 1e-3) / 1e12 if item_avg_ms > 0 else None
+        tr_item = measured_traffic(args.config, args.variant, bool(mask & 12), "k_item_bwd<") if world == 1 else None
+        roof_item = {"bound": "mfma", "achieved": item_ach, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
+                     "frac": (item_ach / FP64_PEAK_TFLOPS) if item_ach else None,
+                     "traffic": tr_item[0] if tr_item else None,
+                     "traffic_source": ("profiles/%s @ csrc %s" % (tr_item[1], tr_item[3])) if tr_item
+                     else "none: no committed PMC digest was taken on this device code (csrc %s)" % kernel_source_sha(),
+                     "kernel": "k_item_bwd<%d, %s>" % ((max(prob["Ms"]) + 15) // 16, "true" if mask & 12 else "false"),
+                     "kernel_avg_ms": item_avg_ms, "kernel_launches": item_launches,
+                     "executed_fp64_flops_per_launch": item_flops,
+                     "note": "per-item adjoints + backward + dC / dd sums: v_mfma_f64_16x16x4_f64 (2 048 flops each, counted "
+                             "from the tile structure) plus the kernel evaluations / adjoint accumulations of its "
+                             "quadrature phase on the VALU (ITEM_VALU_FLOPS per (node, inducing point)); fp64 MFMA and fp64 "
+                             "VALU share one datapath on CDNA4 (their times add), so both are priced against the 78.6 "
+                             "TFLOP/s fp64 peak"}
         out = {
             "metric": "ELBO+grad evals/sec at (trials,neurons,latents,ind)=(%d,%d,%d,%d)" % (
                 full["R"], full["N"], full["K"], full["Ms"][0]),
@@ -329,7 +412,8 @@ def main():
                                          + (", spike sums reused across evaluations" if args.estep_cache else "")),
                        "parallelism": f"trials sharded {world}-way by spike count, 1 RCCL all-reduce/step" if world > 1 else "single GPU"},
             "elbo": elbo,
-            "roofline": {"bound": "valu_fp32" if mixed else "valu_fp64", "achieved": achieved, "peak": peak,
+            "roofline": None,
+            "roofline_spike": {"bound": "valu_fp32" if mixed else "valu_fp64", "achieved": achieved, "peak": peak,
                          "unit": "TFLOP/s", "frac": (achieved / peak) if achieved else None,
                          "traffic": traffic[0] if traffic else None,
                          "traffic_unit": "HBM bytes per spike pass (FETCH_SIZE + WRITE_SIZE of its k_spike launches, separate PMC passes)",
@@ -343,8 +427,9 @@ def main():
                          "pair_flops": {"%s/%s" % (t[:3], "full" if f else "value"): v
                                         for (t, f), v in (PAIR_FLOPS_F32 if mixed else PAIR_FLOPS).items()},
                          "note": "k_spike issues no MFMA: its work is one software 2^y (rndne, sub, 10 FMA, ldexp, cvt) and 3-7 "
-                                 "FMAs per (spike, inducing point) pair on the fp64 VALU; periodic latents with a short "
-                                 "cosine series (series_harmonics[k] = H >= 0) cost 18 flops per (spike, harmonic) instead.  `achieved` = fp64 operations the "
+                                 "FMAs per (spike, inducing point) pair on the fp64 VALU; latents whose kernel has a short "
+                                 "cosine series (series_harmonics[k] = H >= 0 periodic, -2 RBF with H per trial) cost 18 / 14 "
+                                 "flops per (spike, harmonic) instead.  `achieved` = fp64 operations the "
                                  "kernel must execute (FMA = 2, add / mul / rndne = 1, ldexp / cvt = 0; per-spike set-up not "
                                  "counted) / its hipEvent time; peak = 78.6 TFLOP/s fp64 vector.  survey_convention_* prices a "
                                  "kernel evaluation at 24 flop-EQUIVALENTS (x3 with gradients) as SURVEY 8(d) does; it is not "
@@ -358,6 +443,12 @@ def main():
                          "eval_survey_convention_frac_fp64": work_full["flops_eval"] / world / (ms_per_step * 1e-3) / 1e12 / FP64_PEAK_TFLOPS,
                          "eval_frac_hbm": work_full["bytes_eval"] / world / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS},
         }
+        # `roofline` = the kernel with the largest measured time in THIS run (the spike pass and k_item_bwd are within a
+        # few per cent of each other at cfg3 since the spike pass uses the kernels' cosine series); the other one follows
+        # as `roofline_second`
+        spike_first = spike_avg_ms >= item_avg_ms
+        out["roofline"] = out.pop("roofline_spike") if spike_first else roof_item
+        out["roofline_second"] = roof_item if spike_first else out.pop("roofline_spike")
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.config, args.variant, args.cpu_sample_trials, args.cpu_reps)
         print(json.dumps(out), flush=True)

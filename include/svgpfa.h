@@ -149,8 +149,11 @@ int svgpfa_latent_stats_backward(svgpfa_engine* e,
 
 /* Diagnostics: how the spike-time pass evaluates each latent's kernel since the last svgpfa_build_kernels.
  * out_host[k] (HOST array of n_latents) = H >= 0: periodic kernel through the first H + 1 terms of its cosine series
- * exp(beta (cos x - 1)) = sum_n c_n cos(n x) (terms below 1e-18 dropped); -1: one kernel evaluation per (spike,
- * inducing point) pair (every RBF latent; periodic latents with a short lengthscale or few inducing points). */
+ * exp(beta (cos x - 1)) = sum_n c_n cos(n x) (terms below 1e-18 dropped); -2: RBF kernel through the cosine series of
+ * its periodisation over the item's time window, period and number of terms chosen per (trial, latent) at run time
+ * (pair by pair where the lengthscale is short against the window); -1: one kernel evaluation per (spike, inducing
+ * point) pair (periodic latents with a short lengthscale or few inducing points; every latent in precision mode
+ * "mixed"). */
 int svgpfa_get_series_harmonics(svgpfa_engine* e, int32_t* out_host);
 
 /* KL divergence term alone (stats/klDivergence.py:18-44) of the parameters of the latest svgpfa_elbo /
@@ -188,11 +191,13 @@ int svgpfa_get_ktz_spikes(svgpfa_engine* e, int32_t k, double* out);
  * disables the reuse.  The caller must change the token whenever it changes C. */
 int svgpfa_set_embedding_token(svgpfa_engine* e, uint64_t token);
 
-/* Timing hook for bench.py.  While enabled, every svgpfa_elbo call brackets its dominant kernel
- * (the spike-time pass) with a hipEvent pair on the engine's stream; nothing is waited for at
- * record time.  svgpfa_spike_kernel_ms synchronises the stream, adds up the elapsed device time
- * of all pairs recorded since the previous query and returns it with the launch count. */
+/* Timing hook for bench.py.  While enabled, every svgpfa_elbo call brackets its two largest kernels -- the spike-time
+ * pass (which = 0) and k_item_bwd (which = 1) -- with hipEvent pairs on the stream each is launched on; nothing is
+ * waited for at record time.  svgpfa_kernel_ms synchronises, adds up the elapsed device time of all pairs of that
+ * kernel recorded since svgpfa_enable_timing(e, 1) and returns it with the launch count.
+ * svgpfa_spike_kernel_ms = svgpfa_kernel_ms(e, 0, ...). */
 int svgpfa_enable_timing(svgpfa_engine* e, int on);
+int svgpfa_kernel_ms(svgpfa_engine* e, int32_t which, double* total_ms, int32_t* launches);
 int svgpfa_spike_kernel_ms(svgpfa_engine* e, double* total_ms, int32_t* launches);
 
 #ifdef __cplusplus

@@ -57,6 +57,7 @@ SIGNATURES = {
     "svgpfa_get_ktz_spikes": (ctypes.c_int, [_vp, _i32, _vp]),
     "svgpfa_set_embedding_token": (ctypes.c_int, [_vp, ctypes.c_uint64]),
     "svgpfa_enable_timing": (ctypes.c_int, [_vp, ctypes.c_int]),
+    "svgpfa_kernel_ms": (ctypes.c_int, [_vp, _i32, ctypes.POINTER(_f64), ctypes.POINTER(_i32)]),
     "svgpfa_spike_kernel_ms": (ctypes.c_int, [_vp, ctypes.POINTER(_f64), ctypes.POINTER(_i32)]),
 }
 

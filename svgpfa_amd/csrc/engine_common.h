@@ -25,7 +25,7 @@
 #define SV_MAX_K 32
 
 #define SV_FH 64                      // most harmonics of the periodic kernel's Fourier series used by the spike pass
-#define SV_FROWS 3                    // rows of the per-latent series table: c_n | dc_n / dbeta | n c_n / beta
+#define SV_FROWS 3                    // rows of the per-latent series table: c_n | g_n | e_n (kernels_spike.h)
 #define SV_SPL 8                      // spikes per lane in the spike pass (optionally 4, engine::spl)
 #define SV_SPIKE_CHUNK (64 * SV_SPL)  // largest number of spikes per wavefront work item
 
@@ -76,6 +76,9 @@ struct EngineView {
   const double* wq;
   const double* spk_t;
   const int* spk_n;
+  const double* spk_lo;       // R : earliest / latest spike of each trial (window of the RBF kernel's cosine series)
+  const double* spk_hi;
+  int rbf_series;             // 1: the spike pass may evaluate RBF kernels through their periodised series (default)
   const long long* spk_off;   // R+1
   const long long* seg_off;   // R*N+1 : first spike of (trial, neuron)
   const double* spk_cnt;      // N     : spikes per neuron over all local trials
@@ -192,8 +195,8 @@ __device__ __forceinline__ void kern_eval(double delta, const KPar& p, double& k
 // the coefficients fall super-exponentially (beta = 0.44: c_13 ~ 1e-19), so sums over spikes of ktil and of its
 // derivatives follow from 4 (H + 1) trigonometric moments of the spikes instead of one exponential per (spike,
 // inducing point) pair (kernels_spike.h).  Scaled Bessel functions e^-beta I_n(beta) by Miller's downward recurrence,
-// normalised with e^-beta (I_0 + 2 sum I_n) = 1; rows: c_n, dc_n / dbeta = e^-beta ((I_{n-1} + I_{n+1}) / 2 - I_n) (x 2 for
-// n > 0), n c_n / beta.  Returns the last harmonic H with n c_n >= 1e-18 (every kernel value is <= 1), or -1 when more
+// normalised with e^-beta (I_0 + 2 sum I_n) = 1; rows: c_n, g_n = -1/2 dc_n / dbeta with dc_n / dbeta = e^-beta ((I_{n-1} +
+// I_{n+1}) / 2 - I_n) (x 2 for n > 0), e_n = n c_n / beta.  Returns the last harmonic H with n c_n >= 1e-18 (every kernel value is <= 1), or -1 when more
 // than SV_FH harmonics would be needed (short lengthscales) or the pair-by-pair evaluation is cheaper (few inducing
 // points).  One lane per latent, once per kernel build.
 // f: workspace of SV_FH + 3 doubles (LDS of the caller: a private array would put the whole kernel on scratch memory).
@@ -222,7 +225,7 @@ __device__ inline int periodic_series(double beta, int M, double* tab, double* f
     const double ive = f[n] * inv, ivep = f[n + 1] * inv, ivem = (n ? f[n - 1] : f[1]) * inv;
     const double cn = (n ? 2.0 : 1.0) * ive;
     tab[n] = cn;
-    tab[(SV_FH + 2) + n] = (n ? 2.0 : 1.0) * (0.5 * (ivem + ivep) - ive);
+    tab[(SV_FH + 2) + n] = -0.5 * (n ? 2.0 : 1.0) * (0.5 * (ivem + ivep) - ive);   // g_n = -1/2 dc_n / dbeta
     tab[2 * (SV_FH + 2) + n] = n * cn / beta;
     if (n * cn >= 1e-18 || n == 0) H = n;
   }

@@ -209,38 +209,58 @@ __device__ void spike_body_periodic_full(const EngineView& ev, const double* __r
   }
 }
 
-// Periodic kernel through its cosine series (engine_common.h periodic_series): with theta_s = 2 pi t_s / p,
-// phi_j = 2 pi z_j / p and ktil(delta) = sum_n c_n cos(n x), every sum over spikes the pass needs follows from the
-// trigonometric moments of the chunk's spikes
-//     A_n = sum_s c_s cos(n theta_s)   B_n = sum_s c_s sin(n theta_s)   At_n = sum_s c_s t_s cos(n theta_s)   Bt_n = ... sin
+// Kernels as cosine series: ktil(delta) = sum_n c_n cos(n w delta).
+//   periodic (engine_common.h periodic_series): w = 2 pi / p, c_n = (2) e^-beta I_n(beta), beta = 1 / l^2 -- exact
+//       (Jacobi-Anger), truncated where n c_n < 1e-18; table per latent made at kernel-build time.
+//   RBF: exp(-h delta^2), h = 1 / (2 l^2), on the bounded window W of the item (all spike times of the trial and all its
+//       inducing points) equals its periodisation with period L = |W| + sqrt(41.5 / h) up to the wrapped copies
+//       exp(-h (L - |W|)^2) <= 1e-18, and the periodised Gaussian has the series (Poisson summation)
+//       c_n = (2) sqrt(pi / h) / L exp(-pi^2 n^2 / (h L^2)),  w = 2 pi / L,  truncated where n c_n < 1e-18.
+//       L and the number of harmonics are chosen per (trial, latent) at run time from the data and the current
+//       lengthscale (H ~ 4.3 L / l: 19 at the north-star shape); short lengthscales fall back to the pair loop.
+// With theta_s = w (t_s - t0), phi_j = w (z_j - t0) every sum over spikes the pass needs follows from the trigonometric
+// moments of the chunk's spikes
+//     A_n = sum_s c_s cos(n theta_s)   B_n = sum_s c_s sin(n theta_s)   [periodic: At_n, Bt_n = the same weighted by t_s]
 // (with Cc_nj = cos(n phi_j) A_n + sin(n phi_j) B_n,  Ss_nj = cos(n phi_j) B_n - sin(n phi_j) A_n):
-//     P0_j = sum_s c_s ktil            = sum_n c_n Cc_nj
-//     P1_j = sum_s c_s ktil sin x      = sum_n (n c_n / beta) Ss_nj              (ktil sin x = -(1 / beta) d ktil / dx)
-//     T0   = sum_j a_j sum_s c_s ktil sin^2(x / 2) = -1/2 sum_j a_j sum_n (dc_n / dbeta) Cc_nj
-//     T1   = sum_j a_j sum_s c_s ktil sin x (t_s - z_j) = sum_j a_j sum_n (n c_n / beta) [cos(n phi_j) Bt_n - sin(n phi_j) At_n - z_j Ss_nj]
-//     mu_s = s2 sum_j a_j ktil_sj      = s2 sum_n c_n [cos(n theta_s) Abar_n + sin(n theta_s) Bbar_n],  Abar_n = sum_j a_j cos(n phi_j)
-// A spike costs 10 (H + 1) fp64 operations (4 for the moments, 2 for mu, 4 to rotate (cos, sin) to the next harmonic)
-// instead of M exponentials: H = 13 at the north-star lengthscale against 32 x 23 instructions.  cos / sin of the
-// multiples come from rotations by theta (error ~ n ulp), not from the three-term recurrence (~ n^2 ulp).
-template <bool FULL, int SPL>
-__device__ void spike_body_periodic_series(const EngineView& ev, const double* __restrict__ C, int ch, int k, double* red,
-                                           const int H) {
-  constexpr int NV = FULL ? 4 : 2, JG = 4, NF = SV_FH + 2;
-  const int lane = threadIdx.x;
+//     P0_j = sum_s c_s ktil        = sum_n c_n Cc_nj
+//     P1_j = sum_s c_s ktil bz     = sum_n e_n Ss_nj     periodic bz = sin x:  e_n = n c_n / beta   (ktil sin x = -(1/beta) dktil/dx)
+//                                                         RBF      bz = delta:  e_n = n w c_n / (2 h) (ktil delta = -(1/2h) dktil/ddelta)
+//     T0   = sum_j a_j sum_s c_s ktil b0 = sum_j a_j sum_n g_n Cc_nj
+//                                                         periodic b0 = sin^2(x/2): g_n = -1/2 dc_n/dbeta
+//                                                         RBF      b0 = delta^2:    g_n = -dc_n/dh = c_n (1/(2h) - pi^2 n^2 / (h^2 L^2))
+//     T1   (periodic only) = sum_j a_j sum_n e_n [cos(n phi_j) Bt_n - sin(n phi_j) At_n - z_j Ss_nj]
+//     mu_s = s2 sum_j a_j ktil_sj  = s2 sum_n c_n [cos(n theta_s) Abar_n + sin(n theta_s) Bbar_n],  Abar_n = sum_j a_j cos(n phi_j)
+// A spike costs 8 (RBF) / 10 (periodic) fp64 operations per harmonic (2 / 4 for the moments, 2 for mu, 4 to rotate
+// (cos, sin) to the next harmonic) instead of M exponentials: 14 and 20 harmonics at the north-star shape against
+// 32 x 21..23 instructions.  cos / sin of the multiples come from rotations by theta (error ~ n ulp), not from the
+// three-term recurrence (~ n^2 ulp).  Series values carry an ABSOLUTE error of ~1e-15 of the kernel's maximum (the
+// terms are O(0.3) and cancel where the kernel is small); the sums they feed are dominated by their large terms.
+struct SeriesPar {
+  int H;               // harmonics 0 .. H
+  double sc, t0;       // phase in quarter turns = (t - t0) sc
+  const double* c;     // c_n
+  const double* g;     // T0 weights
+  const double* e;     // P1 weights
+};
+
+template <int KT, bool FULL, int SPL>
+__device__ void spike_body_series(const EngineView& ev, const double* __restrict__ C, int ch, int k, double* red,
+                                  const SeriesPar sp) {
+  constexpr bool TW = FULL && KT == SV_PERIODIC;      // time-weighted moments (period gradient)
+  constexpr int ROWS = FULL ? 16 : 8;                 // LDS reduction rows per group (value-only: half the LDS, more waves)
+  constexpr int NV = TW ? 4 : 2, JG = ROWS / NV;
+  const int lane = threadIdx.x, H = sp.H;
   const SpikeChunk c = ev.chunks[ch];
   const LatentMeta m = ev.meta[k];
   const int M = m.M, K = ev.K, r = c.trial;
   const KPar p = make_kpar(m, ev.theta + 2 * k);
   const double* __restrict__ z = ev.Zs + m.offM + (long long)r * M;
   const double* __restrict__ a = ev.a + m.offM + (long long)r * M;
-  const double* __restrict__ tab = ev.four + (size_t)k * SV_FROWS * NF;    // c_n | dc_n / dbeta | n c_n / beta
-  const double sc = 4.0 * p.ip;                  // phase in quarter turns
-  double* Fs = red + NV * JG * 65;               // [SV_FH + 1][NV] moments of the chunk
-  double* AB = Fs + (SV_FH + 1) * NV;            // [SV_FH + 1][2] c_n Abar_n, c_n Bbar_n   (FULL)
-  double* zph = AB + (SV_FH + 1) * 2;            // z_j | sin phi_j | cos phi_j
-  double* rs = zph + 3 * 64;                     // 16 reduced values of the current group
+  const double sc = sp.sc;
+  double* Fs = red + ROWS * 65;                  // [SV_FH + 1][NV] moments of the chunk
+  double* AB = Fs + (SV_FH + 1) * 4;             // [SV_FH + 1][2] c_n Abar_n, c_n Bbar_n   (FULL)
 
-  double cw[SPL], tw[SPL], c1[SPL], s1[SPL], cn[SPL], sn[SPL], mu[SPL];
+  double cw[SPL], tw[TW ? SPL : 1], c1[SPL], s1[SPL], cn[SPL], sn[SPL], mu[FULL ? SPL : 1];
 #pragma unroll
   for (int i = 0; i < SPL; ++i) {
     const int idx = lane * SPL + i;              // lane owns SPL consecutive spikes
@@ -248,24 +268,24 @@ __device__ void spike_body_periodic_series(const EngineView& ev, const double* _
     const long long gs = c.start + (ok ? idx : 0);
     const double t = ev.spk_t[gs];
     cw[i] = ok ? C[(long long)ev.spk_n[gs] * K + k] : 0.0;
-    tw[i] = cw[i] * t;
-    sv_sincos_quarter(t * sc, s1[i], c1[i]);
+    if constexpr (TW) tw[i] = cw[i] * t;
+    sv_sincos_quarter((t - sp.t0) * sc, s1[i], c1[i]);
     cn[i] = 1.0;
     sn[i] = 0.0;
-    mu[i] = 0.0;
+    if constexpr (FULL) mu[i] = 0.0;
   }
   double zj = 0.0, aj = 0.0, sphi = 0.0, cphi = 1.0;
   if (lane < M) {
     zj = z[lane];
     aj = a[lane];
-    sv_sincos_quarter(zj * sc, sphi, cphi);
+    sv_sincos_quarter((zj - sp.t0) * sc, sphi, cphi);
   }
-  // transposed reduction of `rows` LDS rows of 64 lane-partials (rows <= 16): lane (v, quarter) sums 16 entries, the
-  // quarters are added by shuffles, lanes < rows hold the totals
-  auto reduce_rows = [&](int rows) -> double {
+  // transposed reduction of ROWS LDS rows of 64 lane-partials: lane (v, quarter) sums 16 entries, the quarters are
+  // added by shuffles, lanes < ROWS hold the totals
+  auto reduce_rows = [&]() -> double {
     const int v = lane & 15, qd = lane >> 4;
     double sum = 0.0;
-    if (v < rows) {
+    if (v < ROWS) {
 #pragma unroll
       for (int e = 0; e < 16; ++e) sum += red[v * 65 + qd * 16 + e];
     }
@@ -273,7 +293,7 @@ __device__ void spike_body_periodic_series(const EngineView& ev, const double* _
     sum += __shfl_xor(sum, 32, 64);
     return sum;
   };
-  if (FULL) {
+  if constexpr (FULL) {
     // Abar_n, Bbar_n (times c_n): the posterior-mean weights a_j projected on the harmonics of the inducing points
     double cj = 1.0, sj = 0.0;
     for (int nb = 0; nb <= H; nb += 8) {
@@ -286,9 +306,9 @@ __device__ void spike_body_periodic_series(const EngineView& ev, const double* _
         cj = tq;
       }
       __syncthreads();
-      const double tot = reduce_rows(16);
-      const int n = nb + ((lane & 15) >> 1);
-      if (lane < 16 && n <= H) AB[2 * n + (lane & 1)] = tab[n] * tot;
+      const double tot = reduce_rows();
+      const int n = nb + (lane >> 1);
+      if (lane < 16 && n <= H) AB[2 * n + (lane & 1)] = sp.c[n] * tot;
       __syncthreads();
     }
   }
@@ -300,7 +320,7 @@ __device__ void spike_body_periodic_series(const EngineView& ev, const double* _
       double sa = 0.0, sb = 0.0, sat = 0.0, sbt = 0.0;
       if (n <= H) {
         double cA = 0.0, cB = 0.0;
-        if (FULL) {
+        if constexpr (FULL) {
           cA = AB[2 * n];
           cB = AB[2 * n + 1];
         }
@@ -308,11 +328,11 @@ __device__ void spike_body_periodic_series(const EngineView& ev, const double* _
         for (int i = 0; i < SPL; ++i) {
           sa = fma(cw[i], cn[i], sa);
           sb = fma(cw[i], sn[i], sb);
-          if (FULL) {
+          if constexpr (TW) {
             sat = fma(tw[i], cn[i], sat);
             sbt = fma(tw[i], sn[i], sbt);
-            mu[i] = fma(cn[i], cA, fma(sn[i], cB, mu[i]));
           }
+          if constexpr (FULL) mu[i] = fma(cn[i], cA, fma(sn[i], cB, mu[i]));
           const double tq = cn[i] * c1[i] - sn[i] * s1[i];     // (cos, sin) of (n + 1) theta: rotation by theta
           sn[i] = fma(sn[i], c1[i], cn[i] * s1[i]);
           cn[i] = tq;
@@ -320,14 +340,14 @@ __device__ void spike_body_periodic_series(const EngineView& ev, const double* _
       }
       red[(NV * jj + 0) * 65 + lane] = sa;
       red[(NV * jj + 1) * 65 + lane] = sb;
-      if (FULL) {
+      if constexpr (TW) {
         red[(NV * jj + 2) * 65 + lane] = sat;
         red[(NV * jj + 3) * 65 + lane] = sbt;
       }
     }
     __syncthreads();
-    const double tot = reduce_rows(NV * JG);
-    if (lane < NV * JG && nb + lane / NV <= H) Fs[nb * NV + lane] = tot;
+    const double tot = reduce_rows();
+    if (lane < ROWS && nb + lane / NV <= H) Fs[nb * NV + lane] = tot;
     __syncthreads();
   }
 
@@ -338,12 +358,12 @@ __device__ void spike_body_periodic_series(const EngineView& ev, const double* _
     for (int n = 0; n <= H; ++n) {
       const double An = Fs[n * NV + 0], Bn = Fs[n * NV + 1];
       const double Cc = fma(cj, An, sj * Bn), Ss = fma(cj, Bn, -(sj * An));
-      P0 = fma(tab[n], Cc, P0);
-      if (FULL) {
-        const double en = tab[2 * NF + n];
+      P0 = fma(sp.c[n], Cc, P0);
+      if constexpr (FULL) {
+        const double en = sp.e[n];
         P1 = fma(en, Ss, P1);
-        d0 = fma(tab[NF + n], Cc, d0);
-        d1 = fma(en, fma(cj, Fs[n * NV + 3], -(sj * Fs[n * NV + 2])) - zj * Ss, d1);
+        d0 = fma(sp.g[n], Cc, d0);
+        if constexpr (TW) d1 = fma(en, fma(cj, Fs[n * NV + 3], -(sj * Fs[n * NV + 2])) - zj * Ss, d1);
       }
       const double tq = cj * cphi - sj * sphi;
       sj = fma(sj, cphi, cj * sphi);
@@ -351,47 +371,104 @@ __device__ void spike_body_periodic_series(const EngineView& ev, const double* _
     }
     const long long o = (long long)ch * ev.sumM + m.colM + lane;
     ev.P0[o] = P0;
-    if (FULL) {
+    if constexpr (FULL) {
       ev.P1[o] = P1;
-      t0acc = -0.5 * aj * d0;
+      t0acc = aj * d0;
       t1acc = aj * d1;
     }
   }
-  if (!FULL) return;
-  const double t0 = wave_sum(t0acc), t1 = wave_sum(t1acc);
-  if (lane == 0) {
-    ev.Tpart[((long long)ch * K + k) * 2 + 0] = t0;
-    ev.Tpart[((long long)ch * K + k) * 2 + 1] = t1;
-  }
-  // spike part of dC[n, k]: per-neuron sums of mu_s
-  int nid[SPL];
+  if constexpr (FULL) {
+    const double t0 = wave_sum(t0acc), t1 = wave_sum(t1acc);
+    if (lane == 0) {
+      ev.Tpart[((long long)ch * K + k) * 2 + 0] = t0;
+      ev.Tpart[((long long)ch * K + k) * 2 + 1] = t1;
+    }
+    // spike part of dC[n, k]: per-neuron sums of mu_s
+    int nid[SPL];
 #pragma unroll
-  for (int i = 0; i < SPL; ++i) {
-    const int idx = lane * SPL + i;
-    nid[i] = (idx < c.count) ? ev.spk_n[c.start + idx] : -1;
-  }
-  if (c.split & 1) {
-    double tot = 0.0;
+    for (int i = 0; i < SPL; ++i) {
+      const int idx = lane * SPL + i;
+      nid[i] = (idx < c.count) ? ev.spk_n[c.start + idx] : -1;
+    }
+    if (c.split & 1) {
+      double tot = 0.0;
 #pragma unroll
-    for (int i = 0; i < SPL; ++i) tot += (nid[i] >= 0) ? mu[i] : 0.0;
-    tot = wave_sum(tot);
-    if (lane == 0) ev.splitPart[(long long)ch * K + k] = p.s2 * tot;
-  } else {
-    const long long ob = (long long)r * ev.N * K + k;
+      for (int i = 0; i < SPL; ++i) tot += (nid[i] >= 0) ? mu[i] : 0.0;
+      tot = wave_sum(tot);
+      if (lane == 0) ev.splitPart[(long long)ch * K + k] = p.s2 * tot;
+    } else {
+      const long long ob = (long long)r * ev.N * K + k;
 #pragma unroll
-    for (int i = 0; i < SPL; ++i) mu[i] *= p.s2;
-    seg_emit_lane<SPL>(nid, mu, ev.gCspk + ob, (c.split & 2) ? ev.gCspkB + ob : nullptr, K, lane);
+      for (int i = 0; i < SPL; ++i) mu[i] *= p.s2;
+      seg_emit_lane<SPL>(nid, mu, ev.gCspk + ob, (c.split & 2) ? ev.gCspkB + ob : nullptr, K, lane);
+    }
   }
+}
+
+// RBF: window, period and series of this (trial, latent) item (see above).  Returns H, or -1 for the pair loop.
+// cf: LDS, 3 x (SV_FH + 1) doubles (c_n | g_n | e_n).
+__device__ __forceinline__ int rbf_series_setup(const EngineView& ev, const LatentMeta& m, const KPar& p, int r,
+                                                double* cf, double& sc, double& t0) {
+  const int lane = threadIdx.x, M = m.M;
+  const double* z = ev.Zs + m.offM + (long long)r * M;
+  double lo = ev.spk_lo[r], hi = ev.spk_hi[r];
+  if (lane < M) {
+    const double zj = z[lane];
+    lo = fmin(lo, zj);
+    hi = fmax(hi, zj);
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    lo = fmin(lo, __shfl_xor(lo, o, 64));
+    hi = fmax(hi, __shfl_xor(hi, o, 64));
+  }
+  const double PI = 3.14159265358979323846;
+  const double h = p.h;                                  // exp(-h delta^2)
+  const double L = (hi - lo) + sqrt(41.5 / h);           // wrapped copies below e^-41.5 = 1e-18
+  const double q = PI * PI / (h * L * L);                // c_n ~ exp(-q n^2)
+  const double nmax = sqrt(46.0 / q);                    // n c_n / c_0 < 64 e^-46 = 7e-19 beyond
+  if (!(nmax < (double)SV_FH)) return -1;
+  const int H = (int)nmax + 1;
+  if (H > SV_FH || 10 * (H + 2) > 21 * M) return -1;     // per-spike cost of the series against M kernel evaluations
+  const double w = 2.0 * PI / L, c0 = sqrt(PI / h) / L;
+  __syncthreads();                                       // the previous user of this LDS region is done
+  for (int n = lane; n <= H; n += 64) {
+    const double cn = (n ? 2.0 : 1.0) * c0 * exp(-q * (double)n * (double)n);
+    cf[n] = cn;
+    cf[(SV_FH + 1) + n] = cn * (0.5 / h - q * (double)n * (double)n / h);
+    cf[2 * (SV_FH + 1) + n] = (double)n * w * cn * (0.5 / h);
+  }
+  __syncthreads();
+  sc = 4.0 / L;
+  t0 = lo;
+  return H;
 }
 
 template <int KT, bool FULL, int SPL, typename T>
 __device__ void spike_body(const EngineView& ev, const double* __restrict__ C, int ch, int k,
                            double* red_d) {
-  if constexpr (KT == SV_PERIODIC && sizeof(T) == 8) {
-    const int H = ev.fourH[k];               // >= 0: the kernel's cosine series is short enough (periodic_series)
-    if (H >= 0) {
-      spike_body_periodic_series<FULL, SPL>(ev, C, ch, k, red_d, H);
-      return;
+  if constexpr (sizeof(T) == 8) {            // fp64: the kernel through its cosine series where that is short enough
+    constexpr int NF = SV_FH + 2;
+    if constexpr (KT == SV_PERIODIC) {
+      const int H = ev.fourH[k];             // made by k_build_reg (periodic_series)
+      if (H >= 0) {
+        const double* tab = ev.four + (size_t)k * SV_FROWS * NF;
+        const KPar p = make_kpar(ev.meta[k], ev.theta + 2 * k);
+        spike_body_series<SV_PERIODIC, FULL, SPL>(ev, C, ch, k, red_d,
+                                                  SeriesPar{H, 4.0 * p.ip, 0.0, tab, tab + NF, tab + 2 * NF});
+        return;
+      }
+    } else if (ev.rbf_series) {
+      const LatentMeta ms = ev.meta[k];
+      const KPar p = make_kpar(ms, ev.theta + 2 * k);
+      double* cf = red_d + (FULL ? 16 : 8) * 65 + (SV_FH + 1) * 6;   // behind the series body's own LDS
+      double sc, t0;
+      const int H = rbf_series_setup(ev, ms, p, ev.chunks[ch].trial, cf, sc, t0);
+      if (H >= 0) {
+        spike_body_series<SV_RBF, FULL, SPL>(ev, C, ch, k, red_d,
+                                             SeriesPar{H, sc, t0, cf, cf + (SV_FH + 1), cf + 2 * (SV_FH + 1)});
+        return;
+      }
     }
   }
   if constexpr (KT == SV_PERIODIC && FULL) {
@@ -568,7 +645,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 8))) void
   // LDS bounds the waves per CU: RBF full 3 x 8 rows + 4 x 64 (14.5 KB in fp64), periodic full 5 x 4 rows + ~7 x 64 (14 KB),
   // value-only 8 rows; half of that in fp32
   constexpr int LDS_RBF = 3 * SV_SPIKE_JG * 65 + 4 * 64, LDS_PER = 5 * 4 * 65 + 7 * 64 + 32;
-  constexpr int LDS_SER = (FULL ? 16 : 8) * 65 + (SV_FH + 1) * (FULL ? 6 : 4) + 3 * 64 + 16;   // cosine-series body
+  constexpr int LDS_SER = (FULL ? 16 : 8) * 65 + (SV_FH + 1) * 9 + 8;   // cosine-series body: rows, moments + Abar / Bbar, RBF coefficients
   constexpr int LDS_FULL = LDS_RBF > LDS_PER ? (LDS_RBF > LDS_SER ? LDS_RBF : LDS_SER) : (LDS_PER > LDS_SER ? LDS_PER : LDS_SER);
   constexpr int LDS_VAL = SV_SPIKE_JG * 65 + 4 * 64 > LDS_SER ? SV_SPIKE_JG * 65 + 4 * 64 : LDS_SER;
   __shared__ double red[FULL ? LDS_FULL : LDS_VAL];

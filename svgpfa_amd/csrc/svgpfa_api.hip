@@ -41,6 +41,7 @@ struct svgpfa_engine {
   bool timing = false;
   uint64_t emb_token = 0, p0_token = 0;   // svgpfa_set_embedding_token: content id of C now / when P0 was computed
   std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool;  // event pairs, reused
+  std::vector<int> ev_slot;                                // which kernel a pair brackets: 0 k_spike, 1 k_item_bwd
   size_t ev_used = 0;
   std::string err;
   int* status_host = nullptr;  // pinned
@@ -342,6 +343,18 @@ int svgpfa_set_spikes(svgpfa_engine* e, const int64_t* off, const double* times,
   const long long CHUNK = 64LL * e->spl;
   std::vector<int32_t> nh((size_t)S);
   if (S) HIPCHK(e, hipMemcpy(nh.data(), neuron, sizeof(int32_t) * S, hipMemcpyDeviceToHost));
+  std::vector<double> tlo((size_t)v.R, 0.0), thi((size_t)v.R, 0.0);   // spike-time window per trial (RBF cosine series)
+  {
+    std::vector<double> th((size_t)S);
+    if (S) HIPCHK(e, hipMemcpy(th.data(), times, sizeof(double) * S, hipMemcpyDeviceToHost));
+    for (int r = 0; r < v.R; ++r) {
+      if (off[r + 1] > off[r]) {
+        auto mm = std::minmax_element(th.begin() + off[r], th.begin() + off[r + 1]);
+        tlo[r] = *mm.first;
+        thi[r] = *mm.second;
+      }
+    }
+  }
   std::vector<long long> seg((size_t)v.R * v.N + 1);
   std::vector<double> cnt(v.N, 0.0);
   std::vector<SpikeChunk> chunks;
@@ -413,6 +426,15 @@ int svgpfa_set_spikes(svgpfa_engine* e, const int64_t* off, const double* times,
   if (!chunks.empty())
     HIPCHK(e, hipMemcpy(dc, chunks.data(), sizeof(SpikeChunk) * chunks.size(), hipMemcpyHostToDevice));
   HIPCHK(e, hipMemcpy(cf, cfirst.data(), sizeof(int) * (v.R + 1), hipMemcpyHostToDevice));
+  {
+    double* dlo; double* dhi;
+    DALLOC(e, dlo, v.R); DALLOC(e, dhi, v.R);
+    HIPCHK(e, hipMemcpy(dlo, tlo.data(), sizeof(double) * v.R, hipMemcpyHostToDevice));
+    HIPCHK(e, hipMemcpy(dhi, thi.data(), sizeof(double) * v.R, hipMemcpyHostToDevice));
+    v.spk_lo = dlo; v.spk_hi = dhi;
+    const char* rs = getenv("SVGPFA_RBF_SERIES");
+    v.rbf_series = (rs && atoi(rs) == 0) ? 0 : 1;
+  }
   v.spk_t = st; v.spk_n = sn; v.spk_off = so; v.seg_off = sg; v.spk_cnt = sc; v.chunks = dc; v.chunk_first = cf;
   DALLOC(e, v.P0, (size_t)v.nchunks * v.sumM); DALLOC(e, v.P1, (size_t)v.nchunks * v.sumM);
   DALLOC(e, v.Tpart, (size_t)v.nchunks * v.K * 2);
@@ -546,6 +568,21 @@ static int launch_times_quad(svgpfa_engine* e) {
   return launch_times(e, v.tq, nullptr, v.Q, v.muq, v.varq, (long long)v.K * v.Q, 1LL, (long long)v.Q, 1);
 }
 
+// svgpfa_enable_timing: bracket a kernel with a hipEvent pair on the stream it is launched on
+static std::pair<hipEvent_t, hipEvent_t>* timing_begin(svgpfa_engine* e, int slot, hipStream_t st) {
+  if (!e->timing) return nullptr;
+  if (e->ev_used == e->ev_pool.size()) {
+    std::pair<hipEvent_t, hipEvent_t> pr;
+    if (hipEventCreate(&pr.first) != hipSuccess || hipEventCreate(&pr.second) != hipSuccess) return nullptr;
+    e->ev_pool.push_back(pr);
+    e->ev_slot.push_back(0);
+  }
+  e->ev_slot[e->ev_used] = slot;
+  std::pair<hipEvent_t, hipEvent_t>* evp = &e->ev_pool[e->ev_used++];
+  (void)hipEventRecord(evp->first, st);
+  return evp;
+}
+
 static int check_ready(svgpfa_engine* e) {
   if (!e->have_quad) FAIL(e, SVGPFA_ERR_STATE, "svgpfa_set_quad has not been called");
   if (!e->have_spikes) FAIL(e, SVGPFA_ERR_STATE, "svgpfa_set_spikes has not been called");
@@ -582,17 +619,7 @@ int svgpfa_elbo(svgpfa_engine* e, const double* const* mean, const double* const
     // only a value-only pass leaves reusable sums: the full pass accumulates P0 with different roundings, and
     // cached and un-cached evaluations are to stay bit-identical
     e->p0_token = full ? 0 : e->emb_token;
-    std::pair<hipEvent_t, hipEvent_t>* evp = nullptr;
-    if (e->timing) {
-      if (e->ev_used == e->ev_pool.size()) {
-        std::pair<hipEvent_t, hipEvent_t> pr;
-        HIPCHK(e, hipEventCreate(&pr.first));
-        HIPCHK(e, hipEventCreate(&pr.second));
-        e->ev_pool.push_back(pr);
-      }
-      evp = &e->ev_pool[e->ev_used++];
-      HIPCHK(e, hipEventRecord(evp->first, sk));
-    }
+    std::pair<hipEvent_t, hipEvent_t>* evp = timing_begin(e, 0, sk);
     const dim3 gs(v.nchunks * v.K), bs(64);
     if (e->precision == SVGPFA_PRECISION_MIXED) {
       if (e->spl == 16) {
@@ -617,6 +644,7 @@ int svgpfa_elbo(svgpfa_engine* e, const double* const* mean, const double* const
   if ((rc = launch_quad_ell(e, C, d, (mask & 2u) ? 1 : 0, want_lat ? 1 : 0))) return rc;
   // ---- join the spike pass; per-item adjoints + backward + the fixed-order cross-trial reductions in one kernel
   if (side) HIPCHK(e, hipStreamWaitEvent(sm, e->ev_spk, 0));
+  std::pair<hipEvent_t, hipEvent_t>* evb = timing_begin(e, 1, sm);
   if (mask & (4u | 8u)) {
     DISPATCH_NT(e->NT, hipLaunchKernelGGL((k_item_bwd<NT_, true>), dim3(v.R * v.K), dim3(64 * e->tile_nw),
                                           lds_item_bwd(NT_, e->tile_nw), sm, v, pt, mask, C, d, shared));
@@ -624,6 +652,7 @@ int svgpfa_elbo(svgpfa_engine* e, const double* const* mean, const double* const
     DISPATCH_NT(e->NT, hipLaunchKernelGGL((k_item_bwd<NT_, false>), dim3(v.R * v.K), dim3(64 * e->tile_nw),
                                           lds_item_bwd(NT_, e->tile_nw), sm, v, pt, mask, C, d, shared));
   }
+  if (evb) HIPCHK(e, hipEventRecord(evb->second, sm));
   hipLaunchKernelGGL(k_fin_items, dim3(v.nth_total + SV_FIN_NS), dim3(256), 0, sm, v, mask, shared);
   HIPCHK(e, hipGetLastError());
   return SVGPFA_OK;
@@ -788,6 +817,8 @@ int svgpfa_get_series_harmonics(svgpfa_engine* e, int32_t* out_host) {
   if (!e->have_kernels) FAIL(e, SVGPFA_ERR_STATE, "svgpfa_build_kernels has not been called");
   HIPCHK(e, hipMemcpyAsync(out_host, e->v.fourH, sizeof(int32_t) * e->v.K, hipMemcpyDeviceToHost, e->stream));
   HIPCHK(e, hipStreamSynchronize(e->stream));
+  for (int k = 0; k < e->v.K; ++k)
+    if (e->meta[k].ktype == SV_RBF && e->have_spikes && e->v.rbf_series) out_host[k] = -2;
   return SVGPFA_OK;
 }
 
@@ -804,20 +835,26 @@ int svgpfa_enable_timing(svgpfa_engine* e, int on) {
   return SVGPFA_OK;
 }
 
-int svgpfa_spike_kernel_ms(svgpfa_engine* e, double* total_ms, int32_t* launches) {
-  if (!e || !total_ms || !launches) return SVGPFA_ERR_INVALID;
+int svgpfa_kernel_ms(svgpfa_engine* e, int32_t which, double* total_ms, int32_t* launches) {
+  if (!e || !total_ms || !launches || which < 0 || which > 1) return SVGPFA_ERR_INVALID;
   HIPCHK(e, hipStreamSynchronize(e->stream));
   if (e->s_side) HIPCHK(e, hipStreamSynchronize(e->s_side));   // the event pairs live there when the pass is overlapped
   double tot = 0.0;
+  int n = 0;
   for (size_t i = 0; i < e->ev_used; ++i) {
+    if (e->ev_slot[i] != which) continue;
     float ms = 0.f;
     HIPCHK(e, hipEventElapsedTime(&ms, e->ev_pool[i].first, e->ev_pool[i].second));
     tot += ms;
+    ++n;
   }
   *total_ms = tot;
-  *launches = (int32_t)e->ev_used;
-  e->ev_used = 0;
+  *launches = n;
   return SVGPFA_OK;
+}
+
+int svgpfa_spike_kernel_ms(svgpfa_engine* e, double* total_ms, int32_t* launches) {
+  return svgpfa_kernel_ms(e, 0, total_ms, launches);
 }
 
 }  // extern "C"

@@ -291,11 +291,15 @@ class Engine:
     def enable_timing(self, on=True):
         self._check(self.lib.svgpfa_enable_timing(self._h, int(on)))
 
-    def spike_kernel_ms(self):
-        """(total device ms, launches) of the spike-pass kernel since the last query (syncs the stream)."""
+    def kernel_ms(self, which):
+        """(total device ms, launches) of the spike pass (which = 0) or k_item_bwd (which = 1) since enable_timing(True)
+        (syncs the streams)."""
         tot, n = ctypes.c_double(0.0), ctypes.c_int32(0)
-        self._check(self.lib.svgpfa_spike_kernel_ms(self._h, ctypes.byref(tot), ctypes.byref(n)))
+        self._check(self.lib.svgpfa_kernel_ms(self._h, int(which), ctypes.byref(tot), ctypes.byref(n)))
         return tot.value, n.value
+
+    def spike_kernel_ms(self):
+        return self.kernel_ms(0)
 
 
 def engine_from_problem(prob, device=None, precision="fp64"):

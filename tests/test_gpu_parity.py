@@ -528,3 +528,39 @@ def test_periodic_series_coefficients():
         want = int(n[2.0 * ive(n, beta) * n >= 1e-18].max())
         assert H == want, (ls, H, want)
         eng.close()
+
+
+@pytest.mark.parametrize("ls,M,trial_len", [(0.3, 32, 1.0), (0.08, 48, 1.0), (0.02, 32, 1.0), (0.3, 5, 1.0), (0.5, 24, 8.0)])
+def test_rbf_series_and_pairwise_paths(ls, M, trial_len, monkeypatch):
+    """The spike pass evaluates an RBF kernel through the cosine series of its periodisation over the item's window
+    when the lengthscale is long enough against the window (kernels_spike.h rbf_series_setup) and pair by pair otherwise.
+    Whatever the pass chooses per (trial, latent) must agree with the oracle on all gradient groups and on the
+    value-only mask, and with the pure pair-by-pair pass (SVGPFA_RBF_SERIES=0) to rounding."""
+    from oracle import svgpfa_oracle as orc
+    prob = synthetic.make_problem(R=3, N=7, K=2, M=[M, max(M - 3, 2)], kernels="rbf", seed=47, n_quad=60, rate=25.0,
+                                  jitter=1.0, trial_len=trial_len)
+    prob["theta"] = [np.array([ls]), np.array([ls * 1.3])]
+    prob["Z"][0][1] += 0.3 * trial_len                      # inducing points of one trial partly outside the spike window
+    ref = orc.elbo_and_grads(orc.from_numpy_problem(prob), 15)
+    outs = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("SVGPFA_RBF_SERIES", mode)
+        eng, P = _engine(prob)
+        assert eng.series_harmonics() == ([-2, -2] if mode == "1" else [-1, -1])
+        for mask in (15, 1, 0):
+            out = _eval(eng, P, mask)
+            assert _close(out["elbo"], float(ref["elbo"]), TOL_S), (mode, mask, out["elbo"], float(ref["elbo"]))
+            if mask == 15:
+                outs[mode] = out
+                assert rel_err(out["g_C"], ref["g_C"].numpy()) < TOL_A
+                assert rel_err(out["g_d"], ref["g_d"].numpy()) < TOL_A
+                for k in range(prob["K"]):
+                    assert rel_err(out["g_mean"][k], ref["g_mean"][k].numpy()[:, :, 0]) < TOL_A
+                    assert rel_err(out["g_cholVecs"][k], ref["g_cholVecs"][k].numpy()[:, :, 0]) < TOL_A
+                    assert rel_err(out["g_theta"][k], ref["g_theta"][k].numpy()) < TOL_A
+                    assert rel_err(out["g_Z"][k], ref["g_Z"][k].numpy()[:, :, 0]) < TOL_A
+        eng.close()
+    assert abs(outs["1"]["elbo"] - outs["0"]["elbo"]) <= 1e-12 * abs(outs["0"]["elbo"])
+    for k in range(prob["K"]):
+        assert rel_err(outs["1"]["g_Z"][k], outs["0"]["g_Z"][k]) < 1e-9
+        assert rel_err(outs["1"]["g_theta"][k], outs["0"]["g_theta"][k]) < 1e-9
