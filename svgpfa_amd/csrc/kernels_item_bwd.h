@@ -18,7 +18,7 @@
 #include "kernels_mfma.h"
 
 #ifndef SV_BWD_STOP
-#define SV_BWD_STOP 0   // diagnosis builds only (tests/tools/phase_times.sh): 1 stop after phase 1, 2 after the spike gather, 3 before phase 3
+#define SV_BWD_STOP 0   // diagnosis builds only (tests/tools/phase_times.sh): 1 stop after phase 1, 2 after the spike gather, 3 before phase 3, 6 / 7 / 8 inside phase 2
 #endif
 #define SV_MASK_STATS 16u   // internal mask bit: svgpfa_latent_stats_backward (adjoints at quadrature nodes AND spikes given)
 #define SV_FIN_OUT 8   // outputs per reduction group of phase 3 (8 consecutive doubles = one 64-B segment per trial)
@@ -53,10 +53,22 @@ __device__ __forceinline__ void fin_cd_group(const EngineView& ev, const double*
       if (mask & 2u) {
         const int n = id / K, k = id % K;
         const double cnk = C[id];
-        for (int r = pg; r < R; r += NG) s += ev.gCspk[(long long)r * NK + id] + ev.gCspkB[(long long)r * NK + id];
-        for (int b = pg; b < ev.ncd; b += NG) {      // dC = -(E^T mu + C . E^T var)
-          const long long o2 = ((long long)b * N + n) * 2 * K + k;
-          s -= ev.gCpart[o2] + cnk * ev.gCpart[o2 + K];
+        // four trials per step: sixteen independent loads in flight per thread (one trial per step left this block
+        // waiting on memory ~30 times in a row), partial sums added in a fixed order
+        for (int r0 = pg; r0 < R; r0 += 4 * NG) {
+          double v[4];
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            const int r = r0 + u * NG;
+            double t = 0.0;
+            if (r < R) {
+              const long long o2 = ((long long)r * N + n) * 2 * K + k;      // ncd == R: one partial row per trial
+              t = (ev.gCspk[(long long)r * NK + id] + ev.gCspkB[(long long)r * NK + id]) -
+                  (ev.gCpart[o2] + cnk * ev.gCpart[o2 + K]);               // dC = spikes - (E^T mu + C . E^T var)
+            }
+            v[u] = t;
+          }
+          s += (v[0] + v[1]) + (v[2] + v[3]);
         }
         if (pg == 0)
           for (int l = 0; l < ev.nsplit; ++l) {
@@ -70,7 +82,15 @@ __device__ __forceinline__ void fin_cd_group(const EngineView& ev, const double*
     if (n < N) {
       out = 3 + NK + n;
       if (mask & 2u) {
-        for (int b = pg; b < ev.ncd; b += NG) s += ev.gdpart[(long long)b * N + n];
+        for (int b0 = pg; b0 < ev.ncd; b0 += 4 * NG) {
+          double v[4];
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            const int b = b0 + u * NG;
+            v[u] = (b < ev.ncd) ? ev.gdpart[(long long)b * N + n] : 0.0;
+          }
+          s += (v[0] + v[1]) + (v[2] + v[3]);
+        }
         if (pg == 0) s += ev.spk_cnt[n];
       }
     }
@@ -440,11 +460,7 @@ __device__ void item_bwd_body(const EngineView& ev, const int r, const int k, co
     }
     // stage Vt (phase 2 needs it; in the FULL variant the buffer held D).  Gt's padding rows / columns are exact zeros:
     // they are sums of products with zero-padded rows of Linv
-    for (int e = tid; e < MP * MP; e += NTHB) {
-      const int i = e / MP, j = e % MP;
-      const bool in = (i < M) && (j < M);
-      Vl[i * LD + j] = in ? ev.Vt[base + i * M + j] : 0.0;
-    }
+    stage_matrix<NT>(Vl, ev.Vt + base, M, tid, NTHB);
   } else {
     if (tid < MP) {
       ul[tid] = 0.0;
@@ -466,18 +482,18 @@ __device__ void item_bwd_body(const EngineView& ev, const int r, const int k, co
   const int c0 = ev.chunk_first[r], c1 = (mask & SV_MASK_STATS) ? c0 : ev.chunk_first[r + 1];
   if (tid < M) {
     double p0 = 0.0;
-    for (int ch = c0; ch < c1; ch += 4) {          // 4 chunks per step: independent loads in flight, fixed order
-      double v[4], w[4];
+    for (int ch = c0; ch < c1; ch += 8) {          // 8 chunks per step (a cfg3 trial has 8): 16 independent loads in
+      double v[8], w[8];                            // flight, fixed order
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
+      for (int u = 0; u < 8; ++u) {
         const bool in = ch + u < c1;
         const long long o = (long long)(in ? ch + u : ch) * ev.sumM + m.colM + tid;
         v[u] = ev.P0[o];
         w[u] = want_zt ? ev.P1[o] : 0.0;
         if (!in) { v[u] = 0.0; w[u] = 0.0; }
       }
-      p0 += (v[0] + v[1]) + (v[2] + v[3]);
-      p1sum += (w[0] + w[1]) + (w[2] + w[3]);
+      p0 += ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
+      p1sum += ((w[0] + w[1]) + (w[2] + w[3])) + ((w[4] + w[5]) + (w[6] + w[7]));
     }
     a_l = al[tid];
     const double gsp = p.s2 * p0;
@@ -567,6 +583,7 @@ __device__ void item_bwd_body(const EngineView& ev, const int r, const int k, co
     }
   }
   if (!want_zt) return;
+  if (SV_BWD_STOP == 6) return;      // after dm / dL_S
 
   // ---- panel c of C = Vt Vt^T Gt and of VV = Vt Vt^T, kept in registers until Vt is dead in every wave
   d4 VV[NT], Cm[NT];
@@ -593,6 +610,7 @@ __device__ void item_bwd_body(const EngineView& ev, const int r, const int k, co
       for (int q = 0; q < 4; ++q) Cs[(16 * a + 4 * q + lg) * LD + 16 * c + li] = Cm[a][q];
   }
   __syncthreads();
+  if (SV_BWD_STOP == 7) return;      // after C, Vt Vt^T
   // ---- At (in place over Gt): each element is read and written by exactly one lane; the transposed reads of Gt
   //      itself do not occur (only C is read transposed), so no wave sees a half-updated panel
   if (pan) {
@@ -607,6 +625,7 @@ __device__ void item_bwd_body(const EngineView& ev, const int r, const int k, co
       }
   }
   __syncthreads();
+  if (SV_BWD_STOP == 8) return;      // after At
   // ---- panel c of A = Linv^T At Linv, contracted on the fly with dKzz/dZ and dKzz/dtheta
   if (pan) {
     d4 P[NT], Dm[NT], Am[NT];
@@ -628,6 +647,7 @@ __device__ void item_bwd_body(const EngineView& ev, const int r, const int k, co
     }
     tri_chain<NT, 1>(Am, Li, LD, Dm, li, lg);
     const double zc = zl[16 * c + li];
+    const double szc = (KT == SV_PERIODIC) ? szl[16 * c + li] : 0.0, czc = (KT == SV_PERIODIC) ? czl[16 * c + li] : 0.0;
     double t0 = 0.0, t1 = 0.0;
 #pragma unroll
     for (int a = 0; a < NT; ++a)
@@ -637,7 +657,15 @@ __device__ void item_bwd_body(const EngineView& ev, const int r, const int k, co
         double gz = 0.0;
         if (i < M && j < M) {
           double kt, bz, b0, b1;
-          kern_eval<KT>(zl[i] - zc, p, kt, bz, b0, b1);
+          if (KT == SV_PERIODIC) {      // sin / cos of the inducing points' phases are in LDS since phase 1: angle addition
+            const double cs = fma(czl[i], czc, szl[i] * szc), sn = fma(szl[i], czc, -(czl[i] * szc));
+            kt = sv_exp2_neg(fmin(fma(cs, p.h2, -p.h2), 0.0));
+            bz = sn;
+            b0 = 0.5 - 0.5 * cs;
+            b1 = (zl[i] - zc) * sn;
+          } else {
+            kern_eval<KT>(zl[i] - zc, p, kt, bz, b0, b1);
+          }
           double ak = Am[a][q] * kt;
           gz = -(ak * bz);
           t0 = fma(ak, b0, t0);

@@ -51,19 +51,36 @@ __device__ __forceinline__ double grp4_sum(double x) {    // sum over the 4 lane
   return x;
 }
 
+// Stage one M x M matrix of the item (row-major, leading dimension M) into LDS, zero padded to MP x MP with rows padded to
+// LD.  Four independent global loads per thread are in flight before the first LDS store (a plain element loop waits
+// for every load before its store: the staging of a 32 x 32 matrix by 128 threads was eight exposed memory latencies).
+template <int NT>
+__device__ __forceinline__ void stage_matrix(double* dst, const double* src, int M, int tid, int nth) {
+  constexpr int MP = 16 * NT, LD = MP + 2;
+  for (int e0 = tid; e0 < MP * MP; e0 += 4 * nth) {
+    double v[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int e = e0 + u * nth, i = e / MP, j = e % MP;
+      v[u] = (e < MP * MP && i < M && j < M) ? src[i * M + j] : 0.0;
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int e = e0 + u * nth, i = e / MP, j = e % MP;
+      if (e < MP * MP) dst[i * LD + j] = v[u];
+    }
+  }
+}
+
 template <int NT>
 __device__ __forceinline__ void load_factors(const EngineView& ev, const LatentMeta& m, int r, double* Li,
                                              double* Vl, double* ul, double* zl, bool want_v) {
-  constexpr int MP = 16 * NT, LD = MP + 2;
+  constexpr int MP = 16 * NT;
   const int M = m.M, tid = threadIdx.x;
   const long long base = m.offMM + (long long)r * M * M;
   const long long vbase = m.offM + (long long)r * M;
-  for (int e = tid; e < MP * MP; e += (int)blockDim.x) {
-    int i = e / MP, j = e % MP;
-    bool in = (i < M) && (j < M);
-    Li[i * LD + j] = in ? ev.Linv[base + i * M + j] : 0.0;
-    if (want_v) Vl[i * LD + j] = in ? ev.Vt[base + i * M + j] : 0.0;
-  }
+  stage_matrix<NT>(Li, ev.Linv + base, M, tid, (int)blockDim.x);
+  if (want_v) stage_matrix<NT>(Vl, ev.Vt + base, M, tid, (int)blockDim.x);
   if (tid < MP) {
     ul[tid] = (tid < M) ? ev.ut[vbase + tid] : 0.0;
     zl[tid] = (tid < M) ? ev.Zs[vbase + tid] : 0.0;
@@ -203,11 +220,19 @@ __global__ __launch_bounds__(64 * NT) void k_prep_mfma(EngineView ev, LatentPtrT
   const long long base = m.offMM + (long long)r * M * M;
   const long long vbase = m.offM + (long long)r * M;
   const double* cv = pt.cholvec + (long long)r * m.P;
-  for (int e = tid; e < MP * MP; e += NTH) {
-    int i = e / MP, j = e % MP;
-    bool in = (i < M) && (j < M);
-    Li[i * LD + j] = in ? ev.Linv[base + i * M + j] : 0.0;
-    Ls[i * LD + j] = (in && j <= i) ? cv[i * (i + 1) / 2 + j] : 0.0;
+  stage_matrix<NT>(Li, ev.Linv + base, M, tid, NTH);
+  for (int e0 = tid; e0 < MP * MP; e0 += 4 * NTH) {      // L_S from the row-major tril vector, four loads in flight
+    double v[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int e = e0 + u * NTH, i = e / MP, j = e % MP;
+      v[u] = (e < MP * MP && i < M && j <= i) ? cv[i * (i + 1) / 2 + j] : 0.0;
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int e = e0 + u * NTH, i = e / MP, j = e % MP;
+      if (e < MP * MP) Ls[i * LD + j] = v[u];
+    }
   }
   __syncthreads();
 
