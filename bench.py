@@ -374,7 +374,7 @@ def main():
         ms_per_step = 1e3 * elapsed / args.steps
         full_pass = bool(mask & 14)
         mixed = args.dtype == "mixed"
-        harmonics = None if mixed else eng.series_harmonics()      # the fp32 pass always works pair by pair
+        harmonics = eng.series_harmonics()
         exec_flops = spike_pass_flops(prob, full_pass, PAIR_FLOPS_F32 if mixed else PAIR_FLOPS, harmonics)
         peak = FP32_PEAK_TFLOPS if mixed else FP64_PEAK_TFLOPS
         secs = spike_avg_ms * 1e-3

@@ -152,8 +152,7 @@ int svgpfa_latent_stats_backward(svgpfa_engine* e,
  * exp(beta (cos x - 1)) = sum_n c_n cos(n x) (terms below 1e-18 dropped); -2: RBF kernel through the cosine series of
  * its periodisation over the item's time window, period and number of terms chosen per (trial, latent) at run time
  * (pair by pair where the lengthscale is short against the window); -1: one kernel evaluation per (spike, inducing
- * point) pair (periodic latents with a short lengthscale or few inducing points; every latent in precision mode
- * "mixed"). */
+ * point) pair (periodic latents with a short lengthscale or few inducing points; in fp32 in precision mode "mixed"). */
 int svgpfa_get_series_harmonics(svgpfa_engine* e, int32_t* out_host);
 
 /* KL divergence term alone (stats/klDivergence.py:18-44) of the parameters of the latest svgpfa_elbo /

@@ -447,7 +447,9 @@ __device__ __forceinline__ int rbf_series_setup(const EngineView& ev, const Late
 template <int KT, bool FULL, int SPL, typename T>
 __device__ void spike_body(const EngineView& ev, const double* __restrict__ C, int ch, int k,
                            double* red_d) {
-  if constexpr (sizeof(T) == 8) {            // fp64: the kernel through its cosine series where that is short enough
+  {   // the kernel through its cosine series where that is short enough.  The series bodies are fp64 in both precision
+      // modes: rotations accumulate ~n ulp, too much in fp32, and they beat the fp32 pair loop anyway; precision mode
+      // "mixed" uses fp32 in the pair loop, i.e. where the series does not apply
     constexpr int NF = SV_FH + 2;
     if constexpr (KT == SV_PERIODIC) {
       const int H = ev.fourH[k];             // made by k_build_reg (periodic_series)

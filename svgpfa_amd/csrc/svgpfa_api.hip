@@ -336,9 +336,12 @@ int svgpfa_set_spikes(svgpfa_engine* e, const int64_t* off, const double* times,
   v.S = (int)S;
   // granularity of the spike pass: optional half-size chunks for small shards (off by default: measured slower)
   e->spl = ((S + 459) / 460) * v.K < e->small_spike_waves ? 4 : 8;
-  if (e->precision == SVGPFA_PRECISION_MIXED) {      // fp32 pair loop: per-item overheads weigh more, larger work items
-    e->spl = 16;
-    if (getenv("SVGPFA_SPL_F32")) e->spl = atoi(getenv("SVGPFA_SPL_F32")) == 8 ? 8 : 16;
+  if (e->precision == SVGPFA_PRECISION_MIXED) {
+    // 8 spikes per lane as in fp64: the cosine-series bodies (fp64 in both modes) keep 6-7 doubles per spike in
+    // registers.  16 per lane gave the fp32 PAIR loop 9 % (per-item overheads weigh more there) but would spill the
+    // series bodies, which most latents take; SVGPFA_SPL_F32=16 is for runs known to fall back to the pair loop
+    e->spl = 8;
+    if (getenv("SVGPFA_SPL_F32")) e->spl = atoi(getenv("SVGPFA_SPL_F32")) == 16 ? 16 : 8;
   }
   const long long CHUNK = 64LL * e->spl;
   std::vector<int32_t> nh((size_t)S);
