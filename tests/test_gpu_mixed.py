@@ -129,3 +129,31 @@ def test_mixed_model_through_the_factory():
     assert "Maximum number of iterations" in info.message
     assert abs(hist[0] - want[0]) <= TOL_ELBO * abs(want[0])
     assert hist[-1] > hist[0] and abs(hist[-1] - want[-1]) <= 2e-3 * abs(want[-1])     # same optimum to 0.2 %
+
+
+def test_mixed_fp32_pair_loops(monkeypatch):
+    """Most latents take the (fp64) cosine-series spike bodies in both precision modes; this case forces the fp32 PAIR
+    loops of every kernel type and mask -- RBF with the series switched off, periodic with a lengthscale too short for
+    it -- and holds them to the mode's tolerances."""
+    from oracle import svgpfa_oracle as orc
+    from svgpfa_amd.engine import engine_from_problem
+    monkeypatch.setenv("SVGPFA_RBF_SERIES", "0")
+    prob = synthetic.make_problem(R=3, N=9, K=4, M=[12, 16, 9, 20], kernels="mix", seed=53, n_quad=50, rate=30.0, jitter=1.0)
+    for k in (1, 3):
+        prob["theta"][k] = np.array([0.12, 0.4 + 0.05 * k])
+    eng, P = engine_from_problem(prob, precision="mixed")
+    assert eng.series_harmonics() == [-1, -1, -1, -1]
+    eng.close()
+    ref = orc.elbo_and_grads(orc.from_numpy_problem(prob), 15)
+    scale = max(abs(float(ref["elbo"])), abs(float(ref["ell"])), float(prob["spike_offsets"][-1]))
+    for mask in (15, 1, 0):
+        out = _eval(prob, "mixed", mask)
+        assert abs(out["elbo"] - float(ref["elbo"])) <= TOL_ELBO * scale, (mask, out["elbo"], float(ref["elbo"]))
+        if mask & 1:
+            for k in range(prob["K"]):
+                assert rel_err(out["g_mean"][k], ref["g_mean"][k].numpy()[:, :, 0]) < TOL_G
+        if mask == 15:
+            assert rel_err(out["g_C"], ref["g_C"].numpy()) < TOL_GC
+            for k in range(prob["K"]):
+                assert rel_err(out["g_Z"][k], ref["g_Z"][k].numpy()[:, :, 0]) < TOL_G
+                assert rel_err(out["g_theta"][k], ref["g_theta"][k].numpy()) < TOL_G
