@@ -142,12 +142,13 @@ def item_bwd_flops(prob, mask):
 
 
 def kernel_source_sha():
-    """Content hash of the device code: a PMC digest only describes the kernels it was measured on."""
+    """Content hash of the ELBO path's device code: a PMC digest only describes the kernels it was measured on.
+    (lbfgs_*: the optimiser's vector kernels, a separate translation unit that no evaluation launches.)"""
     import hashlib
     h = hashlib.sha256()
     csrc = os.path.join(REPO, "svgpfa_amd", "csrc")
     for f in sorted(os.listdir(csrc)):
-        if f.endswith((".h", ".hip")):
+        if f.endswith((".h", ".hip")) and not f.startswith("lbfgs_"):
             with open(os.path.join(csrc, f), "rb") as fh:
                 h.update(f.encode() + b"\0" + fh.read())
     return h.hexdigest()[:16]

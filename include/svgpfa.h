@@ -199,6 +199,34 @@ int svgpfa_enable_timing(svgpfa_engine* e, int on);
 int svgpfa_kernel_ms(svgpfa_engine* e, int32_t which, double* total_ms, int32_t* launches);
 int svgpfa_spike_kernel_ms(svgpfa_engine* e, double* total_ms, int32_t* launches);
 
+/* ---- Vector kernels of the EM loop's optimiser -------------------------------------------------------------------
+ * The reference optimises every conditional-maximisation step with torch.optim.LBFGS (stats/svEM.py:266-294); its
+ * iteration is ~60 small tensor operations.  These stateless entry points (no engine: device pointers, a HIP stream,
+ * a caller workspace of svgpfa_lbfgs_workspace_doubles(n, max_history) doubles) do the vector work of one
+ * L-BFGS iteration over ONE flat parameter vector of n doubles in the minimum number of passes, with fixed-order
+ * (bit-reproducible) sums.  Entries [0, n_weighted) carry `weight` in every sum (replicated parameters count once across
+ * ranks: weight 0 on all ranks but one); maxima are unweighted and propagate NaN.  Used by
+ * svgpfa_amd/stats/shardedLBFGS.py; arithmetic and decisions stay those of torch.optim.LBFGS.
+ *
+ * svgpfa_lbfgs_grad_stats: g = sign * g_raw;  out6 = [g.d (0 when d is NULL), g.g, |g|_1, max|g|, sign * *value,
+ *   *carry] (the last two only when the pointers are non-NULL: the closure's value and a scalar carried along, so that the
+ *   host reads everything an evaluation produced in one transfer).
+ * svgpfa_lbfgs_pair_dots: y = g - g_prev -> Y[m], s = t d -> S[m] (history rows of row_stride doubles; rows 0..m-1 hold
+ *   the accepted pairs, oldest first); out[0..5) = [y.s, y.y, g.g, s.g, y.g], out[5 + j m + i] for i < m =
+ *   S_i.y (j = 0), Y_i.s (1), Y_i.y (2), S_i.g (3), Y_i.g (4).
+ * svgpfa_lbfgs_direction: d = -H g + sum_i cY_i Y_i + sum_i cS_i S_i with coef = [cY (m), cS (m), H] on the device;
+ *   x0 = x when both are given (the line search's restart point); out_dmax[0] = max|d|. */
+int64_t svgpfa_lbfgs_workspace_doubles(int64_t n, int32_t max_history);
+int svgpfa_lbfgs_grad_stats(void* stream, int64_t n, const double* g_raw, double sign, const double* d, double* g,
+                            int64_t n_weighted, double weight, const double* value, const double* carry, double* work,
+                            double* out6);
+int svgpfa_lbfgs_pair_dots(void* stream, int64_t n, const double* g, const double* g_prev, const double* d, double t,
+                           double* S, double* Y, int64_t row_stride, int32_t m, int64_t n_weighted, double weight,
+                           double* work, double* out);
+int svgpfa_lbfgs_direction(void* stream, int64_t n, const double* g, const double* S, const double* Y, int64_t row_stride,
+                           int32_t m, const double* coef, double* d, const double* x, double* x0, double* work,
+                           double* out_dmax);
+
 #ifdef __cplusplus
 }
 #endif

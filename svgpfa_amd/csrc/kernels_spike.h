@@ -677,37 +677,65 @@ __global__ void k_mseg(EngineView ev) {
   ev.Mseg[id] = s;
 }
 
-// ELL with frozen latent stats (embedding M-step closure): out = [ELL, dC, dd]
+// ELL with frozen latent stats (embedding M-step closure): out = [ELL, dC, dd].
+// Block g < nbo sums SV_FS_OUT consecutive outputs over the per-trial partial rows: thread (o, pg) adds the trials pg,
+// pg + NG, ... four at a time (eight independent loads in flight; one thread per output walking all R rows left ten
+// blocks waiting on memory 500 times in a row), the NG partial sums are added in order through LDS.  Last block: ELL.
+#define SV_FS_OUT 8
 __global__ __launch_bounds__(256) void k_finalize_stats(EngineView ev, const double* C, const double* d,
                                                         int want_grad, double* out) {
-  __shared__ double red[4];
+  __shared__ double red[256];
   const int tid = threadIdx.x;
-  const int NK = ev.N * ev.K;
+  const int NK = ev.N * ev.K, N = ev.N, K = ev.K;
   if (blockIdx.x == gridDim.x - 1) {
     double e = 0.0;
     for (int i = tid; i < ev.nell; i += 256) e += ev.ellq[i];
     for (int i = tid; i < NK; i += 256) e += C[i] * ev.Mseg[i];
-    for (int n = tid; n < ev.N; n += 256) e += ev.spk_cnt[n] * d[n];
+    for (int n = tid; n < N; n += 256) e += ev.spk_cnt[n] * d[n];
     e = block_sum(e, red);
     if (tid == 0) out[0] = e;
     return;
   }
   if (!want_grad) return;
-  int id = blockIdx.x * 256 + tid;
+  const int o = tid % SV_FS_OUT, pg = tid / SV_FS_OUT, NG = 256 / SV_FS_OUT;
+  const int id = blockIdx.x * SV_FS_OUT + o;
+  double s = 0.0;
   if (id < NK) {
-    const int n = id / ev.K, k = id % ev.K;
+    const int n = id / K, k = id % K;
     const double cnk = C[id];
-    double s = 0.0;
-    for (int b = 0; b < ev.ncd; ++b) {
-      const long long o = ((long long)b * ev.N + n) * 2 * ev.K + k;
-      s -= ev.gCpart[o] + cnk * ev.gCpart[o + ev.K];
+    for (int b0 = pg; b0 < ev.ncd; b0 += 4 * NG) {
+      double v[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int b = b0 + u * NG;
+        double t = 0.0;
+        if (b < ev.ncd) {
+          const long long o2 = ((long long)b * N + n) * 2 * K + k;
+          t = ev.gCpart[o2] + cnk * ev.gCpart[o2 + K];
+        }
+        v[u] = t;
+      }
+      s += (v[0] + v[1]) + (v[2] + v[3]);
     }
-    out[1 + id] = s + ev.Mseg[id];
-  } else if (id < NK + ev.N) {
-    int n = id - NK;
-    double s = 0.0;
-    for (int b = 0; b < ev.ncd; ++b) s += ev.gdpart[(long long)b * ev.N + n];
-    out[1 + id] = s + ev.spk_cnt[n];
+    s = -s;
+  } else if (id < NK + N) {
+    const int n = id - NK;
+    for (int b0 = pg; b0 < ev.ncd; b0 += 4 * NG) {
+      double v[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int b = b0 + u * NG;
+        v[u] = (b < ev.ncd) ? ev.gdpart[(long long)b * N + n] : 0.0;
+      }
+      s += (v[0] + v[1]) + (v[2] + v[3]);
+    }
+  }
+  red[pg * SV_FS_OUT + o] = s;
+  __syncthreads();
+  if (pg == 0 && id < NK + N) {
+    double t = red[o];
+    for (int q = 1; q < NG; ++q) t += red[q * SV_FS_OUT + o];
+    out[1 + id] = t + (id < NK ? ev.Mseg[id] : ev.spk_cnt[id - NK]);
   }
 }
 

@@ -753,7 +753,8 @@ int svgpfa_ell_given_stats(svgpfa_engine* e, const double* C, const double* d, i
   int rc;
   if ((rc = launch_quad_ell(e, C, d, want_grad ? 1 : 0, 0))) return rc;
   int nout = v.N * v.K + v.N;
-  hipLaunchKernelGGL(k_finalize_stats, dim3((nout + 255) / 256 + 1), dim3(256), 0, e->stream, v, C, d, want_grad, out);
+  hipLaunchKernelGGL(k_finalize_stats, dim3((nout + SV_FS_OUT - 1) / SV_FS_OUT + 1), dim3(256), 0, e->stream, v, C, d, want_grad,
+                     out);
   HIPCHK(e, hipGetLastError());
   return SVGPFA_OK;
 }

@@ -18,6 +18,7 @@ bracketing / zoom with cubic interpolation, evaluation counting) follow torch.op
 it is a drop-in for it; tests/test_sharded_lbfgs.py checks both the one-rank equivalence and a 2-rank gloo run.
 """
 import math
+import os
 
 import numpy as np
 import torch
@@ -39,21 +40,163 @@ def _cubic_min(x1, f1, g1, x2, f2, g2, bounds=None):
     return min(max(pos, lo), hi)
 
 
+def _two_loop(SY, YY, S_g, Y_g, H, gg, m):
+    """Two-loop recursion on coefficients over the basis {s_i, y_i, g}: q = -g - sum_j al_j y_j,
+    r = H q + sum_j (al_j - be_j) s_j.  -> (al, be, g . d)."""
+    al, be = np.zeros(m), np.zeros(m)
+    dg = np.diag(SY).copy() if m else np.zeros(0)
+    for i in range(m - 1, -1, -1):
+        al[i] = (-S_g[i] - al[i + 1:].dot(SY[i, i + 1:])) / dg[i]
+    yq = -Y_g - YY.dot(al) if m else np.zeros(0)
+    for i in range(m):
+        be[i] = (H * yq[i] + (al[:i] - be[:i]).dot(SY[:i, i])) / dg[i]
+    gtd = -H * gg
+    if m:
+        gtd += float(-H * al.dot(Y_g) + (al - be).dot(S_g))
+    return al, be, gtd
+
+
+class _TorchVec:
+    """The three fused vector primitives of flat mode in plain tensor operations (CPU tensors: tests, gloo rehearsals).
+    Same argument meaning and output layout as the svgpfa_lbfgs_* entry points (include/svgpfa.h)."""
+
+    def __init__(self, x, ns, w0, history_size):
+        self._w = None
+        if ns and w0 != 1.0:
+            self._w = torch.ones_like(x)
+            self._w[:ns] = w0
+
+    def grad_stats(self, g_raw, sign, d, value, carry):
+        g = g_raw.detach().reshape(-1) * sign
+        gw = g if self._w is None else g * self._w
+        zero = g.new_zeros(())
+        out = torch.stack([gw.dot(d) if d is not None else zero, gw.dot(g), gw.abs().sum(),
+                           g.abs().max() if g.numel() else zero,
+                           value.detach().reshape(()).to(g.dtype) * sign if value is not None else zero,
+                           carry.reshape(()) if carry is not None else zero])
+        return g, out
+
+    def pair_dots(self, g, prev_g, d, t, S, Y, m):
+        torch.sub(g, prev_g, out=Y[m])
+        torch.mul(d, t, out=S[m])
+        y, s = Y[m], S[m]
+        w = self._w
+        yw, sw, gw = (y, s, g) if w is None else (y * w, s * w, g * w)
+        head = torch.stack([yw.dot(s), yw.dot(y), gw.dot(g), sw.dot(g), yw.dot(g)])
+        if not m:
+            return head
+        Sm, Ym = S[:m], Y[:m]
+        return torch.cat([head, Sm @ yw, Ym @ sw, Ym @ yw, Sm @ gw, Ym @ gw])
+
+    def direction(self, g, S, Y, m, coef, d, x, x0):
+        c = torch.from_numpy(np.ascontiguousarray(coef)).to(device=g.device, dtype=g.dtype)
+        torch.mul(g, -float(coef[2 * m]), out=d)
+        if m:
+            d.addmv_(Y[:m].t(), c[:m])
+            d.addmv_(S[:m].t(), c[m:2 * m])
+        if x0 is not None:
+            x0.copy_(x)
+        return d.abs().max().reshape(1)
+
+
+class _HipVec:
+    """The same primitives through the fused HIP kernels (svgpfa_amd/csrc/lbfgs_api.hip): fp64 vectors on one GPU."""
+
+    def __init__(self, x, ns, w0, history_size):
+        from .. import _lib
+        self._lib = _lib.load()
+        if x.dtype != torch.float64:
+            raise TypeError("the fused optimiser kernels work on float64 vectors")
+        self._n, self._ns, self._w0 = x.numel(), int(ns), float(w0)
+        self._dev = x.device
+        self._hist = 8
+        self._work = None
+        self._grow(8)
+        self._dmax = torch.empty(1, dtype=torch.float64, device=x.device)
+
+    def _grow(self, m):
+        if self._work is None or m > self._hist:
+            self._hist = max(self._hist, 2 * m)
+            nw = int(self._lib.svgpfa_lbfgs_workspace_doubles(self._n, self._hist))
+            self._work = torch.empty(nw, dtype=torch.float64, device=self._dev)
+
+    def _stream(self):
+        return torch.cuda.current_stream(self._dev).cuda_stream
+
+    @staticmethod
+    def _ptr(t):
+        if t is None:
+            return None
+        if not (t.is_cuda and t.dtype == torch.float64 and t.is_contiguous()):
+            raise TypeError("the fused optimiser kernels need contiguous float64 device tensors")
+        return t.data_ptr()
+
+    def _check(self, rc, what):
+        if rc:
+            raise RuntimeError(f"{what} failed (status {rc})")
+
+    def grad_stats(self, g_raw, sign, d, value, carry):
+        g_raw = g_raw.detach().reshape(-1)
+        g = torch.empty_like(g_raw)
+        out = torch.empty(6, dtype=torch.float64, device=self._dev)
+        if value is None or carry is None:
+            out.zero_()
+        value = None if value is None else value.detach().reshape(1)
+        self._check(self._lib.svgpfa_lbfgs_grad_stats(self._stream(), self._n, self._ptr(g_raw), float(sign), self._ptr(d),
+                                                      self._ptr(g), self._ns, self._w0, self._ptr(value),
+                                                      self._ptr(carry), self._ptr(self._work), self._ptr(out)),
+                    "svgpfa_lbfgs_grad_stats")
+        return g, out
+
+    def pair_dots(self, g, prev_g, d, t, S, Y, m):
+        self._grow(m)
+        out = torch.empty(5 * m + 5, dtype=torch.float64, device=self._dev)
+        self._check(self._lib.svgpfa_lbfgs_pair_dots(self._stream(), self._n, self._ptr(g), self._ptr(prev_g), self._ptr(d),
+                                                     float(t), S.data_ptr(), Y.data_ptr(), S.stride(0), int(m), self._ns,
+                                                     self._w0, self._ptr(self._work), self._ptr(out)),
+                    "svgpfa_lbfgs_pair_dots")
+        return out
+
+    def direction(self, g, S, Y, m, coef, d, x, x0):
+        c = torch.from_numpy(np.ascontiguousarray(coef, dtype=np.float64)).to(self._dev)
+        self._check(self._lib.svgpfa_lbfgs_direction(self._stream(), self._n, self._ptr(g),
+                                                     S.data_ptr() if m else None, Y.data_ptr() if m else None,
+                                                     S.stride(0) if m else self._n, int(m), self._ptr(c), self._ptr(d),
+                                                     self._ptr(x), self._ptr(x0), self._ptr(self._work),
+                                                     self._ptr(self._dmax)),
+                    "svgpfa_lbfgs_direction")
+        return self._dmax
+
+
 class ShardedLBFGS:
     """``local_params``: tensors this rank owns exclusively.  ``shared_params``: tensors replicated on every rank,
     whose gradients the closure has already summed over ranks (svgpfa_amd.distributed.attach does that).
 
     Flat mode (``flat=x``): the whole parameter group is ONE contiguous tensor ``x`` (the model keeps each group in one
     buffer and hands out views, SVLowerBound.flatParams) and ``closure()`` returns ``(loss, flat_gradient)`` directly
-    (SVLowerBound.evalFlat: no autograd graph, gradients written by the engine straight into a flat buffer).  A trial
-    step is then one axpy and a line-search rollback one copy, instead of one small kernel per parameter tensor (4 K + 2
-    tensors at the north-star size: ~100 launches per closure); ``shared=True`` says the group is replicated on every
-    rank.  Arithmetic and decisions are the same as in list mode."""
+    (SVLowerBound.evalFlat: no autograd graph, gradients written by the engine straight into a flat buffer);
+    ``shared=True`` says the group is replicated on every rank.  ``maximize=True``: the closure returns (value,
+    gradient) of an objective to MAXIMISE and the optimiser minimises its negative (the sign change rides on the copy
+    of the gradient it has to take anyway).  Arithmetic and decisions are those of list mode; two execution paths,
+    chosen per group:
+
+    * vectors on the device (per-trial groups): an iteration's vector work is three fused passes -- gradient copy +
+      statistics, history update + all inner products, direction + restart point (``_HipVec``: the
+      ``svgpfa_lbfgs_*`` entry points of include/svgpfa.h; ``_TorchVec``: the same primitives in plain tensor
+      operations for CPU tensors, i.e. tests and gloo rehearsals) -- and ONE host read-back per evaluation;
+    * vectors on the host (``host_max`` doubles or fewer, and the group replicated or the run single-rank: embedding
+      and kernel parameters): value and gradient come back in the evaluation's one transfer, the recursion runs in numpy
+      and the new parameters go up with one copy.  A replicated group needs no collective at all: every rank sees the
+      same all-reduced gradient and takes the same decisions."""
 
     def __init__(self, local_params=(), shared_params=(), lr=1.0, max_iter=20, max_eval=None, tolerance_grad=1e-7,
-                 tolerance_change=1e-9, history_size=100, line_search_fn=None, group=None, flat=None, shared=False):
+                 tolerance_change=1e-9, history_size=100, line_search_fn=None, group=None, flat=None, shared=False,
+                 maximize=False, host_max=None):
         if line_search_fn not in (None, "strong_wolfe"):
             raise RuntimeError("only 'strong_wolfe' is supported")
+        if maximize and flat is None:
+            raise ValueError("maximize=True needs flat mode")
+        self._maximize = bool(maximize)
         self._flat = flat
         if flat is not None:
             if not (flat.dim() == 1 and flat.is_contiguous()):
@@ -83,6 +226,10 @@ class ShardedLBFGS:
             self._w[:self._ns] = 0.0
         self.state = {p0: {"func_evals": 0, "n_iter": 0}}
         self.collectives = 0          # number of all-gathers issued (reported by the tests / bench)
+        if host_max is None:
+            host_max = int(os.environ.get("SVGPFA_LBFGS_HOST_MAX", "32768"))
+        self._host = flat is not None and flat.numel() <= host_max and (shared or self._world == 1)
+        self._vec = None
 
     # ------------------------------------------------------------------ flat views
     def zero_grad(self, set_to_none=True):
@@ -97,17 +244,11 @@ class ShardedLBFGS:
 
     def _eval(self, closure):
         """-> (loss tensor, flat gradient as a tensor of its own)."""
-        if self._flat is not None:
-            loss, g = closure()
-            return loss, g
         loss = closure()
         return loss, self._flat_grad()
 
     @torch.no_grad()
     def _add(self, t, d):
-        if self._flat is not None:
-            self._flat.add_(d, alpha=t)
-            return
         o = 0
         for p in self._params:
             n = p.numel()
@@ -158,6 +299,12 @@ class ShardedLBFGS:
 
     # ------------------------------------------------------------------ optimisation
     def step(self, closure):
+        if self._flat is not None:
+            with torch.no_grad():
+                return self._step_host(closure) if self._host else self._step_flat(closure)
+        return self._step_list(closure)
+
+    def _step_list(self, closure):
         st = self.state[self._params[0]]
         closure = torch.enable_grad()(closure)
         tg, tc = self.tolerance_grad, self.tolerance_change
@@ -225,21 +372,12 @@ class ShardedLBFGS:
                     S_g, Y_g = np.append(S_g, sg), np.append(Y_g, yg)
                     H = ys / yy
                     m += 1
-                # two-loop recursion on coefficients: q = -g - sum_j al_j y_j ; r = H q + sum_j (al_j - be_j) s_j
-                al, be = np.zeros(m), np.zeros(m)
-                dg = np.diag(SY).copy() if m else np.zeros(0)
-                for i in range(m - 1, -1, -1):
-                    al[i] = (-S_g[i] - al[i + 1:].dot(SY[i, i + 1:])) / dg[i]
-                yq = -Y_g - YY.dot(al) if m else np.zeros(0)
-                for i in range(m):
-                    be[i] = (H * yq[i] + (al[:i] - be[:i]).dot(SY[:i, i])) / dg[i]
+                al, be, gtd = _two_loop(SY, YY, S_g, Y_g, H, gg, m)
                 d = g.mul(-H)
-                gtd = -H * gg
                 if m:
                     coef = torch.from_numpy(np.concatenate([-H * al, al - be])).to(device=g.device, dtype=g.dtype)
                     d.addmv_(Yb[:m].t(), coef[:m])
                     d.addmv_(Sb[:m].t(), coef[m:])
-                    gtd += float(-H * al.dot(Y_g) + (al - be).dot(S_g))
             prev_g = g.clone()
             prev_loss = loss
             t = min(1.0, 1.0 / gabs) * self.lr if st["n_iter"] == 1 else self.lr
@@ -285,13 +423,276 @@ class ShardedLBFGS:
         st.update(d=d, t=t, Sb=Sb, Yb=Yb, m=m, SY=SY, YY=YY, H=H, prev_g=prev_g, prev_loss=prev_loss)
         return orig_loss
 
-    def _strong_wolfe(self, phi, t, d, f, g, gtd, c1=1e-4, c2=0.9, max_ls=25):
+    # ------------------------------------------------------------------ flat mode, vectors on the device
+    def _read(self, out, nsum, maxes=(), extra=()):
+        """Host copy of a small device vector `out` whose first nsum entries are local partial sums, entries `maxes`
+        local partial maxima and entries `extra` already global: ONE transfer (and at most one all-gather)."""
+        if self._world == 1:
+            return out.double().cpu().numpy()
+        idx = list(range(nsum)) + list(maxes)
+        loc = out[idx] if len(idx) != out.numel() else out
+        rs, rm = self._reduce(loc[:nsum], loc[nsum:] if maxes else None)
+        vals = out.double().cpu().numpy().copy()
+        if nsum:
+            vals[:nsum] = rs.double().cpu().numpy()
+        if maxes:
+            vals[list(maxes)] = rm.double().cpu().numpy()
+        return vals
+
+    def _vectors(self):
+        if self._vec is None:
+            x = self._flat
+            ns = x.numel() if self._shared else 0
+            w0 = 1.0 if self._rank == 0 else 0.0
+            cls = _HipVec if x.is_cuda else _TorchVec
+            self._vec = cls(x, ns, w0, self.history_size)
+        return self._vec
+
+    def _step_flat(self, closure):
+        """One optimiser step over the flat group with the vectors on the device; same control flow as _step_list."""
+        st = self.state[self._params[0]]
+        tg, tc = self.tolerance_grad, self.tolerance_change
+        vec, x = self._vectors(), self._flat
+        sign = -1.0 if self._maximize else 1.0
+
+        val, graw = closure()
+        g, out = vec.grad_stats(graw, sign, None, val, None)
+        v = self._read(out[:5], 3, maxes=(3,))
+        gg, gabs, gmax, loss = float(v[1]), float(v[2]), float(v[3]), float(v[4])
+        orig_loss = loss
+        evals = 1
+        st["func_evals"] += 1
+        if gmax <= tg:
+            return torch.as_tensor(orig_loss)
+
+        d, t = st.get("d"), st.get("t")
+        Sb, Yb, m = st.get("Sb"), st.get("Yb"), st.get("m", 0)      # history rows 0..m-1 (oldest first), row m: candidate
+        SY, YY = st.get("SY"), st.get("YY")
+        H = st.get("H", 1.0)
+        prev_g, prev_loss = st.get("prev_g"), st.get("prev_loss")
+        x0 = st.get("x0")
+        if d is None:
+            d, x0 = torch.empty_like(x), torch.empty_like(x)
+        n_iter = 0
+        while n_iter < self.max_iter:
+            n_iter += 1
+            st["n_iter"] += 1
+            if st["n_iter"] == 1:
+                m = 0
+                SY = YY = np.zeros((0, 0))
+                H = 1.0
+                gtd = -gg
+                coef = np.array([H])
+            else:
+                if Sb is None or m + 1 > Sb.shape[0]:                 # grow the history buffers geometrically
+                    cap = min(self.history_size, max(8, 2 * m)) + 1
+                    nS, nY = x.new_empty(cap, x.numel()), x.new_empty(cap, x.numel())
+                    if m:
+                        nS[:m], nY[:m] = Sb[:m], Yb[:m]
+                    Sb, Yb = nS, nY
+                part = vec.pair_dots(g, prev_g, d, t, Sb, Yb, m)      # writes the candidate pair into row m
+                tot = self._read(part, part.numel())                  # the one host sync of the iteration
+                ys, yy, gg, sg, yg = (float(v) for v in tot[:5])
+                S_y, s_Y, Y_y, S_g, Y_g = (tot[5 + i * m:5 + (i + 1) * m] for i in range(5))
+                if ys > 1e-10:
+                    if m == self.history_size:       # drop the oldest pair (the candidate moves down with the rest)
+                        Sb[:m] = Sb[1:m + 1].clone()
+                        Yb[:m] = Yb[1:m + 1].clone()
+                        SY, YY = SY[1:, 1:], YY[1:, 1:]
+                        S_y, s_Y, Y_y, S_g, Y_g = S_y[1:], s_Y[1:], Y_y[1:], S_g[1:], Y_g[1:]
+                        m -= 1
+                    nSY, nYY = np.zeros((m + 1, m + 1)), np.zeros((m + 1, m + 1))
+                    nSY[:m, :m], nYY[:m, :m] = SY, YY
+                    nSY[:m, m], nSY[m, :m], nSY[m, m] = S_y, s_Y, ys       # SY[i, j] = s_i . y_j
+                    nYY[:m, m], nYY[m, :m], nYY[m, m] = Y_y, Y_y, yy
+                    SY, YY = nSY, nYY
+                    S_g, Y_g = np.append(S_g, sg), np.append(Y_g, yg)
+                    H = ys / yy
+                    m += 1
+                al, be, gtd = _two_loop(SY, YY, S_g, Y_g, H, gg, m)
+                coef = np.concatenate([-H * al, al - be, [H]])
+            dmax_t = vec.direction(g, Sb, Yb, m, coef, d, x, x0)          # d, x0 = x, max |d| (stays on the device)
+            prev_g = g
+            prev_loss = loss
+            t = min(1.0, 1.0 / gabs) * self.lr if st["n_iter"] == 1 else self.lr
+            if gtd > -tc:
+                break
+
+            ls_evals = 0
+            if self.line_search_fn == "strong_wolfe":
+                last = [None]
+
+                def phi(step):    # -> (loss, gradient, g . d, max |g|, max |d|) at x0 + step d; ONE host sync
+                    torch.add(x0, d, alpha=step, out=x)
+                    last[0] = step
+                    f, graw = closure()
+                    gn, o6 = vec.grad_stats(graw, sign, d, f, dmax_t)
+                    v = self._read(o6, 3, maxes=(3, 5))
+                    return float(v[4]), gn, float(v[0]), float(v[3]), float(v[5])
+                loss, g, t, ls_evals, gmax, dmax = self._strong_wolfe(phi, t, d, loss, g, gtd, gm0=gmax)
+                if last[0] != t:
+                    torch.add(x0, d, alpha=t, out=x)
+            else:
+                x.add_(d, alpha=t)
+                if n_iter != self.max_iter:
+                    f, graw = closure()
+                    g, o6 = vec.grad_stats(graw, sign, None, f, dmax_t)
+                    ls_evals = 1
+                    v = self._read(o6, 3, maxes=(3, 5))
+                    loss, gmax, dmax = float(v[4]), float(v[3]), float(v[5])
+                else:
+                    gmax = math.inf
+                    dmax = float(self._read(dmax_t, 0, maxes=(0,))[0])
+            evals += ls_evals
+            st["func_evals"] += ls_evals
+
+            if n_iter == self.max_iter or evals >= self.max_eval:
+                break
+            if gmax <= tg:
+                break
+            if dmax * abs(t) <= tc:
+                break
+            if abs(loss - prev_loss) < tc:
+                break
+
+        st.update(d=d, t=t, Sb=Sb, Yb=Yb, m=m, SY=SY, YY=YY, H=H, prev_g=prev_g, prev_loss=prev_loss, x0=x0)
+        return torch.as_tensor(orig_loss)
+
+    # ------------------------------------------------------------------ flat mode, vectors on the host
+    def _step_host(self, closure):
+        """One optimiser step over a small flat group with the vectors in host memory (numpy): the evaluation's one
+        transfer brings value and gradient, the new parameters go up with one copy.  torch.optim.LBFGS's own two-loop
+        recursion, operation for operation."""
+        st = self.state[self._params[0]]
+        tg, tc = self.tolerance_grad, self.tolerance_change
+        xdev = self._flat
+        n = xdev.numel()
+        sign = -1.0 if self._maximize else 1.0
+        cuda = xdev.is_cuda
+        if "host" not in st:
+            pin = dict(pin_memory=True) if cuda else {}
+            st["host"] = (torch.empty(n + 1, dtype=xdev.dtype, **pin), torch.empty(n, dtype=xdev.dtype, **pin))
+        rbuf, xbuf = st["host"]
+        pending = [False]
+
+        def evaluate():          # -> (loss, gradient) as (float, fresh array): the ONE synchronisation of an evaluation
+            val, graw = closure()
+            pack = torch.cat([val.detach().reshape(1).to(graw.dtype), graw.detach().reshape(-1)])
+            if cuda:
+                rbuf.copy_(pack, non_blocking=True)
+                torch.cuda.current_stream(xdev.device).synchronize()
+            else:
+                rbuf.copy_(pack)
+            pending[0] = False
+            a = rbuf.numpy()
+            return sign * float(a[0]), sign * a[1:]
+
+        def upload(xnew):
+            if pending[0] and cuda:      # the pinned buffer may still be travelling
+                torch.cuda.current_stream(xdev.device).synchronize()
+            xbuf.numpy()[:] = xnew
+            xdev.copy_(xbuf, non_blocking=True)
+            pending[0] = True
+
+        xcur = xdev.detach().cpu().numpy().astype(np.float64, copy=True)
+        loss, g = evaluate()
+        orig_loss = loss
+        evals = 1
+        st["func_evals"] += 1
+        gmax = float(np.abs(g).max()) if n else 0.0
+        if gmax <= tg:
+            return torch.as_tensor(orig_loss)
+
+        d, t = st.get("d"), st.get("t")
+        old_dirs, old_stps, ro = st.get("old_dirs", []), st.get("old_stps", []), st.get("ro", [])
+        H = st.get("H", 1.0)
+        prev_g, prev_loss = st.get("prev_g"), st.get("prev_loss")
+        n_iter = 0
+        while n_iter < self.max_iter:
+            n_iter += 1
+            st["n_iter"] += 1
+            if st["n_iter"] == 1:
+                d = -g
+                old_dirs, old_stps, ro = [], [], []
+                H = 1.0
+            else:
+                y = g - prev_g
+                s = d * t
+                ys = float(y.dot(s))
+                if ys > 1e-10:
+                    if len(old_dirs) == self.history_size:
+                        old_dirs.pop(0)
+                        old_stps.pop(0)
+                        ro.pop(0)
+                    old_dirs.append(y)
+                    old_stps.append(s)
+                    ro.append(1.0 / ys)
+                    H = ys / float(y.dot(y))
+                k = len(old_dirs)
+                al = [0.0] * k
+                q = -g
+                for i in range(k - 1, -1, -1):
+                    al[i] = float(old_stps[i].dot(q)) * ro[i]
+                    q = q - al[i] * old_dirs[i]
+                d = q * H
+                for i in range(k):
+                    be_i = float(old_dirs[i].dot(d)) * ro[i]
+                    d = d + old_stps[i] * (al[i] - be_i)
+            prev_g = g
+            prev_loss = loss
+            t = min(1.0, 1.0 / float(np.abs(g).sum())) * self.lr if st["n_iter"] == 1 else self.lr
+            gtd = float(g.dot(d))
+            if gtd > -tc:
+                break
+
+            ls_evals = 0
+            dmax = float(np.abs(d).max())
+            if self.line_search_fn == "strong_wolfe":
+                x0 = xcur
+                last = [None]
+
+                def phi(step):
+                    upload(x0 + step * d)
+                    last[0] = step
+                    f, gn = evaluate()
+                    return f, gn, float(gn.dot(d)), float(np.abs(gn).max()), dmax
+                loss, g, t, ls_evals, gmax, dmax = self._strong_wolfe(phi, t, d, loss, g, gtd, gm0=gmax)
+                xcur = x0 + t * d
+                if last[0] != t:
+                    upload(xcur)
+            else:
+                xcur = xcur + t * d
+                upload(xcur)
+                gmax = math.inf
+                if n_iter != self.max_iter:
+                    loss, g = evaluate()
+                    ls_evals = 1
+                    gmax = float(np.abs(g).max())
+            evals += ls_evals
+            st["func_evals"] += ls_evals
+
+            if n_iter == self.max_iter or evals >= self.max_eval:
+                break
+            if gmax <= tg:
+                break
+            if dmax * abs(t) <= tc:
+                break
+            if abs(loss - prev_loss) < tc:
+                break
+
+        if pending[0] and cuda:          # the pinned buffer belongs to this optimiser: leave nothing in flight
+            torch.cuda.current_stream(xdev.device).synchronize()
+        st.update(d=d, t=t, old_dirs=old_dirs, old_stps=old_stps, ro=ro, H=H, prev_g=prev_g, prev_loss=prev_loss)
+        return torch.as_tensor(orig_loss)
+
+    def _strong_wolfe(self, phi, t, d, f, g, gtd, c1=1e-4, c2=0.9, max_ls=25, gm0=None):
         """Bracketing + zoom line search for the strong Wolfe conditions; phi(t) -> (loss, flat grad, grad . d,
-        max |grad|, max |d|).  Returns (loss, grad, step, evaluations, max |grad| at the step, max |d|)."""
+        max |grad|, max |d|); gm0 = max |g| at the starting point when the caller knows it.  Returns (loss, grad, step,
+        evaluations, max |grad| at the step, max |d|)."""
         tc = self.tolerance_change
         f_new, g_new, gtd_new, gm_new, d_norm = phi(t)
         n_eval = 1
-        t_prev, f_prev, g_prev, gtd_prev, gm_prev = 0.0, f, g, gtd, None
+        t_prev, f_prev, g_prev, gtd_prev, gm_prev = 0.0, f, g, gtd, gm0
         done = False
         it = 0
         br = None
@@ -311,7 +712,7 @@ class ShardedLBFGS:
             n_eval += 1
             it += 1
         if br is None:                      # ran out of bracketing iterations
-            br = [[0.0, f, g, gtd, None], [t, f_new, g_new, gtd_new, gm_new]]
+            br = [[0.0, f, g, gtd, gm0], [t, f_new, g_new, gtd_new, gm_new]]
 
         insufficient = False
         lo, hi = (0, 1) if br[0][1] <= br[-1][1] else (1, 0)
@@ -345,5 +746,5 @@ class ShardedLBFGS:
             lo = 0
         t, f_new, g_new, gm = br[lo][0], br[lo][1], br[lo][2], br[lo][4]
         if gm is None:                      # the search fell back to the starting point: its gradient is the caller's g
-            _, (gm,), _ = self._scalars(None, g_new.abs().max().reshape(1))
+            _, (gm,), _ = self._scalars(None, torch.as_tensor(g_new).abs().max().reshape(1))
         return f_new, g_new, t, n_eval, gm, d_norm

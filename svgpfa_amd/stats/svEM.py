@@ -173,13 +173,11 @@ class SVEM_PyTorch:
         flat = model.flatParams(group) if (use_sharded and model is not None and hasattr(model, "flatParams")) else None
         if flat is not None:
             from svgpfa_amd.stats.shardedLBFGS import ShardedLBFGS
-            optimizer = ShardedLBFGS(flat=flat, shared=not per_trial, **optim_params)
-
-            def flat_closure():
-                val, grad = model.evalFlat(group)
-                return -val, -grad                  # minimise the negative bound; the negation is also the copy
+            # maximise the bound: the optimiser takes (value, gradient) as the engine leaves them and changes the sign
+            # on the copy of the gradient it has to keep anyway
+            optimizer = ShardedLBFGS(flat=flat, shared=not per_trial, maximize=True, **optim_params)
             with torch.no_grad():
-                optimizer.step(flat_closure)
+                optimizer.step(lambda: model.evalFlat(group))
             lowerBound = evalFunc()
             state = optimizer.state[optimizer._params[0]]
             return {"lowerBound": lowerBound, "nfeval": state["func_evals"], "niter": state["n_iter"]}
