@@ -30,10 +30,12 @@ __host__ __device__ constexpr int sv_tr_stride(int MP) { return ((MP + 14) / 32)
 
 // LDS of one block (doubles).  The transpose scratch of phase 1 and the Gt / At matrix of phase 2 share one region:
 // at the north-star shape (NT = 2, 2 waves) a block needs 34 KB, so four blocks (8 waves) stay resident per CU.
-__host__ __device__ constexpr size_t sv_item_bwd_lds_doubles(int NT, int NWB) {
+// Above M = 32 the FULL variant keeps D in a buffer of its own (Vt stays staged: a block is alone on its CU there, and a
+// second staging phase is an exposed memory latency).
+__host__ __device__ constexpr size_t sv_item_bwd_lds_doubles(int NT, int NWB, bool full = true) {
   const size_t MP = 16 * NT, LD = MP + 2, L2 = sv_tr_stride(16 * NT);
   const size_t S = (NWB * 16 * L2 > MP * LD) ? NWB * 16 * L2 : MP * LD;
-  return 2 * MP * LD + S + 9 * MP + NWB * 16 + NWB * 2 * MP + NWB * 2 + NT * MP + 2 * NT + 8;
+  return 2 * MP * LD + S + 9 * MP + NWB * 16 + NWB * 2 + NT * MP + 2 * NT + 8 + ((NT >= 3 && full) ? MP * LD : 0);
 }
 
 // ---- phase 3 -------------------------------------------------------------------------------------------------------
@@ -200,7 +202,7 @@ __device__ void item_bwd_body(const EngineView& ev, const int r, const int k, co
   const int M = m.M, Q = ev.Q, K = ev.K;
   const size_t SZ = ((size_t)NWB * 16 * L2S > (size_t)MP * LD) ? (size_t)NWB * 16 * L2S : (size_t)MP * LD;
   double* Li = sm;                    // MP*LD  Linv
-  double* Vl = Li + MP * LD;          // MP*LD  phase 1 (FULL): D = Linv^T (Vt Vt^T - I); phase 2: Vt, later C
+  double* Vl = Li + MP * LD;          // MP*LD  Vt (M <= 32, FULL: D = Linv^T (Vt Vt^T - I) during phase 1); later C
   double* S = Vl + MP * LD;           // SZ     phase 1: per-wave transpose scratch; then Gt summed over the waves
   double* Gl = S;                     //        (symmetric, rows padded to LD: phase 2's Gt, later At)
   double* ul = S + SZ;                // MP     ut
@@ -213,11 +215,12 @@ __device__ void item_bwd_body(const EngineView& ev, const int r, const int k, co
   double* szl = gzq + MP;             // MP     sin of the inducing-point phases (periodic)
   double* czl = szl + MP;             // MP     cos
   double* gvs = czl + MP;             // NWB*16
-  double* vred = gvs + NWB * 16;      // NWB*2*MP  gu / dz partials per wave
-  double* tred = vred + NWB * 2 * MP; // NWB*2
+  double* tred = gvs + NWB * 16;      // NWB*2
   double* redz = tred + NWB * 2;      // NT*MP  per-panel row sums of the dZ contraction
   double* redt = redz + NT * MP;      // NT*2   per-panel dtheta partials
   double* thq = redt + 2 * NT;        // 2      quadrature part of dtheta (direct)
+  constexpr bool DSEP = NT >= 3 && FULL;   // D in its own buffer
+  double* Dl = DSEP ? thq + 8 : Vl;   // MP*LD  D
   const KPar p = make_kpar(m, ev.theta + 2 * k);
   const long long base = m.offMM + (long long)r * M * M;
   const long long vbase = m.offM + (long long)r * M;
@@ -226,7 +229,7 @@ __device__ void item_bwd_body(const EngineView& ev, const int r, const int k, co
 
   if (want_lat) {
     // ================================================================= phase 1: quadrature adjoints
-    load_factors<NT>(ev, m, r, Li, Vl, ul, zl, FULL);
+    load_factors<NT>(ev, m, r, Li, Vl, ul, zl, true);
     if (tid < MP) al[tid] = (tid < M) ? ev.a[vbase + tid] : 0.0;
     __syncthreads();
     if (KT == SV_PERIODIC && tid < MP) sv_sincos_quarter(zl[tid] * p.q4, szl[tid], czl[tid]);
@@ -249,13 +252,13 @@ __device__ void item_bwd_body(const EngineView& ev, const int r, const int k, co
             if (16 * a + 4 * q + lg == 16 * c + li) VV[a][q] -= 1.0;
         tri_chain<NT, 1>(Dp, Li, LD, VV, li, lg);
       }
-      __syncthreads();                                                   // every wave is done reading Vt
+      if (!DSEP) __syncthreads();                                        // every wave is done reading Vt
       if (wave < NT) {
         const int c = wave;
 #pragma unroll
         for (int a = 0; a < NT; ++a)
 #pragma unroll
-          for (int q = 0; q < 4; ++q) Vl[(16 * a + 4 * q + lg) * LD + 16 * c + li] = Dp[a][q];
+          for (int q = 0; q < 4; ++q) Dl[(16 * a + 4 * q + lg) * LD + 16 * c + li] = Dp[a][q];
       }
     }
     __syncthreads();
@@ -336,7 +339,7 @@ __device__ void item_bwd_body(const EngineView& ev, const int r, const int k, co
           for (int b = 0; b < NT; ++b)
 #pragma unroll
             for (int q = 0; q < 4; ++q)
-              acc = __builtin_amdgcn_mfma_f64_16x16x4f64(Vl[(16 * a + li) * LD + 16 * b + 4 * q + lg], Kw[b][q], acc, 0, 0, 0);
+              acc = __builtin_amdgcn_mfma_f64_16x16x4f64(Dl[(16 * a + li) * LD + 16 * b + 4 * q + lg], Kw[b][q], acc, 0, 0, 0);
           Gk[a] = acc;                                            // D kt
         }
 #pragma unroll
@@ -399,9 +402,9 @@ __device__ void item_bwd_body(const EngineView& ev, const int r, const int k, co
       for (int q = 0; q < 4; ++q) {
         double g = row16_sum(gu[a][q]);
         double z = FULL ? row16_sum(dz[a][q]) : 0.0;
-        if (li == 0) {
-          vred[(wave * 2 + 0) * MP + 16 * a + 4 * q + lg] = g;
-          vred[(wave * 2 + 1) * MP + 16 * a + 4 * q + lg] = z;
+        if (li == 0) {               // per-wave partials of gu / dz: in the wave's own transpose scratch, now idle
+          Sw[16 * a + 4 * q + lg] = g;
+          Sw[MP + 16 * a + 4 * q + lg] = z;
         }
       }
     th0 = wave_sum(th0);
@@ -410,35 +413,15 @@ __device__ void item_bwd_body(const EngineView& ev, const int r, const int k, co
       tred[wave * 2 + 0] = th0;
       tred[wave * 2 + 1] = th1;
     }
-    __syncthreads();   // all waves done with their scratch (and with D): the region becomes Gt, summed over the waves in
-                       // order, both triangles (tile (a, b), a > b, is mirrored into (b, a)), rows padded to LD
-    for (int w = 0; w < NWB; ++w) {
-      if (wave == w) {
-        int t = 0;
-#pragma unroll
-        for (int a = 0; a < NT; ++a)
-#pragma unroll
-          for (int b = 0; b <= a; ++b) {
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-              const int row = 16 * a + lg + 4 * q, col = 16 * b + li;
-              const double v = (w == 0) ? GW[t][q] : Gl[row * LD + col] + GW[t][q];
-              Gl[row * LD + col] = v;
-              if (a != b) Gl[col * LD + row] = v;
-            }
-            ++t;
-          }
-      }
-      __syncthreads();
-    }
-    if (tid < MP) {
+    __syncthreads();   // all waves done with their tiles (and with D)
+    if (tid < MP) {    // gu / dz: the waves' partials, in order (read before Gt takes the scratch region over)
       double g = 0.0, z = 0.0;
       if (tid < M) {
-        g = vred[tid];
-        for (int w = 1; w < NWB; ++w) g += vred[(2 * w) * MP + tid];
+        g = S[tid];
+        for (int w = 1; w < NWB; ++w) g += S[w * 16 * L2S + tid];
         if (FULL) {
-          z = vred[MP + tid];
-          for (int w = 1; w < NWB; ++w) z += vred[(2 * w + 1) * MP + tid];
+          z = S[MP + tid];
+          for (int w = 1; w < NWB; ++w) z += S[w * 16 * L2S + MP + tid];
           z *= p.cz;
         }
       }
@@ -458,9 +441,30 @@ __device__ void item_bwd_body(const EngineView& ev, const int r, const int k, co
       thq[0] = p.c0 * t0s;
       thq[1] = p.c1 * t1s;
     }
-    // stage Vt (phase 2 needs it; in the FULL variant the buffer held D).  Gt's padding rows / columns are exact zeros:
-    // they are sums of products with zero-padded rows of Linv
-    stage_matrix<NT>(Vl, ev.Vt + base, M, tid, NTHB);
+    __syncthreads();   // the scratch region becomes Gt, summed over the waves in order, both triangles (tile (a, b), a > b,
+                       // is mirrored into (b, a)), rows padded to LD
+    for (int w = 0; w < NWB; ++w) {
+      if (wave == w) {
+        int t = 0;
+#pragma unroll
+        for (int a = 0; a < NT; ++a)
+#pragma unroll
+          for (int b = 0; b <= a; ++b) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+              const int row = 16 * a + lg + 4 * q, col = 16 * b + li;
+              const double v = (w == 0) ? GW[t][q] : Gl[row * LD + col] + GW[t][q];
+              Gl[row * LD + col] = v;
+              if (a != b) Gl[col * LD + row] = v;
+            }
+            ++t;
+          }
+      }
+      __syncthreads();
+    }
+    // Vt for phase 2: staged again only where D took its buffer.  Gt's padding rows / columns are exact zeros: they are
+    // sums of products with zero-padded rows of Linv
+    if (FULL && !DSEP) stage_matrix<NT>(Vl, ev.Vt + base, M, tid, NTHB);
   } else {
     if (tid < MP) {
       ul[tid] = 0.0;
@@ -482,18 +486,25 @@ __device__ void item_bwd_body(const EngineView& ev, const int r, const int k, co
   const int c0 = ev.chunk_first[r], c1 = (mask & SV_MASK_STATS) ? c0 : ev.chunk_first[r + 1];
   if (tid < M) {
     double p0 = 0.0;
-    for (int ch = c0; ch < c1; ch += 8) {          // 8 chunks per step (a cfg3 trial has 8): 16 independent loads in
-      double v[8], w[8];                            // flight, fixed order
+    // 8 chunks per step (a cfg3 trial has 8): 16 independent loads in flight, fixed order of the additions
+    constexpr int GB = 8;
+    for (int ch = c0; ch < c1; ch += GB) {
+      double v[GB], w[GB];
 #pragma unroll
-      for (int u = 0; u < 8; ++u) {
+      for (int u = 0; u < GB; ++u) {
         const bool in = ch + u < c1;
         const long long o = (long long)(in ? ch + u : ch) * ev.sumM + m.colM + tid;
         v[u] = ev.P0[o];
         w[u] = want_zt ? ev.P1[o] : 0.0;
         if (!in) { v[u] = 0.0; w[u] = 0.0; }
       }
-      p0 += ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
-      p1sum += ((w[0] + w[1]) + (w[2] + w[3])) + ((w[4] + w[5]) + (w[6] + w[7]));
+#pragma unroll
+      for (int h = 0; h < GB; h += 8) {
+        if (h == 0 || ch + h < c1) {
+          p0 += ((v[h] + v[h + 1]) + (v[h + 2] + v[h + 3])) + ((v[h + 4] + v[h + 5]) + (v[h + 6] + v[h + 7]));
+          p1sum += ((w[h] + w[h + 1]) + (w[h + 2] + w[h + 3])) + ((w[h + 4] + w[h + 5]) + (w[h + 6] + w[h + 7]));
+        }
+      }
     }
     a_l = al[tid];
     const double gsp = p.s2 * p0;
@@ -702,6 +713,9 @@ __device__ void item_bwd_body(const EngineView& ev, const int r, const int k, co
 }
 
 // grid = R*K blocks of 64 NWB threads (NWB = 2 or 4 >= NT); FULL = gradients wrt Z / theta wanted (mask & 12).
+// M > 32 (cfg5): one block per CU (115 / 151 KB of LDS), one wave per SIMD.  Eight waves per block were measured for the
+// value-only variant (it fits 256 registers): no gain -- 13 node tiles give the busiest SIMD four tiles either way, and the
+// item's serial sections (staging, cross-wave sums) overlap with nothing while a block is alone on its CU.
 template <int NT, bool FULL>
 __global__ __launch_bounds__(256, (NT <= 2 ? 2 : 1)) void k_item_bwd(EngineView ev, LatentPtrTable ptab, unsigned mask,
                                                                      const double* C, const double* d, double* shared) {

@@ -52,20 +52,21 @@ __device__ __forceinline__ double grp4_sum(double x) {    // sum over the 4 lane
 }
 
 // Stage one M x M matrix of the item (row-major, leading dimension M) into LDS, zero padded to MP x MP with rows padded to
-// LD.  Four independent global loads per thread are in flight before the first LDS store (a plain element loop waits
+// LD.  U independent global loads per thread are in flight before the first LDS store (a plain element loop waits
 // for every load before its store: the staging of a 32 x 32 matrix by 128 threads was eight exposed memory latencies).
-template <int NT>
+// (U = 8 at M = 64 measured: k_item_bwd<4> 12.5 -> 14.0 ms at cfg5 -- the registers it takes cost more than the latency.)
+template <int NT, int U = 4>
 __device__ __forceinline__ void stage_matrix(double* dst, const double* src, int M, int tid, int nth) {
   constexpr int MP = 16 * NT, LD = MP + 2;
-  for (int e0 = tid; e0 < MP * MP; e0 += 4 * nth) {
-    double v[4];
+  for (int e0 = tid; e0 < MP * MP; e0 += U * nth) {
+    double v[U];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
+    for (int u = 0; u < U; ++u) {
       const int e = e0 + u * nth, i = e / MP, j = e % MP;
       v[u] = (e < MP * MP && i < M && j < M) ? src[i * M + j] : 0.0;
     }
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
+    for (int u = 0; u < U; ++u) {
       const int e = e0 + u * nth, i = e / MP, j = e % MP;
       if (e < MP * MP) dst[i * LD + j] = v[u];
     }

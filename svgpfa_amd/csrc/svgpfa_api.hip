@@ -32,8 +32,9 @@ struct svgpfa_engine {
   int ell_parts = 0, KKT = 1;  // ell_parts > 0: MFMA GEMM form of the quadrature term
   int ell_lc[2] = {0, 0};      // looped tiles resident in LDS per role (fewer than all: streamed in chunks)
   int ell_nw = 4;              // waves per block of the ELL kernels
-  int tile_nw = 4;             // waves per block of k_item_bwd: 2 when R K >= 2048 and M <= 32 (13 tiles of Q = 200 split
-                               // 7 + 6 instead of 4 + 3 + 3 + 3: 226 -> 203 us on cfg3), else 4 (shorter per-block latency).
+  int tile_nw = 4;             // waves per block of k_item_bwd: 2 when R K >= 512 and M <= 32 (13 tiles of Q = 200 split
+                               // 7 + 6 instead of 4 + 3 + 3 + 3, and four blocks instead of two per CU: cfg3 226 -> 203 us,
+                               // its 8-way shard 0.200 -> 0.186 ms per step), else 4 (shorter per-block latency).
                                // k_times_fwd stays at 4 (2 measured slower: 107 vs 101 us)
   long long totM = 0, totMM = 0;  // R*sum M, R*sum M^2
   bool have_quad = false, have_spikes = false, have_kernels = false, have_stats = false;
@@ -99,7 +100,7 @@ static size_t lds_times_mfma(int NT) {
   size_t MP = 16 * NT, LD = MP + 2;
   return (2 * MP * LD + 4 * MP) * 8;
 }
-static size_t lds_item_bwd(int NT, int NWB = 4) { return sv_item_bwd_lds_doubles(NT, NWB) * 8; }
+static size_t lds_item_bwd(int NT, int NWB, bool full) { return sv_item_bwd_lds_doubles(NT, NWB, full) * 8; }
 #define DISPATCH_NT(nt, ...)                                 \
   switch (nt) {                                              \
     case 1: { constexpr int NT_ = 1; __VA_ARGS__; } break;   \
@@ -216,7 +217,7 @@ int svgpfa_create(const svgpfa_dims* d, int device, svgpfa_engine** out) {
   // but at ~165 VGPRs only 12 waves fit a CU, i.e. ONE such block instead of three: measured 152 us vs 128 us.
   e->ell_nw = 4;
   if (getenv("SVGPFA_ELL_NW")) e->ell_nw = std::min(8, std::max(1, atoi(getenv("SVGPFA_ELL_NW"))));
-  e->tile_nw = ((long long)v.R * v.K >= 2048 && e->NT <= 2) ? 2 : 4;
+  e->tile_nw = ((long long)v.R * v.K >= 512 && e->NT <= 2) ? 2 : 4;
   if (getenv("SVGPFA_TILE_NW")) e->tile_nw = atoi(getenv("SVGPFA_TILE_NW")) == 2 && e->NT <= 2 ? 2 : 4;
   e->ell_lc[0] = qell_chunk(e, 0);
   e->ell_lc[1] = qell_chunk(e, 1);
@@ -247,8 +248,8 @@ int svgpfa_create(const svgpfa_dims* d, int device, svgpfa_engine** out) {
   int rc = 0;
   DISPATCH_NT(e->NT, rc = allow_lds(e, (k_prep_mfma<NT_>), lds_prep_mfma(NT_));
               if (!rc) rc = allow_lds(e, (k_times_fwd_mfma<NT_>), lds_times_mfma(NT_));
-              if (!rc) rc = allow_lds(e, (k_item_bwd<NT_, true>), lds_item_bwd(NT_));
-              if (!rc) rc = allow_lds(e, (k_item_bwd<NT_, false>), lds_item_bwd(NT_)));
+              if (!rc) rc = allow_lds(e, (k_item_bwd<NT_, true>), lds_item_bwd(NT_, 4, true));
+              if (!rc) rc = allow_lds(e, (k_item_bwd<NT_, false>), lds_item_bwd(NT_, 4, false)));
   if (rc) return rc;
   if (e->precision == SVGPFA_PRECISION_MIXED) {
     DISPATCH_KS(e->KKT, rc = allow_lds(e, (k_quad_ell_mfma<KS_, 0, float>), lds_qell_mfma(e, 0));
@@ -650,10 +651,10 @@ int svgpfa_elbo(svgpfa_engine* e, const double* const* mean, const double* const
   std::pair<hipEvent_t, hipEvent_t>* evb = timing_begin(e, 1, sm);
   if (mask & (4u | 8u)) {
     DISPATCH_NT(e->NT, hipLaunchKernelGGL((k_item_bwd<NT_, true>), dim3(v.R * v.K), dim3(64 * e->tile_nw),
-                                          lds_item_bwd(NT_, e->tile_nw), sm, v, pt, mask, C, d, shared));
+                                          lds_item_bwd(NT_, e->tile_nw, true), sm, v, pt, mask, C, d, shared));
   } else {
     DISPATCH_NT(e->NT, hipLaunchKernelGGL((k_item_bwd<NT_, false>), dim3(v.R * v.K), dim3(64 * e->tile_nw),
-                                          lds_item_bwd(NT_, e->tile_nw), sm, v, pt, mask, C, d, shared));
+                                          lds_item_bwd(NT_, e->tile_nw, false), sm, v, pt, mask, C, d, shared));
   }
   if (evb) HIPCHK(e, hipEventRecord(evb->second, sm));
   hipLaunchKernelGGL(k_fin_items, dim3(v.nth_total + SV_FIN_NS), dim3(256), 0, sm, v, mask, shared);
@@ -732,11 +733,11 @@ int svgpfa_latent_stats_backward(svgpfa_engine* e, const double* const* mean, co
   const unsigned m2 = mask | SV_MASK_STATS;
   if (mask & (4u | 8u)) {
     DISPATCH_NT(e->NT, hipLaunchKernelGGL((k_item_bwd<NT_, true>), dim3(v.R * v.K), dim3(64 * e->tile_nw),
-                                          lds_item_bwd(NT_, e->tile_nw), e->stream, v, pt, m2, (const double*)nullptr,
+                                          lds_item_bwd(NT_, e->tile_nw, true), e->stream, v, pt, m2, (const double*)nullptr,
                                           (const double*)nullptr, shared));
   } else {
     DISPATCH_NT(e->NT, hipLaunchKernelGGL((k_item_bwd<NT_, false>), dim3(v.R * v.K), dim3(64 * e->tile_nw),
-                                          lds_item_bwd(NT_, e->tile_nw), e->stream, v, pt, m2, (const double*)nullptr,
+                                          lds_item_bwd(NT_, e->tile_nw, false), e->stream, v, pt, m2, (const double*)nullptr,
                                           (const double*)nullptr, shared));
   }
   hipLaunchKernelGGL(k_fin_items, dim3(v.nth_total + SV_FIN_NS), dim3(256), 0, e->stream, v, m2, shared);
