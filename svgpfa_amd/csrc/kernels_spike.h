@@ -243,10 +243,14 @@ struct SeriesPar {
   const double* e;     // P1 weights
 };
 
-template <int KT, bool FULL, int SPL>
+// WC = false (only with FULL): the caller wants no embedding gradient (kernel-parameter / inducing-point closures of the
+// EM loop): the posterior mean at the spikes and its per-neuron sums are left out -- the projections Abar / Bbar, two of
+// the 8..10 operations per (spike, harmonic) and the segmented emit.
+template <int KT, bool FULL, int SPL, bool WC = true>
 __device__ void spike_body_series(const EngineView& ev, const double* __restrict__ C, int ch, int k, double* red,
                                   const SeriesPar sp) {
   constexpr bool TW = FULL && KT == SV_PERIODIC;      // time-weighted moments (period gradient)
+  constexpr bool MU = FULL && WC;                     // posterior mean at the spikes -> dC
   constexpr int ROWS = FULL ? 16 : 8;                 // LDS reduction rows per group (value-only: half the LDS, more waves)
   constexpr int NV = TW ? 4 : 2, JG = ROWS / NV;
   const int lane = threadIdx.x, H = sp.H;
@@ -260,7 +264,7 @@ __device__ void spike_body_series(const EngineView& ev, const double* __restrict
   double* Fs = red + ROWS * 65;                  // [SV_FH + 1][NV] moments of the chunk
   double* AB = Fs + (SV_FH + 1) * 4;             // [SV_FH + 1][2] c_n Abar_n, c_n Bbar_n   (FULL)
 
-  double cw[SPL], tw[TW ? SPL : 1], c1[SPL], s1[SPL], cn[SPL], sn[SPL], mu[FULL ? SPL : 1];
+  double cw[SPL], tw[TW ? SPL : 1], c1[SPL], s1[SPL], cn[SPL], sn[SPL], mu[MU ? SPL : 1];
 #pragma unroll
   for (int i = 0; i < SPL; ++i) {
     const int idx = lane * SPL + i;              // lane owns SPL consecutive spikes
@@ -272,7 +276,7 @@ __device__ void spike_body_series(const EngineView& ev, const double* __restrict
     sv_sincos_quarter((t - sp.t0) * sc, s1[i], c1[i]);
     cn[i] = 1.0;
     sn[i] = 0.0;
-    if constexpr (FULL) mu[i] = 0.0;
+    if constexpr (MU) mu[i] = 0.0;
   }
   double zj = 0.0, aj = 0.0, sphi = 0.0, cphi = 1.0;
   if (lane < M) {
@@ -293,7 +297,7 @@ __device__ void spike_body_series(const EngineView& ev, const double* __restrict
     sum += __shfl_xor(sum, 32, 64);
     return sum;
   };
-  if constexpr (FULL) {
+  if constexpr (MU) {
     // Abar_n, Bbar_n (times c_n): the posterior-mean weights a_j projected on the harmonics of the inducing points
     double cj = 1.0, sj = 0.0;
     for (int nb = 0; nb <= H; nb += 8) {
@@ -320,7 +324,7 @@ __device__ void spike_body_series(const EngineView& ev, const double* __restrict
       double sa = 0.0, sb = 0.0, sat = 0.0, sbt = 0.0;
       if (n <= H) {
         double cA = 0.0, cB = 0.0;
-        if constexpr (FULL) {
+        if constexpr (MU) {
           cA = AB[2 * n];
           cB = AB[2 * n + 1];
         }
@@ -332,7 +336,7 @@ __device__ void spike_body_series(const EngineView& ev, const double* __restrict
             sat = fma(tw[i], cn[i], sat);
             sbt = fma(tw[i], sn[i], sbt);
           }
-          if constexpr (FULL) mu[i] = fma(cn[i], cA, fma(sn[i], cB, mu[i]));
+          if constexpr (MU) mu[i] = fma(cn[i], cA, fma(sn[i], cB, mu[i]));
           const double tq = cn[i] * c1[i] - sn[i] * s1[i];     // (cos, sin) of (n + 1) theta: rotation by theta
           sn[i] = fma(sn[i], c1[i], cn[i] * s1[i]);
           cn[i] = tq;
@@ -383,6 +387,8 @@ __device__ void spike_body_series(const EngineView& ev, const double* __restrict
       ev.Tpart[((long long)ch * K + k) * 2 + 0] = t0;
       ev.Tpart[((long long)ch * K + k) * 2 + 1] = t1;
     }
+  }
+  if constexpr (MU) {
     // spike part of dC[n, k]: per-neuron sums of mu_s
     int nid[SPL];
 #pragma unroll
@@ -444,7 +450,7 @@ __device__ __forceinline__ int rbf_series_setup(const EngineView& ev, const Late
   return H;
 }
 
-template <int KT, bool FULL, int SPL, typename T>
+template <int KT, bool FULL, int SPL, typename T, bool WC = true>
 __device__ void spike_body(const EngineView& ev, const double* __restrict__ C, int ch, int k,
                            double* red_d) {
   {   // the kernel through its cosine series where that is short enough.  The series bodies are fp64 in both precision
@@ -456,7 +462,7 @@ __device__ void spike_body(const EngineView& ev, const double* __restrict__ C, i
       if (H >= 0) {
         const double* tab = ev.four + (size_t)k * SV_FROWS * NF;
         const KPar p = make_kpar(ev.meta[k], ev.theta + 2 * k);
-        spike_body_series<SV_PERIODIC, FULL, SPL>(ev, C, ch, k, red_d,
+        spike_body_series<SV_PERIODIC, FULL, SPL, WC>(ev, C, ch, k, red_d,
                                                   SeriesPar{H, 4.0 * p.ip, 0.0, tab, tab + NF, tab + 2 * NF});
         return;
       }
@@ -467,7 +473,7 @@ __device__ void spike_body(const EngineView& ev, const double* __restrict__ C, i
       double sc, t0;
       const int H = rbf_series_setup(ev, ms, p, ev.chunks[ch].trial, cf, sc, t0);
       if (H >= 0) {
-        spike_body_series<SV_RBF, FULL, SPL>(ev, C, ch, k, red_d,
+        spike_body_series<SV_RBF, FULL, SPL, WC>(ev, C, ch, k, red_d,
                                              SeriesPar{H, sc, t0, cf, cf + (SV_FH + 1), cf + 2 * (SV_FH + 1)});
         return;
       }
@@ -641,7 +647,8 @@ __device__ void spike_body(const EngineView& ev, const double* __restrict__ C, i
 // One launch over all (chunk, latent) work items; the covariance type is resolved per block.  Longest jobs first: all
 // periodic items, then the RBF ones, so that the tail of the grid is filled with the shorter work items (a small shard
 // is only 2-3 occupancy rounds long).  Registers are capped so that 3 waves / SIMD stay resident.
-template <bool FULL, int SPL, typename T = double>
+// WC = false: no embedding gradient wanted (series bodies skip the spike means; the pair-loop fallbacks compute them anyway).
+template <bool FULL, int SPL, typename T = double, bool WC = true>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 8))) void k_spike(EngineView ev,
                                                                                          const double* __restrict__ C) {
   // LDS bounds the waves per CU: RBF full 3 x 8 rows + 4 x 64 (14.5 KB in fp64), periodic full 5 x 4 rows + ~7 x 64 (14 KB),
@@ -655,10 +662,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 8))) void
   const int nper = ev.ntype[SV_PERIODIC], nrbf = ev.ntype[SV_RBF];
   const int nb_per = ev.nchunks * nper;
   if (item < nb_per) {
-    spike_body<SV_PERIODIC, FULL, SPL, T>(ev, C, item / nper, ev.klist[SV_PERIODIC][item % nper], red);
+    spike_body<SV_PERIODIC, FULL, SPL, T, WC>(ev, C, item / nper, ev.klist[SV_PERIODIC][item % nper], red);
   } else {
     const int it = item - nb_per;
-    spike_body<SV_RBF, FULL, SPL, T>(ev, C, it / nrbf, ev.klist[SV_RBF][it % nrbf], red);
+    spike_body<SV_RBF, FULL, SPL, T, WC>(ev, C, it / nrbf, ev.klist[SV_RBF][it % nrbf], red);
   }
 }
 

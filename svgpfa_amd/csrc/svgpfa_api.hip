@@ -630,14 +630,17 @@ int svgpfa_elbo(svgpfa_engine* e, const double* const* mean, const double* const
         if (full) hipLaunchKernelGGL((k_spike<true, 16, float>), gs, bs, 0, sk, v, C);
         else hipLaunchKernelGGL((k_spike<false, 16, float>), gs, bs, 0, sk, v, C);
       } else {
-        if (full) hipLaunchKernelGGL((k_spike<true, 8, float>), gs, bs, 0, sk, v, C);
+        if (full && !(mask & 2u)) hipLaunchKernelGGL((k_spike<true, 8, float, false>), gs, bs, 0, sk, v, C);
+        else if (full) hipLaunchKernelGGL((k_spike<true, 8, float>), gs, bs, 0, sk, v, C);
         else hipLaunchKernelGGL((k_spike<false, 8, float>), gs, bs, 0, sk, v, C);
       }
     } else if (e->spl == 4) {
       if (full) hipLaunchKernelGGL((k_spike<true, 4>), gs, bs, 0, sk, v, C);
       else hipLaunchKernelGGL((k_spike<false, 4>), gs, bs, 0, sk, v, C);
     } else {
-      if (full) hipLaunchKernelGGL((k_spike<true, 8>), gs, bs, 0, sk, v, C);
+      // kernel-parameter / inducing-point closures (no embedding gradient): the series bodies skip the spike means
+      if (full && !(mask & 2u)) hipLaunchKernelGGL((k_spike<true, 8, double, false>), gs, bs, 0, sk, v, C);
+      else if (full) hipLaunchKernelGGL((k_spike<true, 8>), gs, bs, 0, sk, v, C);
       else hipLaunchKernelGGL((k_spike<false, 8>), gs, bs, 0, sk, v, C);
     }
     if (evp) HIPCHK(e, hipEventRecord(evp->second, sk));
