@@ -259,7 +259,10 @@ def measured_traffic(config, variant, full_mask, prefix="k_spike<"):
         tot, n = 0.0, 0     # the spike pass of one evaluation = the k_spike launches of all covariance types
         insts = 0.0
         for k, e in d.get("kernels", {}).items():
-            if k.startswith(prefix) and (("true" in k) == bool(full_mask)) \
+            # the FULL template argument: first of k_spike<FULL, SPL, T, WC>, second of k_item_bwd<NT, FULL>
+            targs = [a.strip() for a in k[k.find("<") + 1:k.rfind(">")].split(",")] if "<" in k else []
+            full_arg = targs[1 if prefix.startswith("k_item_bwd") else 0] if len(targs) > 1 else ""
+            if k.startswith(prefix) and ((full_arg == "true") == bool(full_mask)) \
                     and "hbm_read_bytes_raw" in e and "hbm_write_bytes" in e:
                 tot += e["hbm_read_bytes_raw"] + e["hbm_write_bytes"]
                 insts += e.get("SQ_INSTS_VALU", 0.0)
