@@ -16,7 +16,13 @@ optim = {"em_max_iter": iters}
 for name in ("estep", "mstep_embedding", "mstep_kernels", "mstep_indpointslocs"):
     optim[f"{name}_estimate"] = True
     optim[f"{name}_optim_params"] = dict(step)
-for which in ("torch", "sharded"):
+for which in ("warm-up", "torch", "sharded"):
+    if which == "warm-up":      # first use of every code path in this process (module loads, allocator growth): not timed
+        for w in ("torch", "sharded"):
+            SVEM_PyTorch(optimizer=w).maximize(model=build_model(prob), optim_params=dict(optim, em_max_iter=1), method="ECM",
+                                               out=io.StringIO(), verbose=False)
+        torch.cuda.synchronize()
+        continue
     t0 = time.time()
     model = build_model(prob)
     t_setup = time.time() - t0
