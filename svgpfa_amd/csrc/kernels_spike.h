@@ -644,9 +644,8 @@ __device__ void spike_body(const EngineView& ev, const double* __restrict__ C, i
   }
 }
 
-// One launch over all (chunk, latent) work items; the covariance type is resolved per block.  Longest jobs first: all
-// periodic items, then the RBF ones, so that the tail of the grid is filled with the shorter work items (a small shard
-// is only 2-3 occupancy rounds long).  Registers are capped so that 3 waves / SIMD stay resident.
+// One launch over all (chunk, latent) work items; the covariance type is resolved per block.  Registers are capped so
+// that 3 waves / SIMD stay resident.
 // WC = false: no embedding gradient wanted (series bodies skip the spike means; the pair-loop fallbacks compute them anyway).
 template <bool FULL, int SPL, typename T = double, bool WC = true>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 8))) void k_spike(EngineView ev,
@@ -658,14 +657,18 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 8))) void
   constexpr int LDS_FULL = LDS_RBF > LDS_PER ? (LDS_RBF > LDS_SER ? LDS_RBF : LDS_SER) : (LDS_PER > LDS_SER ? LDS_PER : LDS_SER);
   constexpr int LDS_VAL = SV_SPIKE_JG * 65 + 4 * 64 > LDS_SER ? SV_SPIKE_JG * 65 + 4 * 64 : LDS_SER;
   __shared__ double red[FULL ? LDS_FULL : LDS_VAL];
-  const int item = blockIdx.x;
-  const int nper = ev.ntype[SV_PERIODIC], nrbf = ev.ntype[SV_RBF];
-  const int nb_per = ev.nchunks * nper;
-  if (item < nb_per) {
-    spike_body<SV_PERIODIC, FULL, SPL, T, WC>(ev, C, item / nper, ev.klist[SV_PERIODIC][item % nper], red);
+  // Work item = (chunk, latent).  Blocks b and b + 8 share an XCD (and its L2) under the dispatcher's round-robin
+  // placement -- a speed assumption only -- so the grid is re-indexed such that the blocks of one XCD walk a contiguous
+  // range of chunk-major items: the K blocks that read the same chunk's spike times / neuron ids run on one XCD, back to
+  // back, and all but the first find them in its L2 (the item starts with a chain of dependent global loads).
+  const int nper = ev.ntype[SV_PERIODIC], nrbf = ev.ntype[SV_RBF], nlat = nper + nrbf;
+  const int nb = gridDim.x, b = blockIdx.x, x = b & 7, q = nb >> 3, rem = nb & 7;
+  const int item = ((x < rem) ? x * (q + 1) : rem * (q + 1) + (x - rem) * q) + (b >> 3);   // bijective for any nb
+  const int ch = item / nlat, slot = item % nlat;
+  if (slot < nper) {
+    spike_body<SV_PERIODIC, FULL, SPL, T, WC>(ev, C, ch, ev.klist[SV_PERIODIC][slot], red);
   } else {
-    const int it = item - nb_per;
-    spike_body<SV_RBF, FULL, SPL, T, WC>(ev, C, it / nrbf, ev.klist[SV_RBF][it % nrbf], red);
+    spike_body<SV_RBF, FULL, SPL, T, WC>(ev, C, ch, ev.klist[SV_RBF][slot - nper], red);
   }
 }
 
