@@ -231,10 +231,17 @@ class SVLowerBound:
         for r in range(R):
             if len(measurements[r]) != N:
                 raise ValueError("every trial must list the same number of neurons")
-            arrs = [np.asarray(x.detach().cpu() if isinstance(x, torch.Tensor) else x, dtype=np.float64).reshape(-1)
-                    for x in measurements[r]]
-            lens = np.fromiter((a.size for a in arrs), dtype=np.int64, count=N)
-            times.append(np.concatenate(arrs) if N else np.zeros(0))
+            row = measurements[r]
+            if N and all(isinstance(x, torch.Tensor) for x in row):
+                # the reference's format (a tensor per neuron): one concatenation per trial instead of one host
+                # conversion per (trial, neuron) -- 100 000 of them at the north-star size
+                lens = np.fromiter((x.numel() for x in row), dtype=np.int64, count=N)
+                times.append(torch.cat([x.detach().reshape(-1) for x in row]).to(device="cpu", dtype=torch.float64).numpy())
+            else:
+                arrs = [np.asarray(x.detach().cpu() if isinstance(x, torch.Tensor) else x, dtype=np.float64).reshape(-1)
+                        for x in row]
+                lens = np.fromiter((a.size for a in arrs), dtype=np.int64, count=N)
+                times.append(np.concatenate(arrs) if N else np.zeros(0))
             neuron.append(np.repeat(np.arange(N, dtype=np.int32), lens))
             offsets[r + 1] = offsets[r] + int(lens.sum())
         self._R_data, self._N = R, N
