@@ -35,7 +35,7 @@ __host__ __device__ constexpr int sv_tr_stride(int MP) { return ((MP + 14) / 32)
 __host__ __device__ constexpr size_t sv_item_bwd_lds_doubles(int NT, int NWB, bool full = true) {
   const size_t MP = 16 * NT, LD = MP + 2, L2 = sv_tr_stride(16 * NT);
   const size_t S = (NWB * 16 * L2 > MP * LD) ? NWB * 16 * L2 : MP * LD;
-  return 2 * MP * LD + S + 9 * MP + NWB * 16 + NWB * 2 + NT * MP + 2 * NT + 8 + ((NT >= 3 && full) ? MP * LD : 0);
+  return 2 * MP * LD + S + 11 * MP + NWB * 16 + NWB * 2 + NT * MP + 2 * NT + 16 + ((NT >= 3 && full) ? MP * LD : 0);
 }
 
 // ---- phase 3 -------------------------------------------------------------------------------------------------------
@@ -189,6 +189,56 @@ __global__ __launch_bounds__(256) void k_fin_items(EngineView ev, unsigned mask,
   }
 }
 
+// Inputs of phase 2 that are complete when the kernel starts: the spike partial sums of the trial (fixed chunk order;
+// thread j < M owns inducing point j) -> gs = s2 P0, p1l = P1; the trial's spike-direct theta partials -> tpl; 1 / diag(L_S)
+// -> cvd.  Statistics mode: the spike term arrives through the segment-1 adjoints, there is nothing to gather.
+template <int MP>
+__device__ __forceinline__ void gather_item_inputs(const EngineView& ev, const LatentMeta& m, const LatentPtrs& pt, int r,
+                                                   int k, unsigned mask, bool want_zt, double s2, double* gs, double* p1l,
+                                                   double* cvd, double* gt, double* tpl) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, NWB = blockDim.x >> 6, M = m.M;
+  const int c0 = ev.chunk_first[r], c1 = (mask & SV_MASK_STATS) ? c0 : ev.chunk_first[r + 1];
+  if (tid < MP) {
+    double p0 = 0.0, p1sum = 0.0, dinv = 0.0;
+    if (tid < M) {
+      constexpr int GB = 8;      // chunks per step (a cfg3 trial has 8): 16 independent loads in flight
+      for (int ch = c0; ch < c1; ch += GB) {
+        double v[GB], w[GB];
+#pragma unroll
+        for (int u = 0; u < GB; ++u) {
+          const bool in = ch + u < c1;
+          const long long o = (long long)(in ? ch + u : ch) * ev.sumM + m.colM + tid;
+          v[u] = ev.P0[o];
+          w[u] = want_zt ? ev.P1[o] : 0.0;
+          if (!in) { v[u] = 0.0; w[u] = 0.0; }
+        }
+        p0 += ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
+        p1sum += ((w[0] + w[1]) + (w[2] + w[3])) + ((w[4] + w[5]) + (w[6] + w[7]));
+      }
+      if (mask & 1u) dinv = 1.0 / pt.cholvec[(long long)r * m.P + tid * (tid + 1) / 2 + tid];
+    }
+    gs[tid] = s2 * p0;
+    p1l[tid] = p1sum;
+    cvd[tid] = dinv;
+    gt[tid] = 0.0;
+  }
+  if (wave == NWB - 1) {   // spike-direct theta partials: one chunk per lane, then a fixed-order wave tree
+    double tp0 = 0.0, tp1 = 0.0;
+    if (want_zt) {
+      for (int ch = c0 + lane; ch < c1; ch += 64) {
+        tp0 += ev.Tpart[((long long)ch * ev.K + k) * 2 + 0];
+        tp1 += ev.Tpart[((long long)ch * ev.K + k) * 2 + 1];
+      }
+      tp0 = wave_sum(tp0);
+      tp1 = wave_sum(tp1);
+    }
+    if (lane == 0) {
+      tpl[0] = tp0;
+      tpl[1] = tp1;
+    }
+  }
+}
+
 // ---- phases 1 + 2 --------------------------------------------------------------------------------------------------
 template <int NT, int KT, bool FULL>
 __device__ void item_bwd_body(const EngineView& ev, const int r, const int k, const LatentPtrs pt, unsigned mask,
@@ -219,8 +269,11 @@ __device__ void item_bwd_body(const EngineView& ev, const int r, const int k, co
   double* redz = tred + NWB * 2;      // NT*MP  per-panel row sums of the dZ contraction
   double* redt = redz + NT * MP;      // NT*2   per-panel dtheta partials
   double* thq = redt + 2 * NT;        // 2      quadrature part of dtheta (direct)
+  double* p1l = thq + 8;              // MP     spike partial sums P1 of the trial
+  double* cvd = p1l + MP;             // MP     1 / diag(L_S)
+  double* tpl = cvd + MP;             // 2      spike-direct theta partials of the trial
   constexpr bool DSEP = NT >= 3 && FULL;   // D in its own buffer
-  double* Dl = DSEP ? thq + 8 : Vl;   // MP*LD  D
+  double* Dl = DSEP ? tpl + 8 : Vl;   // MP*LD  D
   const KPar p = make_kpar(m, ev.theta + 2 * k);
   const long long base = m.offMM + (long long)r * M * M;
   const long long vbase = m.offM + (long long)r * M;
@@ -228,9 +281,22 @@ __device__ void item_bwd_body(const EngineView& ev, const int r, const int k, co
   const bool want_zt = (mask & (4u | 8u)) != 0;
 
   if (want_lat) {
-    // ================================================================= phase 1: quadrature adjoints
     load_factors<NT>(ev, m, r, Li, Vl, ul, zl, true);
-    if (tid < MP) al[tid] = (tid < M) ? ev.a[vbase + tid] : 0.0;
+  } else if (tid < MP) {
+    ul[tid] = 0.0;
+    zl[tid] = 0.0;
+  }
+  if (tid < MP) al[tid] = (tid < M) ? ev.a[vbase + tid] : 0.0;
+  // The gather of phase 2's inputs runs HERE, beside the staging of the factors, up to M = 32: between the phases, where
+  // the values are used, its memory latency was exposed (12 us of the kernel at the north-star size).  Above M = 32 it
+  // stays between the phases: in front of phase 1 the FULL variant with D in its own buffer returned wrong sums (not
+  // understood: every access is in range and every barrier uniform; the value-only variant and M <= 32 are unaffected),
+  // so the arrangement that the parity tests cover is kept there.
+  constexpr bool GATHER_EARLY = NT <= 2;
+  if (GATHER_EARLY) gather_item_inputs<MP>(ev, m, pt, r, k, mask, want_zt, p.s2, gs, p1l, cvd, gt, tpl);
+
+  if (want_lat) {
+    // ================================================================= phase 1: quadrature adjoints
     __syncthreads();
     if (KT == SV_PERIODIC && tid < MP) sv_sincos_quarter(zl[tid] * p.q4, szl[tid], czl[tid]);
     if (FULL) {
@@ -465,88 +531,54 @@ __device__ void item_bwd_body(const EngineView& ev, const int r, const int k, co
     // Vt for phase 2: staged again only where D took its buffer.  Gt's padding rows / columns are exact zeros: they are
     // sums of products with zero-padded rows of Linv
     if (FULL && !DSEP) stage_matrix<NT>(Vl, ev.Vt + base, M, tid, NTHB);
-  } else {
-    if (tid < MP) {
-      ul[tid] = 0.0;
-      zl[tid] = 0.0;
-      al[tid] = (tid < M) ? ev.a[vbase + tid] : 0.0;
-    }
   }
 
   if (SV_BWD_STOP == 1) return;
   // =================================================================== phase 2: per-item backward
-  // ---- gather the spike partial sums of this trial (fixed chunk order); thread j < M owns inducing point j
+  if (!GATHER_EARLY) {
+    __syncthreads();
+    gather_item_inputs<MP>(ev, m, pt, r, k, mask, want_zt, p.s2, gs, p1l, cvd, gt, tpl);
+  }
+  // ---- spike part of the ELL of this item: sum_j a_j gs_j
   double p1sum = 0.0, espk = 0.0, a_l = 0.0;
-  if (tid < MP) {
-    gs[tid] = 0.0;
-    gt[tid] = 0.0;
-  }
-  __syncthreads();
-  // statistics mode: the spike term arrived through the segment-1 adjoints, there are no a-priori spike sums to gather
-  const int c0 = ev.chunk_first[r], c1 = (mask & SV_MASK_STATS) ? c0 : ev.chunk_first[r + 1];
   if (tid < M) {
-    double p0 = 0.0;
-    // 8 chunks per step (a cfg3 trial has 8): 16 independent loads in flight, fixed order of the additions
-    constexpr int GB = 8;
-    for (int ch = c0; ch < c1; ch += GB) {
-      double v[GB], w[GB];
-#pragma unroll
-      for (int u = 0; u < GB; ++u) {
-        const bool in = ch + u < c1;
-        const long long o = (long long)(in ? ch + u : ch) * ev.sumM + m.colM + tid;
-        v[u] = ev.P0[o];
-        w[u] = want_zt ? ev.P1[o] : 0.0;
-        if (!in) { v[u] = 0.0; w[u] = 0.0; }
-      }
-#pragma unroll
-      for (int h = 0; h < GB; h += 8) {
-        if (h == 0 || ch + h < c1) {
-          p0 += ((v[h] + v[h + 1]) + (v[h + 2] + v[h + 3])) + ((v[h + 4] + v[h + 5]) + (v[h + 6] + v[h + 7]));
-          p1sum += ((w[h] + w[h + 1]) + (w[h + 2] + w[h + 3])) + ((w[h + 4] + w[h + 5]) + (w[h + 6] + w[h + 7]));
-        }
-      }
-    }
     a_l = al[tid];
-    const double gsp = p.s2 * p0;
-    espk = a_l * gsp;
-    gs[tid] = gsp;
+    espk = a_l * gs[tid];
+    p1sum = p1l[tid];
   }
-  // spike-direct theta partials: one chunk per lane of wave 0, then a fixed-order wave tree
-  double tp0 = 0.0, tp1 = 0.0;
   if (wave == 0) {
     espk = wave_sum(espk);
-    if (want_zt) {
-      for (int ch = c0 + lane; ch < c1; ch += 64) {
-        tp0 += ev.Tpart[((long long)ch * ev.K + k) * 2 + 0];
-        tp1 += ev.Tpart[((long long)ch * ev.K + k) * 2 + 1];
-      }
-      tp0 = wave_sum(tp0);
-      tp1 = wave_sum(tp1);
-    }
     if (lane == 0) ev.ells[item] = espk;
   }
   if (!want_lat) return;
   if (SV_BWD_STOP == 2) return;
 
   __syncthreads();
-  if (tid < M) {
-    double s = gq[tid];
-    for (int q = 0; q <= tid; ++q) s += Li[tid * LD + q] * gs[q];
-    gt[tid] = s;
+  // the two triangular matrix-vector products of the item, LPR lanes per row (one thread per row walked up to M
+  // LDS-latency-bound iterations: a microsecond each at M = 32)
+  const int LPR = (NTHB >= 16 * MP) ? 16 : (NTHB >= 8 * MP) ? 8 : (NTHB >= 4 * MP) ? 4 : (NTHB >= 2 * MP) ? 2 : 1;
+  const int mrow = tid / LPR, msub = tid % LPR;
+  {   // gt = gq + Linv gs
+    double s = 0.0;
+    if (mrow < M)
+      for (int q = msub; q <= mrow; q += LPR) s = fma(Li[mrow * LD + q], gs[q], s);
+    for (int o = 1; o < LPR; o <<= 1) s += __shfl_xor(s, o, 64);
+    if (msub == 0 && mrow < M) gt[mrow] = gq[mrow] + s;
   }
   __syncthreads();
 
   const int c = wave;                     // panel index of this wavefront (waves >= NT idle through the panel work)
   const bool pan = c < NT;
   if (mask & 1u) {
-    if (tid < M) {
+    {   // dm = Linv^T (gt - ut)
       double s = 0.0;
-      for (int q = tid; q < M; ++q) s += Li[q * LD + tid] * (gt[q] - ul[q]);
-      pt.g_mean[(long long)r * M + tid] = s;
+      if (mrow < M)
+        for (int q = mrow + msub; q < M; q += LPR) s = fma(Li[q * LD + mrow], gt[q] - ul[q], s);
+      for (int o = 1; o < LPR; o <<= 1) s += __shfl_xor(s, o, 64);
+      if (msub == 0 && mrow < M) pt.g_mean[(long long)r * M + mrow] = s;
     }
     if (pan) {
       // dL_S = tril(Linv^T (2 Gt - I) Vt) + diag(1 / L_S,ii): this wave's 16-column panel
-      const double* cv = pt.cholvec + (long long)r * m.P;
       double* gcv = pt.g_cholvec + (long long)r * m.P;
       d4 P[NT], X[NT];
 #pragma unroll
@@ -585,7 +617,7 @@ __device__ void item_bwd_body(const EngineView& ev, const int r, const int k, co
             int i = 16 * a + 4 * q + lg, j = 16 * c + li;
             if (i < M && j <= i) {
               double g = acc[q];
-              if (i == j) g += 1.0 / cv[i * (i + 1) / 2 + i];
+              if (i == j) g += cvd[i];
               gcv[i * (i + 1) / 2 + j] = g;
             }
           }
@@ -707,8 +739,8 @@ __device__ void item_bwd_body(const EngineView& ev, const int r, const int k, co
       t0 += redt[2 * w + 0];
       t1 += redt[2 * w + 1];
     }
-    ev.gthitem[item * 2 + 0] = t0 * p.c0 + thq[0] + p.c0 * tp0;
-    ev.gthitem[item * 2 + 1] = t1 * p.c1 + thq[1] + p.c1 * tp1;
+    ev.gthitem[item * 2 + 0] = t0 * p.c0 + thq[0] + p.c0 * tpl[0];
+    ev.gthitem[item * 2 + 1] = t1 * p.c1 + thq[1] + p.c1 * tpl[1];
   }
 }
 
