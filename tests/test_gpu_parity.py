@@ -99,6 +99,8 @@ CASES = [
     dict(R=2, N=500, K=20, M=64, kernels="mix", n_quad=200, rate=2.0, seed=6),         # cfg5 shape class (small R)
     dict(R=3, N=40, K=7, M=[48, 20, 33, 9, 16, 40, 5], kernels="mix", n_quad=50, rate=10.0, seed=7),   # NT = 3, ragged M
     dict(R=2, N=6, K=2, M=[20, 24], kernels="periodic", n_quad=120, rate=6.0, seed=8, trial_len=6.0),  # 15 periods per trial
+    dict(R=2, N=3, K=2, M=[8, 12], kernels="mix", n_quad=40, rate=12000.0, seed=9),   # ~36 000 spikes = 70 chunks per trial
+    dict(R=1, N=2, K=1, M=[40], kernels="rbf", n_quad=48, rate=11000.0, seed=10),      # NT = 3 with 43 chunks in the trial
 ]
 
 
