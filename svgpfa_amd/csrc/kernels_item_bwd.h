@@ -289,9 +289,10 @@ __device__ void item_bwd_body(const EngineView& ev, const int r, const int k, co
   if (tid < MP) al[tid] = (tid < M) ? ev.a[vbase + tid] : 0.0;
   // The gather of phase 2's inputs runs HERE, beside the staging of the factors, up to M = 32: between the phases, where
   // the values are used, its memory latency was exposed (12 us of the kernel at the north-star size).  Above M = 32 it
-  // stays between the phases: in front of phase 1 the FULL variant with D in its own buffer returned wrong sums (not
-  // understood: every access is in range and every barrier uniform; the value-only variant and M <= 32 are unaffected),
-  // so the arrangement that the parity tests cover is kept there.
+  // stays between the phases: with the helper inlined in front of phase 1, the FULL variant there (256 VGPRs plus AGPR
+  // spills, D in its own buffer) returned wrong sums, while the same source with the helper kept out of line
+  // (noinline) is correct -- a code-generation matter of that one instantiation, not of the placement; the arrangement
+  // the parity tests have always covered is kept for it (cases M = 33, 40, 48, 64 x all masks in test_gpu_parity.py).
   constexpr bool GATHER_EARLY = NT <= 2;
   if (GATHER_EARLY) gather_item_inputs<MP>(ev, m, pt, r, k, mask, want_zt, p.s2, gs, p1l, cvd, gt, tpl);
 
