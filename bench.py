@@ -143,14 +143,21 @@ def item_bwd_flops(prob, mask):
 
 def kernel_source_sha():
     """Content hash of the ELBO path's device code: a PMC digest only describes the kernels it was measured on.
-    (lbfgs_*: the optimiser's vector kernels, a separate translation unit that no evaluation launches.)"""
+    Comments and blank lines do not count (a reworded comment does not invalidate a measurement); lbfgs_*: the
+    optimiser's vector kernels, a separate translation unit that no evaluation launches."""
     import hashlib
+    import re
     h = hashlib.sha256()
     csrc = os.path.join(REPO, "svgpfa_amd", "csrc")
     for f in sorted(os.listdir(csrc)):
         if f.endswith((".h", ".hip")) and not f.startswith("lbfgs_"):
-            with open(os.path.join(csrc, f), "rb") as fh:
-                h.update(f.encode() + b"\0" + fh.read())
+            with open(os.path.join(csrc, f), "r") as fh:
+                text = fh.read()
+            text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+            text = re.sub(r"//[^\n]*", "", text)
+            lines = [" ".join(ln.split()) for ln in text.splitlines()]
+            code = "\n".join(ln for ln in lines if ln)
+            h.update(f.encode() + b"\0" + code.encode())
     return h.hexdigest()[:16]
 
 
