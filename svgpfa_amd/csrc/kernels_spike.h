@@ -672,26 +672,41 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 8))) void
   }
 }
 
-// Mseg[n][k] = sum over all local spikes of neuron n of mu_k(t_s)   (embedding M-step path)
-__global__ void k_mseg(EngineView ev) {
-  int id = blockIdx.x * blockDim.x + threadIdx.x;
-  if (id >= ev.N * ev.K) return;
-  int n = id / ev.K, k = id % ev.K;
+#define SV_FS_OUT 8   // outputs per block of the two fixed-order cross-trial reductions below
+
+// Mseg[n][k] = sum over all local spikes of neuron n of mu_k(t_s)   (embedding M-step path, once per
+// computeSVPosteriorOnLatentsStats).  Block = SV_FS_OUT consecutive (n, k) outputs x 32 trial groups: thread (o, pg) adds
+// the segments of trials pg, pg + 32, ... (a segment = the consecutive spikes of neuron n in trial r), the 32 partial
+// sums are added in order through LDS.  (One thread per output walking all trials: 4.7 ms at the north-star size.)
+__global__ __launch_bounds__(256) void k_mseg(EngineView ev) {
+  __shared__ double red[256];
+  const int tid = threadIdx.x, o = tid % SV_FS_OUT, pg = tid / SV_FS_OUT, NG = 256 / SV_FS_OUT;
+  const int id = blockIdx.x * SV_FS_OUT + o, NK = ev.N * ev.K;
   double s = 0.0;
-  for (int r = 0; r < ev.R; ++r) {
-    long long rn = (long long)r * ev.N + n;
-    double sr = 0.0;
-    for (long long i = ev.seg_off[rn]; i < ev.seg_off[rn + 1]; ++i) sr += ev.muspk[(long long)k * ev.S + i];
-    s += sr;
+  if (id < NK) {
+    const int n = id / ev.K, k = id % ev.K;
+    const double* mu = ev.muspk + (long long)k * ev.S;
+    for (int r = pg; r < ev.R; r += NG) {
+      const long long rn = (long long)r * ev.N + n;
+      const long long i0 = ev.seg_off[rn], i1 = ev.seg_off[rn + 1];
+      double sr = 0.0;
+      for (long long i = i0; i < i1; ++i) sr += mu[i];
+      s += sr;
+    }
   }
-  ev.Mseg[id] = s;
+  red[pg * SV_FS_OUT + o] = s;
+  __syncthreads();
+  if (pg == 0 && id < NK) {
+    double t = red[o];
+    for (int q = 1; q < NG; ++q) t += red[q * SV_FS_OUT + o];
+    ev.Mseg[id] = t;
+  }
 }
 
 // ELL with frozen latent stats (embedding M-step closure): out = [ELL, dC, dd].
 // Block g < nbo sums SV_FS_OUT consecutive outputs over the per-trial partial rows: thread (o, pg) adds the trials pg,
 // pg + NG, ... four at a time (eight independent loads in flight; one thread per output walking all R rows left ten
 // blocks waiting on memory 500 times in a row), the NG partial sums are added in order through LDS.  Last block: ELL.
-#define SV_FS_OUT 8
 __global__ __launch_bounds__(256) void k_finalize_stats(EngineView ev, const double* C, const double* d,
                                                         int want_grad, double* out) {
   __shared__ double red[256];

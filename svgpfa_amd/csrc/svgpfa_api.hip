@@ -677,7 +677,7 @@ int svgpfa_latent_stats(svgpfa_engine* e, const double* const* mean, const doubl
   launch_prep(e, pt);
   if ((rc = launch_times_quad(e))) return rc;
   if ((rc = launch_times(e, v.spk_t, v.spk_off, 0, v.muspk, v.varspk, 0LL, 1LL, (long long)v.S, 1))) return rc;
-  hipLaunchKernelGGL(k_mseg, dim3((v.N * v.K + 255) / 256), dim3(256), 0, e->stream, v);
+  hipLaunchKernelGGL(k_mseg, dim3((v.N * v.K + SV_FS_OUT - 1) / SV_FS_OUT), dim3(256), 0, e->stream, v);
   {   // the engine keeps [r][k][q]; the caller gets the reference's [r][q][k]
     const long long rqk = (long long)v.R * v.Q * v.K;
     const unsigned g = (unsigned)((rqk + 255) / 256);
