@@ -675,22 +675,25 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 8))) void
 #define SV_FS_OUT 8   // outputs per block of the two fixed-order cross-trial reductions below
 
 // Mseg[n][k] = sum over all local spikes of neuron n of mu_k(t_s)   (embedding M-step path, once per
-// computeSVPosteriorOnLatentsStats).  Block = SV_FS_OUT consecutive (n, k) outputs x 32 trial groups: thread (o, pg) adds
-// the segments of trials pg, pg + 32, ... (a segment = the consecutive spikes of neuron n in trial r), the 32 partial
-// sums are added in order through LDS.  (One thread per output walking all trials: 4.7 ms at the north-star size.)
-__global__ __launch_bounds__(256) void k_mseg(EngineView ev) {
+// computeSVPosteriorOnLatentsStats).  Block = SV_FS_OUT consecutive (n, k) outputs x 32 lanes per output, the lanes laid
+// out as (32 / gs) trial groups x gs segment lanes (a segment = the consecutive spikes of neuron n in trial r; gs = a
+// power of two chosen by the host from the mean segment length): lane (tr, sl) adds the elements sl, sl + gs, ... of the
+// segments of trials tr, tr + 32 / gs, ...; the 32 partial sums are added in order through LDS.  (One thread per output
+// walking every spike of its neuron: 4.7 ms at the north-star size.)
+__global__ __launch_bounds__(256) void k_mseg(EngineView ev, int gs) {
   __shared__ double red[256];
   const int tid = threadIdx.x, o = tid % SV_FS_OUT, pg = tid / SV_FS_OUT, NG = 256 / SV_FS_OUT;
   const int id = blockIdx.x * SV_FS_OUT + o, NK = ev.N * ev.K;
+  const int tr = pg / gs, sl = pg % gs, ntr = NG / gs;
   double s = 0.0;
   if (id < NK) {
     const int n = id / ev.K, k = id % ev.K;
     const double* mu = ev.muspk + (long long)k * ev.S;
-    for (int r = pg; r < ev.R; r += NG) {
+    for (int r = tr; r < ev.R; r += ntr) {
       const long long rn = (long long)r * ev.N + n;
       const long long i0 = ev.seg_off[rn], i1 = ev.seg_off[rn + 1];
       double sr = 0.0;
-      for (long long i = i0; i < i1; ++i) sr += mu[i];
+      for (long long i = i0 + sl; i < i1; i += gs) sr += mu[i];
       s += sr;
     }
   }

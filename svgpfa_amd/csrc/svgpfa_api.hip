@@ -677,7 +677,12 @@ int svgpfa_latent_stats(svgpfa_engine* e, const double* const* mean, const doubl
   launch_prep(e, pt);
   if ((rc = launch_times_quad(e))) return rc;
   if ((rc = launch_times(e, v.spk_t, v.spk_off, 0, v.muspk, v.varspk, 0LL, 1LL, (long long)v.S, 1))) return rc;
-  hipLaunchKernelGGL(k_mseg, dim3((v.N * v.K + SV_FS_OUT - 1) / SV_FS_OUT), dim3(256), 0, e->stream, v);
+  {   // lanes per segment: about a quarter of the mean number of spikes per (trial, neuron), a power of two <= 32
+    const long long seg = (long long)v.S / std::max(1LL, (long long)v.R * v.N);
+    int gs = 1;
+    while (gs < 32 && 4 * gs < seg) gs *= 2;
+    hipLaunchKernelGGL(k_mseg, dim3((v.N * v.K + SV_FS_OUT - 1) / SV_FS_OUT), dim3(256), 0, e->stream, v, gs);
+  }
   {   // the engine keeps [r][k][q]; the caller gets the reference's [r][q][k]
     const long long rqk = (long long)v.R * v.Q * v.K;
     const unsigned g = (unsigned)((rqk + 255) / 256);
