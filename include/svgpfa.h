@@ -155,6 +155,13 @@ int svgpfa_latent_stats_backward(svgpfa_engine* e,
  * point) pair (periodic latents with a short lengthscale or few inducing points; in fp32 in precision mode "mixed"). */
 int svgpfa_get_series_harmonics(svgpfa_engine* e, int32_t* out_host);
 
+/* What svgpfa_ell_given_stats needs of svgpfa_latent_stats -- the statistics at the quadrature nodes and, per (neuron,
+ * latent), the sum of the posterior means at that neuron's spikes -- kept resident, without materialising the mean and
+ * variance at every spike (the embedding M-step of the EM loop, stats/svEM.py:225-232, needs nothing else of them).
+ * C: an N x K embedding matrix; its values do not enter the frozen statistics (the pass that makes the spike means also
+ * accumulates C-weighted sums, which are discarded). */
+int svgpfa_freeze_stats(svgpfa_engine* e, const double* const* mean, const double* const* cholvec, const double* C);
+
 /* KL divergence term alone (stats/klDivergence.py:18-44) of the parameters of the latest svgpfa_elbo /
  * svgpfa_latent_stats / svgpfa_predict call: out[0]. */
 int svgpfa_kl(svgpfa_engine* e, double* out);

@@ -47,6 +47,7 @@ SIGNATURES = {
     "svgpfa_elbo": (ctypes.c_int, [_vp, _vpp, _vpp, _vp, _vp, _u32, _vp, _vpp, _vpp, _vpp]),
     "svgpfa_latent_stats": (ctypes.c_int, [_vp, _vpp, _vpp, _vp, _vp, _vp, _vp]),
     "svgpfa_latent_stats_backward": (ctypes.c_int, [_vp, _vpp, _vpp, _vp, _vp, _vp, _vp, _u32, _vp, _vpp, _vpp, _vpp]),
+    "svgpfa_freeze_stats": (ctypes.c_int, [_vp, _vpp, _vpp, _vp]),
     "svgpfa_kl": (ctypes.c_int, [_vp, _vp]),
     "svgpfa_get_series_harmonics": (ctypes.c_int, [_vp, ctypes.POINTER(_i32)]),
     "svgpfa_ell_given_stats": (ctypes.c_int, [_vp, _vp, _vp, ctypes.c_int, _vp]),

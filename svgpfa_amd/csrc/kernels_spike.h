@@ -706,6 +706,40 @@ __global__ __launch_bounds__(256) void k_mseg(EngineView ev, int gs) {
   }
 }
 
+// The same sums from the spike part of dC that a FULL spike pass has just left per trial (svgpfa_freeze_stats): Mseg[n][k]
+// = sum_r (gCspk + gCspkB)[r][n][k] + the split chunks of neuron n, trials four at a time, fixed order.
+__global__ __launch_bounds__(256) void k_mseg_from_dc(EngineView ev) {
+  __shared__ double red[256];
+  const int tid = threadIdx.x, o = tid % SV_FS_OUT, pg = tid / SV_FS_OUT, NG = 256 / SV_FS_OUT;
+  const int id = blockIdx.x * SV_FS_OUT + o, NK = ev.N * ev.K, R = ev.R;
+  double s = 0.0;
+  if (id < NK) {
+    for (int r0 = pg; r0 < R; r0 += 4 * NG) {
+      double v[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int r = r0 + u * NG;
+        v[u] = (r < R) ? ev.gCspk[(long long)r * NK + id] + ev.gCspkB[(long long)r * NK + id] : 0.0;
+      }
+      s += (v[0] + v[1]) + (v[2] + v[3]);
+    }
+    if (pg == 0) {
+      const int n = id / ev.K, k = id % ev.K;
+      for (int l = 0; l < ev.nsplit; ++l) {
+        const int ch = ev.split_chunks[l];
+        if (ev.chunks[ch].neuron == n) s += ev.splitPart[(long long)ch * ev.K + k];
+      }
+    }
+  }
+  red[pg * SV_FS_OUT + o] = s;
+  __syncthreads();
+  if (pg == 0 && id < NK) {
+    double t = red[o];
+    for (int q = 1; q < NG; ++q) t += red[q * SV_FS_OUT + o];
+    ev.Mseg[id] = t;
+  }
+}
+
 // ELL with frozen latent stats (embedding M-step closure): out = [ELL, dC, dd].
 // Block g < nbo sums SV_FS_OUT consecutive outputs over the per-trial partial rows: thread (o, pg) adds the trials pg,
 // pg + NG, ... four at a time (eight independent loads in flight; one thread per output walking all R rows left ten

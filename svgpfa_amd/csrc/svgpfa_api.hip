@@ -587,6 +587,31 @@ static std::pair<hipEvent_t, hipEvent_t>* timing_begin(svgpfa_engine* e, int slo
   return evp;
 }
 
+// The spike-time pass on stream sk.  full: Z / theta gradient sums wanted too; want_c: the spike means and their per-neuron
+// sums (dC) wanted (only with full).
+static void launch_spike_pass(svgpfa_engine* e, hipStream_t sk, bool full, bool want_c, const double* C) {
+  EngineView& v = e->v;
+  const dim3 gs(v.nchunks * v.K), bs(64);
+  if (e->precision == SVGPFA_PRECISION_MIXED) {
+    if (e->spl == 16) {
+      if (full) hipLaunchKernelGGL((k_spike<true, 16, float>), gs, bs, 0, sk, v, C);
+      else hipLaunchKernelGGL((k_spike<false, 16, float>), gs, bs, 0, sk, v, C);
+    } else {
+      if (full && !want_c) hipLaunchKernelGGL((k_spike<true, 8, float, false>), gs, bs, 0, sk, v, C);
+      else if (full) hipLaunchKernelGGL((k_spike<true, 8, float>), gs, bs, 0, sk, v, C);
+      else hipLaunchKernelGGL((k_spike<false, 8, float>), gs, bs, 0, sk, v, C);
+    }
+  } else if (e->spl == 4) {
+    if (full) hipLaunchKernelGGL((k_spike<true, 4>), gs, bs, 0, sk, v, C);
+    else hipLaunchKernelGGL((k_spike<false, 4>), gs, bs, 0, sk, v, C);
+  } else {
+    // kernel-parameter / inducing-point closures (no embedding gradient): the series bodies skip the spike means
+    if (full && !want_c) hipLaunchKernelGGL((k_spike<true, 8, double, false>), gs, bs, 0, sk, v, C);
+    else if (full) hipLaunchKernelGGL((k_spike<true, 8>), gs, bs, 0, sk, v, C);
+    else hipLaunchKernelGGL((k_spike<false, 8>), gs, bs, 0, sk, v, C);
+  }
+}
+
 static int check_ready(svgpfa_engine* e) {
   if (!e->have_quad) FAIL(e, SVGPFA_ERR_STATE, "svgpfa_set_quad has not been called");
   if (!e->have_spikes) FAIL(e, SVGPFA_ERR_STATE, "svgpfa_set_spikes has not been called");
@@ -624,25 +649,7 @@ int svgpfa_elbo(svgpfa_engine* e, const double* const* mean, const double* const
     // cached and un-cached evaluations are to stay bit-identical
     e->p0_token = full ? 0 : e->emb_token;
     std::pair<hipEvent_t, hipEvent_t>* evp = timing_begin(e, 0, sk);
-    const dim3 gs(v.nchunks * v.K), bs(64);
-    if (e->precision == SVGPFA_PRECISION_MIXED) {
-      if (e->spl == 16) {
-        if (full) hipLaunchKernelGGL((k_spike<true, 16, float>), gs, bs, 0, sk, v, C);
-        else hipLaunchKernelGGL((k_spike<false, 16, float>), gs, bs, 0, sk, v, C);
-      } else {
-        if (full && !(mask & 2u)) hipLaunchKernelGGL((k_spike<true, 8, float, false>), gs, bs, 0, sk, v, C);
-        else if (full) hipLaunchKernelGGL((k_spike<true, 8, float>), gs, bs, 0, sk, v, C);
-        else hipLaunchKernelGGL((k_spike<false, 8, float>), gs, bs, 0, sk, v, C);
-      }
-    } else if (e->spl == 4) {
-      if (full) hipLaunchKernelGGL((k_spike<true, 4>), gs, bs, 0, sk, v, C);
-      else hipLaunchKernelGGL((k_spike<false, 4>), gs, bs, 0, sk, v, C);
-    } else {
-      // kernel-parameter / inducing-point closures (no embedding gradient): the series bodies skip the spike means
-      if (full && !(mask & 2u)) hipLaunchKernelGGL((k_spike<true, 8, double, false>), gs, bs, 0, sk, v, C);
-      else if (full) hipLaunchKernelGGL((k_spike<true, 8>), gs, bs, 0, sk, v, C);
-      else hipLaunchKernelGGL((k_spike<false, 8>), gs, bs, 0, sk, v, C);
-    }
+    launch_spike_pass(e, sk, full, (mask & 2u) != 0, C);
     if (evp) HIPCHK(e, hipEventRecord(evp->second, sk));
     if (side) HIPCHK(e, hipEventRecord(e->ev_spk, sk));
   }
@@ -695,6 +702,28 @@ int svgpfa_latent_stats(svgpfa_engine* e, const double* const* mean, const doubl
     if (mu_spk) hipLaunchKernelGGL(k_transpose_b, dim3(g), dim3(256), 0, e->stream, v.muspk, mu_spk, 1LL, (long long)v.K, (long long)v.S);
     if (var_spk) hipLaunchKernelGGL(k_transpose_b, dim3(g), dim3(256), 0, e->stream, v.varspk, var_spk, 1LL, (long long)v.K, (long long)v.S);
   }
+  HIPCHK(e, hipGetLastError());
+  e->have_stats = true;
+  return SVGPFA_OK;
+}
+
+int svgpfa_freeze_stats(svgpfa_engine* e, const double* const* mean, const double* const* cholvec, const double* C) {
+  if (!e || !C) return SVGPFA_ERR_INVALID;
+  HIPCHK(e, hipSetDevice(e->device));
+  int rc;
+  if ((rc = check_ready(e))) return rc;
+  if (e->precision == SVGPFA_PRECISION_MIXED)   // the fp32 pair loops would carry their rounding into the frozen sums
+    return svgpfa_latent_stats(e, mean, cholvec, nullptr, nullptr, nullptr, nullptr);
+  EngineView& v = e->v;
+  PtrTable pt;
+  if ((rc = fill_ptrs(e, pt, mean, cholvec, nullptr, nullptr, nullptr, 0))) return rc;
+  launch_prep(e, pt);
+  if ((rc = launch_times_quad(e))) return rc;
+  // the per-neuron sums of the spike means are the spike part of dC, which the spike-time pass makes (cosine series:
+  // ~0.3 ms at the north-star size against 2 ms for the posterior mean and variance at every spike)
+  if (v.nchunks > 0) launch_spike_pass(e, e->stream, true, true, C);
+  e->p0_token = 0;                     // that pass overwrote the reusable spike sums
+  hipLaunchKernelGGL(k_mseg_from_dc, dim3((v.N * v.K + SV_FS_OUT - 1) / SV_FS_OUT), dim3(256), 0, e->stream, v);
   HIPCHK(e, hipGetLastError());
   e->have_stats = true;
   return SVGPFA_OK;

@@ -204,6 +204,14 @@ class Engine:
         self._check(self.lib.svgpfa_latent_stats(self._h, mt, ct, *[_ptr(o) for o in outs]))
         return outs
 
+    def freeze_stats(self, mean, cholvec, C):
+        """The statistics ell_given_stats needs, kept resident, without the mean / variance at every spike."""
+        self._use_current_stream()
+        self._dev(C)
+        mt = self._table(mean, [self.R * m for m in self.Ms])
+        ct = self._table(cholvec, [self.R * p for p in self.Ps])
+        self._check(self.lib.svgpfa_freeze_stats(self._h, mt, ct, _ptr(C)))
+
     def series_harmonics(self):
         """Per latent: H >= 0 if the spike pass evaluates the (periodic) kernel through H + 1 terms of its cosine series,
         -1 if pair by pair (include/svgpfa.h).  Waits for the stream."""

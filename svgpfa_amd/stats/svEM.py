@@ -136,7 +136,9 @@ class SVEM_PyTorch:
 
     def _mStepEmbedding(self, model, optim_params):
         x = model.getSVEmbeddingParams()
-        stats = model.computeSVPosteriorOnLatentsStats()
+        # the statistics are only handed back to the model: where it can freeze them without materialising the posterior
+        # at every spike (svgpfa_amd SVLowerBound), it does
+        stats = model.freezeLatentsStats() if hasattr(model, "freezeLatentsStats") else model.computeSVPosteriorOnLatentsStats()
         return self._lbfgs_step(
             x, lambda: model.evalELLSumAcrossTrialsAndNeurons(svPosteriorOnLatentsStats=stats), optim_params,
             per_trial=False, model=model, group="emb")

@@ -537,6 +537,17 @@ class SVLowerBound:
         self._stats_token = stats
         return stats
 
+    def freezeLatentsStats(self):
+        """What the embedding M-step needs of computeSVPosteriorOnLatentsStats() -- the statistics at the quadrature nodes
+        and the per-neuron sums of the posterior means at the spikes, resident in HBM -- without the mean / variance at
+        every spike (extension; svEM.py:225-232 passes the statistics back untouched).  Returns the token that
+        evalELLSumAcrossTrialsAndNeurons(svPosteriorOnLatentsStats=...) and evalFlat("emb") accept."""
+        if self._engine is None:
+            self.buildKernelsMatrices()
+        self._engine.freeze_stats(self._mean, [c.detach() for c in self._chol_vecs()], self._C.detach())
+        self._stats_token = {"frozen": True}        # nothing is factorised here: no status to wait for
+        return self._stats_token
+
     def evalELLSumAcrossTrialsAndNeurons(self, svPosteriorOnLatentsStats=None):
         """svLowerBound.py:72-75 -> expectedLogLikelihood.py:107-135."""
         if svPosteriorOnLatentsStats is None:

@@ -424,3 +424,32 @@ def test_gauss_hermite_with_exp_link_equals_the_fused_model():
     fused = _model(prob)
     a, b = float(gh.eval()), float(fused.eval())
     assert abs(a - b) <= 1e-6 * abs(b), (a, b)
+
+
+@pytest.mark.parametrize("name", ["ragged_small", "oversize_neurons", "ragged_M"])
+def test_frozen_stats_equal_full_statistics(name):
+    """freezeLatentsStats() (quadrature statistics + per-neuron sums of the spike means through the spike pass, no
+    per-spike statistics materialised) leaves the embedding closure with the same value and gradients as
+    computeSVPosteriorOnLatentsStats() (svLowerBound.py:72-81), also after the embedding has moved."""
+    if name == "ragged_small":
+        prob, _ = load_golden(name)
+    elif name == "oversize_neurons":     # 12 000 spikes per (trial, neuron): dedicated chunks, split-chunk sums
+        prob = synthetic.make_problem(R=2, N=3, K=2, M=[8, 12], kernels="mix", n_quad=40, rate=12000.0, seed=9, jitter=1.0)
+    else:                                # M up to 48 (NT = 3), latents that fall back to the pair loops
+        prob = synthetic.make_problem(R=3, N=40, K=7, M=[48, 20, 33, 9, 16, 40, 5], kernels="mix", n_quad=50, rate=10.0,
+                                      seed=7, jitter=1.0)
+    m_full, m_frozen = _model(prob), _model(prob)
+    s_full = m_full.computeSVPosteriorOnLatentsStats()
+    s_frozen = m_frozen.freezeLatentsStats()
+    for step in range(2):
+        v1, g1 = m_full.evalFlat("emb")
+        v2, g2 = m_frozen.evalFlat("emb")
+        assert abs(float(v1) - float(v2)) <= 1e-10 * max(1.0, abs(float(v1)))
+        assert rel_err(g2.cpu().numpy(), g1.cpu().numpy()) < 1e-10
+        e1 = m_full.evalELLSumAcrossTrialsAndNeurons(svPosteriorOnLatentsStats=s_full)
+        e2 = m_frozen.evalELLSumAcrossTrialsAndNeurons(svPosteriorOnLatentsStats=s_frozen)
+        assert abs(float(e1) - float(e2)) <= 1e-10 * max(1.0, abs(float(e1)))
+        for m in (m_full, m_frozen):                      # an optimiser step on the embedding; the statistics stay frozen
+            m.flatParams("emb").mul_(1.01)
+    with pytest.raises(NotImplementedError):
+        m_frozen.evalELLSumAcrossTrialsAndNeurons(svPosteriorOnLatentsStats=s_full)

@@ -19,6 +19,7 @@ def timed(name, fn, reps=3):
 times = torch.linspace(0.0, 1.0, 1000, dtype=torch.double).reshape(1, -1, 1).repeat(prob["R"], 1, 1).cuda()
 timed("eval", lambda: model.eval())
 timed("computeSVPosteriorOnLatentsStats", lambda: model.computeSVPosteriorOnLatentsStats())
+timed("freezeLatentsStats", lambda: model.freezeLatentsStats())
 stats = model.computeSVPosteriorOnLatentsStats()
 timed("evalELLSumAcrossTrialsAndNeurons", lambda: model.evalELLSumAcrossTrialsAndNeurons(svPosteriorOnLatentsStats=stats))
 timed("predictLatents (1000 times / trial)", lambda: model.predictLatents(times=times))
