@@ -157,3 +157,16 @@ def test_mixed_fp32_pair_loops(monkeypatch):
             for k in range(prob["K"]):
                 assert rel_err(out["g_Z"][k], ref["g_Z"][k].numpy()[:, :, 0]) < TOL_G
                 assert rel_err(out["g_theta"][k], ref["g_theta"][k].numpy()) < TOL_G
+
+
+def test_mixed_frozen_stats_take_the_full_statistics_route():
+    """In precision mode "mixed" svgpfa_freeze_stats keeps the fp64 route of svgpfa_latent_stats (the fp32 pair loops would
+    carry their rounding into the frozen sums): the embedding closure is bit-identical either way."""
+    from helpers import build_model
+    prob, _ = load_golden("ragged_small")
+    m_full, m_frozen = build_model(prob, precision="mixed"), build_model(prob, precision="mixed")
+    m_full.computeSVPosteriorOnLatentsStats()
+    m_frozen.freezeLatentsStats()
+    v1, g1 = m_full.evalFlat("emb")
+    v2, g2 = m_frozen.evalFlat("emb")
+    assert float(v1) == float(v2) and torch.equal(g1, g2)
