@@ -426,6 +426,13 @@ class SVLowerBound:
             raise NotImplementedError("the Gauss-Hermite link is not available with trials sharded over ranks")
         muq, varq, mus, vars_, kl = _LatentStatsFunction.apply(self, *self._mean, *chol, *self._theta(), *self._Z)
         self._stats_token = None
+        ell = self._gauss_hermite_ell(muq, varq, mus, vars_)
+        self._last_terms = ((ell - kl).detach(), ell.detach(), kl.detach())
+        return ell - kl
+
+    def _gauss_hermite_ell(self, muq, varq, mus, vars_):
+        """Point-process ELL with the Gauss-Hermite link (expectedLogLikelihood.py:215-255) from the latent statistics at
+        the quadrature nodes (R x Q x K) and at the spikes (S x K); differentiable in C, d and in the statistics."""
         C, d = self._C, self._d.reshape(-1)
         x, w = self._herm
         link = self._link
@@ -443,9 +450,7 @@ class SVLowerBound:
         eLog = torch.zeros_like(mS)
         for l in range(x.numel()):
             eLog = eLog + w[l] * torch.log(link(mS + 2.0 * vS * x[l]))
-        ell = -term1 + torch.sum(eLog)
-        self._last_terms = ((ell - kl).detach(), ell.detach(), kl.detach())
-        return ell - kl
+        return -term1 + torch.sum(eLog)
 
     # ------------------------------------------------------------------------------ flat fast path (EM loop)
     GROUPS = ("var", "emb", "theta", "Z")
@@ -542,6 +547,8 @@ class SVLowerBound:
         and the per-neuron sums of the posterior means at the spikes, resident in HBM -- without the mean / variance at
         every spike (extension; svEM.py:225-232 passes the statistics back untouched).  Returns the token that
         evalELLSumAcrossTrialsAndNeurons(svPosteriorOnLatentsStats=...) and evalFlat("emb") accept."""
+        if getattr(self, "_link", None) is not None:      # the Gauss-Hermite link needs mean and variance at every spike
+            return self.computeSVPosteriorOnLatentsStats()
         if self._engine is None:
             self.buildKernelsMatrices()
         self._engine.freeze_stats(self._mean, [c.detach() for c in self._chol_vecs()], self._C.detach())
@@ -555,6 +562,11 @@ class SVLowerBound:
         elif svPosteriorOnLatentsStats is not self._stats_token:
             raise NotImplementedError("svPosteriorOnLatentsStats must be the object returned by the latest "
                                       "computeSVPosteriorOnLatentsStats() call (the stats stay resident in HBM)")
+        if getattr(self, "_link", None) is not None:      # Gauss-Hermite link: the same torch expression as in eval()
+            st = self._stats_token
+            muq, varq = st["allTimes"]
+            return self._gauss_hermite_ell(muq.detach(), varq.detach(), torch.cat(st["assocTimes"][0]).detach(),
+                                           torch.cat(st["assocTimes"][1]).detach())
         return _ELLGivenStatsFunction.apply(self, self._C, self._d)
 
     def predictLatents(self, times):

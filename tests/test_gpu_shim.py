@@ -426,6 +426,38 @@ def test_gauss_hermite_with_exp_link_equals_the_fused_model():
     assert abs(a - b) <= 1e-6 * abs(b), (a, b)
 
 
+def test_gauss_hermite_embedding_closure_and_em_step():
+    """The embedding M-step closure of a Gauss-Hermite model (evalELLSumAcrossTrialsAndNeurons with the statistics frozen,
+    svEM.py:225-232) uses the Gauss-Hermite ELL, not the fused exponential one: its value is the ELL term of eval() at the
+    same parameters (the reference's own value for it), its gradients are those of eval() with respect to C and d
+    (the KL term does not depend on them), and the EM loop's embedding step raises the bound."""
+    prob, ref = load_golden("gh_small")
+    model = _build_gh_model(prob, ref, torch.nn.functional.softplus)
+    model.buildKernelsMatrices()
+    C, d = model.getSVEmbeddingParams()
+    for t in (C, d):
+        t.requires_grad_(True)
+    val = model.eval()
+    val.backward()
+    gC, gd = C.grad.clone(), d.grad.clone()
+    C.grad = d.grad = None
+    for make in (model.computeSVPosteriorOnLatentsStats, model.freezeLatentsStats):   # frozen: falls back to the full stats
+        stats = make()
+        ell = model.evalELLSumAcrossTrialsAndNeurons(svPosteriorOnLatentsStats=stats)
+        assert abs(float(ell) - float(ref["ref_ell"])) <= 1e-9 * abs(float(ref["ref_ell"]))
+        ell.backward()
+        assert rel_err(C.grad.cpu().numpy(), gC.cpu().numpy()) < 1e-10 and rel_err(d.grad.cpu().numpy(), gd.cpu().numpy()) < 1e-10
+        C.grad = d.grad = None
+    for t in (C, d):
+        t.requires_grad_(False)
+    from svgpfa_amd.stats.svEM import SVEM_PyTorch
+    before = float(model.eval())
+    step = dict(max_iter=5, lr=1.0, tolerance_grad=1e-7, tolerance_change=1e-9, line_search_fn="strong_wolfe")
+    res = SVEM_PyTorch()._mStepEmbedding(model=model, optim_params=step)
+    assert res["nfeval"] >= 2
+    assert float(model.eval()) > before
+
+
 @pytest.mark.parametrize("name", ["ragged_small", "oversize_neurons", "ragged_M"])
 def test_frozen_stats_equal_full_statistics(name):
     """freezeLatentsStats() (quadrature statistics + per-neuron sums of the spike means through the spike pass, no
