@@ -590,9 +590,11 @@ class SVLowerBound:
         return self.predictEmbedding(times)
 
     def computeExpectedPosteriorCIFs(self, times):
-        """expectedLogLikelihood.py:62-73: list[R][N] of exp(mean + var / 2) on the grid."""
+        """expectedLogLikelihood.py:62-73: list[R][N] of link(mean + var / 2) on the grid (link = exp unless the model was
+        built with a link callable)."""
         eMean, eVar = self.predictEmbedding(times)
-        cif = torch.exp(eMean + 0.5 * eVar)
+        link = getattr(self, "_link", None) or torch.exp
+        cif = link(eMean + 0.5 * eVar)
         return [[cif[r, :, n] for n in range(cif.shape[2])] for r in range(cif.shape[0])]
 
     def sampleCIFs(self, times, nudget=1e-3):

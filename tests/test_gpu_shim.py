@@ -450,6 +450,11 @@ def test_gauss_hermite_embedding_closure_and_em_step():
         C.grad = d.grad = None
     for t in (C, d):
         t.requires_grad_(False)
+    times = torch.linspace(0.05, 0.95, 7, dtype=torch.double).reshape(1, -1, 1).repeat(prob["R"], 1, 1)
+    eMean, eVar = model.predictEmbedding(times)
+    cifs = model.computeExpectedPosteriorCIFs(times)          # expectedLogLikelihood.py:62-73: link(mean + var / 2)
+    want = torch.nn.functional.softplus(eMean + 0.5 * eVar)
+    assert len(cifs) == prob["R"] and len(cifs[0]) == prob["N"] and torch.equal(cifs[1][2], want[1, :, 2])
     from svgpfa_amd.stats.svEM import SVEM_PyTorch
     before = float(model.eval())
     step = dict(max_iter=5, lr=1.0, tolerance_grad=1e-7, tolerance_change=1e-9, line_search_fn="strong_wolfe")
