@@ -73,7 +73,6 @@ SERIES_FLOPS_RBF = {True: 14, False: 10}
 def rbf_series_terms(prob, k, r):
     """Harmonics (H + 1) of the RBF series for trial r of latent k, by the device's rule (kernels_spike.h
     rbf_series_setup); 0 where the pass falls back to the pair loop."""
-    import numpy as np
     off = prob["spike_offsets"]
     if off[r + 1] == off[r]:
         return 0

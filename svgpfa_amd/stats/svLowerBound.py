@@ -14,7 +14,6 @@ class keeps the protocol the EM loop relies on (svEM.py:93,106,202,219-263,290):
 
 Parameter tensors live on the GPU (fp64, contiguous); setInitialParams moves what it is given.
 """
-import warnings
 
 import numpy as np
 import torch
