@@ -345,8 +345,10 @@ def main():
             allreduce_shared(shared)   # RCCL sum of [ELBO, ELL, KL, dC, dd, dtheta]
 
     # one-off initialisation outside the W + K protocol: first launches load the code objects and create the RCCL
-    # communicator channels lazily; W warm-up steps then run at steady state even when W is small
-    for _ in range(3):
+    # communicator channels lazily, and the GPU leaves its idle clocks only after some tens of milliseconds of work
+    # (a 20-step run right behind engine set-up measured 0.88 ms per step against 0.84 ms once the clocks had settled);
+    # W warm-up steps then run at steady state even when W is small
+    for _ in range(30):
         step()
     eng.sync()
     for _ in range(args.warmup):
