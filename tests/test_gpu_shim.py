@@ -463,7 +463,7 @@ def test_gauss_hermite_embedding_closure_and_em_step():
     assert float(model.eval()) > before
 
 
-@pytest.mark.parametrize("name", ["ragged_small", "oversize_neurons", "ragged_M"])
+@pytest.mark.parametrize("name", ["ragged_small", "oversize_neurons", "ragged_M", "no_spikes"])
 def test_frozen_stats_equal_full_statistics(name):
     """freezeLatentsStats() (quadrature statistics + per-neuron sums of the spike means through the spike pass, no
     per-spike statistics materialised) leaves the embedding closure with the same value and gradients as
@@ -472,6 +472,13 @@ def test_frozen_stats_equal_full_statistics(name):
         prob, _ = load_golden(name)
     elif name == "oversize_neurons":     # 12 000 spikes per (trial, neuron): dedicated chunks, split-chunk sums
         prob = synthetic.make_problem(R=2, N=3, K=2, M=[8, 12], kernels="mix", n_quad=40, rate=12000.0, seed=9, jitter=1.0)
+    elif name == "no_spikes":            # a recording without a single spike: the spike-side sums are empty
+        prob = synthetic.make_problem(R=2, N=3, K=2, M=[6, 9], kernels="mix", n_quad=30, rate=5.0, seed=3, jitter=1.0)
+        prob["spike_offsets"] = np.zeros(3, dtype=np.int64)
+        prob["spike_times"], prob["spike_neuron"] = np.zeros(0), np.zeros(0, dtype=np.int32)
+        from oracle import svgpfa_oracle as orc
+        want = float(orc.elbo_and_grads(orc.from_numpy_problem(prob), 0)["elbo"])
+        assert abs(float(_model(prob).eval()) - want) <= 1e-9 * abs(want)
     else:                                # M up to 48 (NT = 3), latents that fall back to the pair loops
         prob = synthetic.make_problem(R=3, N=40, K=7, M=[48, 20, 33, 9, 16, 40, 5], kernels="mix", n_quad=50, rate=10.0,
                                       seed=7, jitter=1.0)
