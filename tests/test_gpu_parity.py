@@ -104,9 +104,7 @@ CASES = [
 ]
 
 
-@pytest.mark.parametrize("case", CASES, ids=lambda c: "R{R}N{N}K{K}".format(**c))
-@pytest.mark.parametrize("mask", [0, 1, 2, 4, 8, 15])
-def test_oracle_parity_seeded(case, mask):
+def _check_against_oracle(case, mask):
     from oracle import svgpfa_oracle as orc
     prob = synthetic.make_problem(jitter=1.0, reg=1e-3, **case)
     eng, P = _engine(prob)
@@ -129,6 +127,21 @@ def test_oracle_parity_seeded(case, mask):
     if mask & 8:
         for k in range(K):
             assert rel_err(out["g_Z"][k], ref["g_Z"][k].numpy()[:, :, 0]) < TOL_A
+
+
+@pytest.mark.parametrize("case", CASES, ids=lambda c: "R{R}N{N}K{K}".format(**c))
+@pytest.mark.parametrize("mask", [0, 1, 2, 4, 8, 15])
+def test_oracle_parity_seeded(case, mask):
+    _check_against_oracle(case, mask)
+
+
+@pytest.mark.parametrize("case", [CASES[0], CASES[1], CASES[2]], ids=lambda c: "R{R}N{N}K{K}".format(**c))
+@pytest.mark.parametrize("mask", [3, 5, 6, 9, 10, 12, 14])
+def test_oracle_parity_mask_combinations(case, mask):
+    """Gradient groups in the combinations a caller of the autograd protocol can ask for (requires_grad on several
+    groups at once): every combination selects its own mix of kernel variants (spike pass with / without the spike
+    means, per-item backward with / without the Z / theta path)."""
+    _check_against_oracle(case, mask)
 
 
 def test_embedding_mstep_closure_and_predict(golden_dir):
