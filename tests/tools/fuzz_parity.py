@@ -1,0 +1,49 @@
+"""Random small problems (shapes, kernel mixes, lengthscales, rates, trial lengths) through the engine and the oracle:
+a sweep beyond the fixed cases of tests/test_gpu_parity.py.  usage: python tests/tools/fuzz_parity.py [cases] [seed]"""
+import os, sys
+sys.path.insert(0, os.path.join(os.path.dirname(__file__), "..", ".."))
+sys.path.insert(0, os.path.join(os.path.dirname(__file__), ".."))
+import numpy as np
+import torch
+from helpers import rel_err
+from oracle import svgpfa_oracle as orc
+from svgpfa_amd.engine import engine_from_problem
+from svgpfa_amd.utils import synthetic
+
+n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 40
+rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
+worst = {"scalar": 0.0, "array": 0.0}
+for c in range(n_cases):
+    K = int(rng.integers(1, 7))
+    case = dict(R=int(rng.integers(1, 6)), N=int(rng.integers(1, 41)), K=K,
+                M=[int(rng.integers(1, 49)) for _ in range(K)],
+                kernels=[synthetic.RBF if rng.random() < 0.5 else synthetic.PERIODIC for _ in range(K)],
+                n_quad=int(rng.integers(8, 120)), rate=float(np.exp(rng.uniform(np.log(0.5), np.log(400.0)))),
+                trial_len=float(rng.uniform(0.5, 8.0)), seed=int(rng.integers(0, 1 << 30)), jitter=1.0, reg=1e-3)
+    prob = synthetic.make_problem(**case)
+    for k in range(K):            # lengthscales from short (pair-loop fallback) to long
+        prob["theta"][k][0] = float(np.exp(rng.uniform(np.log(0.03), np.log(2.0)))) * case["trial_len"] ** 0.5
+    mask = int(rng.choice([15, 15, 1, 4, 8, 12, 6, 9]))
+    eng, P = engine_from_problem(prob)
+    shared, gm, gc, gz = eng.elbo(P["mean"], P["cholVecs"], P["C"], P["d"], mask)
+    eng.sync()
+    elbo, ell, kl, gC, gd, gth = eng.split_shared(shared)
+    ref = orc.elbo_and_grads(orc.from_numpy_problem(prob), mask)
+    es = max(abs(float(elbo) - float(ref["elbo"])) / max(1.0, abs(float(ref["elbo"]))),
+             abs(float(kl) - float(ref["kl"])) / max(1.0, abs(float(ref["kl"]))))
+    ea = 0.0
+    if mask & 1:
+        ea = max([ea] + [rel_err(gm[k].cpu().numpy(), ref["g_mean"][k].numpy()[:, :, 0]) for k in range(K)]
+                 + [rel_err(gc[k].cpu().numpy(), ref["g_cholVecs"][k].numpy()[:, :, 0]) for k in range(K)])
+    if mask & 2:
+        ea = max(ea, rel_err(gC.cpu().numpy(), ref["g_C"].numpy()), rel_err(gd.cpu().numpy(), ref["g_d"].numpy()))
+    if mask & 4:
+        ea = max([ea] + [rel_err(gth[k].cpu().numpy(), ref["g_theta"][k].numpy()) for k in range(K)])
+    if mask & 8:
+        ea = max([ea] + [rel_err(gz[k].cpu().numpy(), ref["g_Z"][k].numpy()[:, :, 0]) for k in range(K)])
+    worst["scalar"], worst["array"] = max(worst["scalar"], es), max(worst["array"], ea)
+    flag = "" if (es < 1e-9 and ea < 1e-7) else "   <-- OUT OF TOLERANCE"
+    print(f"case {c:3d} R{case['R']} N{case['N']} K{K} M{case['M']} mask {mask:2d} spikes {int(prob['spike_offsets'][-1]):6d} "
+          f"harm {eng.series_harmonics()}  scalar {es:.1e}  arrays {ea:.1e}{flag}", flush=True)
+    eng.close()
+print("worst", worst)
