@@ -51,8 +51,9 @@ __device__ __forceinline__ double grp4_sum(double x) {    // sum over the 4 lane
   return x;
 }
 
-// Stage one M x M matrix of the item (row-major, leading dimension M) into LDS, zero padded to MP x MP with rows padded to
-// LD.  U independent global loads per thread are in flight before the first LDS store (a plain element loop waits
+// Stage one LOWER-TRIANGULAR M x M matrix of the item (Linv or Vt; row-major, leading dimension M) into LDS, zero padded
+// to MP x MP with rows padded to LD.  The upper triangle is not fetched (its cache lines -- a quarter of them at M = 32,
+// three eighths at M = 64 -- hold zeros by construction).  U independent global loads per thread are in flight before the first LDS store (a plain element loop waits
 // for every load before its store: the staging of a 32 x 32 matrix by 128 threads was eight exposed memory latencies).
 // (U = 8 at M = 64 measured: k_item_bwd<4> 12.5 -> 14.0 ms at cfg5 -- the registers it takes cost more than the latency.)
 template <int NT, int U = 4>
@@ -63,7 +64,7 @@ __device__ __forceinline__ void stage_matrix(double* dst, const double* src, int
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       const int e = e0 + u * nth, i = e / MP, j = e % MP;
-      v[u] = (e < MP * MP && i < M && j < M) ? src[i * M + j] : 0.0;
+      v[u] = (e < MP * MP && i < M && j <= i) ? src[i * M + j] : 0.0;
     }
 #pragma unroll
     for (int u = 0; u < U; ++u) {
