@@ -281,7 +281,7 @@ def measured_traffic(config, variant, full_mask, prefix="k_spike<"):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--config", default="cfg3", choices=["cfg2", "cfg3", "cfg5"])
     ap.add_argument("--variant", default="all", choices=["all", "estep"])
