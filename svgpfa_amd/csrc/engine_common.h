@@ -26,8 +26,11 @@
 
 #define SV_FH 64                      // most harmonics of the periodic kernel's Fourier series used by the spike pass
 #define SV_FROWS 3                    // rows of the per-latent series table: c_n | g_n | e_n (kernels_spike.h)
-#define SV_SPL 8                      // spikes per lane in the spike pass (optionally 4, engine::spl)
-#define SV_SPIKE_CHUNK (64 * SV_SPL)  // largest number of spikes per wavefront work item
+#define SV_SPL 8                      // spikes per lane in the pair-by-pair spike pass
+#define SV_SPIKE_CHUNK (64 * SV_SPL)  // largest number of spikes per wavefront work item of that pass
+#define SV_CLS_MAXMEM 16              // latents per class of the class path of the spike pass (one MFMA operand tile)
+#define SV_ACOLS (4 * (SV_FH + 1))    // columns of one A-moment row: [harmonic][cos | sin | t cos | t sin]
+#define SV_WCOLS (2 * (SV_FH + 1))    // columns of one W row: [harmonic][cos | sin]
 
 struct LatentMeta {
   int M, P, ktype, nth;
@@ -59,8 +62,33 @@ struct SpikeChunk {
   int trial;
   int count;
   long long start;  // global spike index of the first spike of the chunk
-  int split;        // bit 0: piece of an oversize (trial, neuron) segment; bit 1: the first segment continues the previous chunk's last
+  int split;        // bit 0: piece of an oversize (trial, neuron) segment; bit 1: the first segment continues the previous
+                    // chunk's last; bit 2: the last segment continues in the next chunk
   int neuron;       // that neuron (split chunks only)
+};
+
+// ---- class path of the spike pass (kernels_spike_cls.h).  Static per engine: a ROW is one (trial, neuron) segment, one
+// half of a segment (cut to fill the trial's tiles), or a piece of an oversize segment (> SV_SPIKE_CHUNK spikes, the same
+// threshold as the pair-by-pair pass); a TILE is <= 64 rows of one trial, sorted by length; the spike times of a tile are
+// stored transposed (tt[tt_off + i * 64 + row] = i-th spike of the row) so that the per-lane loops load coalesced.
+struct SpikeRow {
+  int len;
+  int neuron;
+  int kind;         // 0 whole segment (dC -> plane A, plane B cleared), 1 first half (-> A), 2 second half (-> B), 3 oversize piece (-> slot)
+  int slot;         // kind 3: index into the split list
+};
+struct SpikeTile {
+  int trial, nrows, maxlen, row0;
+  long long tt_off;
+};
+// Classes of latents that share the angular frequency of their cosine series; rebuilt with every kernel build.
+struct SpikeClassTab {
+  int ncls;
+  int type[SV_MAX_K];                    // SV_RBF / SV_PERIODIC
+  int nmem[SV_MAX_K];
+  int mem[SV_MAX_K][SV_CLS_MAXMEM];      // member latents
+  int cls_of[SV_MAX_K];                  // class of a latent, or -1: pair by pair in every trial
+  int slot_of[SV_MAX_K];                 // its index among the members
 };
 
 // Everything a kernel needs, passed by value (fits well inside the kernarg segment).
@@ -97,6 +125,21 @@ struct EngineView {
   double* gCspk;                                   // [R][N][K] spike part of dC per trial (segment, or its first part)
   double* gCspkB;                                  // [R][N][K] second part of segments cut by a chunk boundary (else 0)
   double* splitPart;                               // [nchunks][K] spike part of dC of split chunks
+  // class path (kernels_spike_cls.h)
+  SpikeClassTab* cls;                              // device copy of the class table
+  double* cls_t0; double* cls_sc; int* cls_H;      // [class][R]: phase origin, quarter turns per unit time, harmonics (-1: pair loop)
+  int* ser;                                        // [R][K]: 1 = the class path serves this (trial, latent), 0 = the pair loop
+  int nrows, ntiles, nsplitS;
+  const SpikeRow* rows;
+  const SpikeTile* tiles;                          // contiguous per trial
+  const int* tile_first;                           // R+1
+  const int* tile_order;                           // tiles, longest first (work order of k_spike_cls)
+  const double* tt;                                // transposed spike times of the tiles
+  const int* splitS_neuron; const int* splitS_trial;   // oversize pieces of the class path
+  double* splitS;                                  // [nsplitS][K]
+  double* Apart;                                   // [ntiles][K][SV_ACOLS] A-moment partials
+  double* Wb;                                      // [R][K][SV_WCOLS] posterior-mean weights on the harmonics
+  double* P0t; double* P1t; double* Tt;            // [R][sumM] x 2, [R][K][2]: spike sums of class-path items
   double* muspk;                                   // [K][S] (stats API only)
   double* varspk;                                  // [K][S] (stats API only)
   double* gmuspk; double* gvarspk;                 // [K][S] adjoints at the spikes (svgpfa_latent_stats_backward only)

@@ -28,14 +28,47 @@
 // up to one bank (the old stride MP + 2 cost a 2-way conflict on every transposed ds_read_b64)
 __host__ __device__ constexpr int sv_tr_stride(int MP) { return ((MP + 14) / 32) * 32 + 17; }
 
-// LDS of one block (doubles).  The transpose scratch of phase 1 and the Gt / At matrix of phase 2 share one region:
-// at the north-star shape (NT = 2, 2 waves) a block needs 34 KB, so four blocks (8 waves) stay resident per CU.
-// Above M = 32 the FULL variant keeps D in a buffer of its own (Vt stays staged: a block is alone on its CU there, and a
-// second staging phase is an exposed memory latency).
-__host__ __device__ constexpr size_t sv_item_bwd_lds_doubles(int NT, int NWB, bool full = true) {
+// LDS layout of one block (offsets in doubles) -- ONE constexpr function shared by the kernel (which places its buffers with
+// it) and the host (which sizes the launch with it), so the two cannot disagree.  The transpose scratch of phase 1 and the
+// Gt / At matrix of phase 2 share one region: at the north-star shape (NT = 2, 2 waves) a block needs 34 KB, so four
+// blocks (8 waves) stay resident per CU.  Above M = 32 the FULL variant keeps D in a buffer of its own (Vt stays staged: a
+// block is alone on its CU there, and a second staging phase is an exposed memory latency).
+struct ItemBwdLayout {
+  size_t Li, Vl, S, ul, al, zl, gt, gs, gq, gzq, szl, czl, gvs, tred, redz, redt, thq, p1l, cvd, tpl, Dl, total;
+};
+__host__ __device__ constexpr ItemBwdLayout sv_item_bwd_layout(int NT, int NWB, bool full) {
   const size_t MP = 16 * NT, LD = MP + 2, L2 = sv_tr_stride(16 * NT);
-  const size_t S = (NWB * 16 * L2 > MP * LD) ? NWB * 16 * L2 : MP * LD;
-  return 2 * MP * LD + S + 11 * MP + NWB * 16 + NWB * 2 + NT * MP + 2 * NT + 16 + ((NT >= 3 && full) ? MP * LD : 0);
+  const size_t SZ = ((size_t)NWB * 16 * L2 > MP * LD) ? (size_t)NWB * 16 * L2 : MP * LD;
+  const bool dsep = NT >= 3 && full;
+  ItemBwdLayout o{};
+  size_t p = 0;
+  o.Li = p; p += MP * LD;          // Linv
+  o.Vl = p; p += MP * LD;          // Vt (M <= 32, FULL: D = Linv^T (Vt Vt^T - I) during phase 1); later C
+  o.S = p; p += SZ;                // phase 1: per-wave transpose scratch; then Gt summed over the waves (rows padded to LD), later At
+  o.ul = p; p += MP;               // ut
+  o.al = p; p += MP;               // a = Linv^T ut
+  o.zl = p; p += MP;               // Z
+  o.gt = p; p += MP;
+  o.gs = p; p += MP;
+  o.gq = p; p += MP;               // quadrature part of the adjoint of ut
+  o.gzq = p; p += MP;              // quadrature part of dZ (direct)
+  o.szl = p; p += MP;              // sin of the inducing-point phases (periodic)
+  o.czl = p; p += MP;              // cos
+  o.gvs = p; p += (size_t)NWB * 16;
+  o.tred = p; p += (size_t)NWB * 2;
+  o.redz = p; p += (size_t)NT * MP;   // per-panel row sums of the dZ contraction
+  o.redt = p; p += 2 * (size_t)NT;    // per-panel dtheta partials
+  o.thq = p; p += 8;               // quadrature part of dtheta (direct), 2 used
+  o.p1l = p; p += MP;              // spike partial sums P1 of the trial
+  o.cvd = p; p += MP;              // 1 / diag(L_S)
+  o.tpl = p; p += 8;               // spike-direct theta partials of the trial, 2 used
+  o.Dl = dsep ? p : o.Vl;          // D: its own MP x LD buffer above M = 32 (FULL), else in Vt's place
+  if (dsep) p += MP * LD;
+  o.total = p;
+  return o;
+}
+__host__ __device__ constexpr size_t sv_item_bwd_lds_doubles(int NT, int NWB, bool full = true) {
+  return sv_item_bwd_layout(NT, NWB, full).total;
 }
 
 // ---- phase 3 -------------------------------------------------------------------------------------------------------
@@ -192,8 +225,13 @@ __global__ __launch_bounds__(256) void k_fin_items(EngineView ev, unsigned mask,
 // Inputs of phase 2 that are complete when the kernel starts: the spike partial sums of the trial (fixed chunk order;
 // thread j < M owns inducing point j) -> gs = s2 P0, p1l = P1; the trial's spike-direct theta partials -> tpl; 1 / diag(L_S)
 // -> cvd.  Statistics mode: the spike term arrives through the segment-1 adjoints, there is nothing to gather.
+#ifdef SV_GATHER_NOINLINE     // diagnosis builds only (tests/tools/gather_early_diag.py)
+#define SV_GATHER_ATTR __attribute__((noinline))
+#else
+#define SV_GATHER_ATTR __forceinline__
+#endif
 template <int MP>
-__device__ __forceinline__ void gather_item_inputs(const EngineView& ev, const LatentMeta& m, const LatentPtrs& pt, int r,
+__device__ SV_GATHER_ATTR void gather_item_inputs(const EngineView& ev, const LatentMeta& m, const LatentPtrs& pt, int r,
                                                    int k, unsigned mask, bool want_zt, double s2, double* gs, double* p1l,
                                                    double* cvd, double* gt, double* tpl) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, NWB = blockDim.x >> 6, M = m.M;
@@ -250,30 +288,30 @@ __device__ void item_bwd_body(const EngineView& ev, const int r, const int k, co
   const int item = r * ev.K + k;
   const LatentMeta m = ev.meta[k];
   const int M = m.M, Q = ev.Q, K = ev.K;
-  const size_t SZ = ((size_t)NWB * 16 * L2S > (size_t)MP * LD) ? (size_t)NWB * 16 * L2S : (size_t)MP * LD;
-  double* Li = sm;                    // MP*LD  Linv
-  double* Vl = Li + MP * LD;          // MP*LD  Vt (M <= 32, FULL: D = Linv^T (Vt Vt^T - I) during phase 1); later C
-  double* S = Vl + MP * LD;           // SZ     phase 1: per-wave transpose scratch; then Gt summed over the waves
-  double* Gl = S;                     //        (symmetric, rows padded to LD: phase 2's Gt, later At)
-  double* ul = S + SZ;                // MP     ut
-  double* al = ul + MP;               // MP     a = Linv^T ut
-  double* zl = al + MP;               // MP     Z
-  double* gt = zl + MP;               // MP
-  double* gs = gt + MP;               // MP
-  double* gq = gs + MP;               // MP     quadrature part of the adjoint of ut
-  double* gzq = gq + MP;              // MP     quadrature part of dZ (direct)
-  double* szl = gzq + MP;             // MP     sin of the inducing-point phases (periodic)
-  double* czl = szl + MP;             // MP     cos
-  double* gvs = czl + MP;             // NWB*16
-  double* tred = gvs + NWB * 16;      // NWB*2
-  double* redz = tred + NWB * 2;      // NT*MP  per-panel row sums of the dZ contraction
-  double* redt = redz + NT * MP;      // NT*2   per-panel dtheta partials
-  double* thq = redt + 2 * NT;        // 2      quadrature part of dtheta (direct)
-  double* p1l = thq + 8;              // MP     spike partial sums P1 of the trial
-  double* cvd = p1l + MP;             // MP     1 / diag(L_S)
-  double* tpl = cvd + MP;             // 2      spike-direct theta partials of the trial
+  const ItemBwdLayout lay = sv_item_bwd_layout(NT, NWB, FULL);   // buffer meanings: see the layout function
+  double* Li = sm + lay.Li;
+  double* Vl = sm + lay.Vl;
+  double* S = sm + lay.S;
+  double* Gl = S;                     // (symmetric, rows padded to LD: phase 2's Gt, later At)
+  double* ul = sm + lay.ul;
+  double* al = sm + lay.al;
+  double* zl = sm + lay.zl;
+  double* gt = sm + lay.gt;
+  double* gs = sm + lay.gs;
+  double* gq = sm + lay.gq;
+  double* gzq = sm + lay.gzq;
+  double* szl = sm + lay.szl;
+  double* czl = sm + lay.czl;
+  double* gvs = sm + lay.gvs;
+  double* tred = sm + lay.tred;
+  double* redz = sm + lay.redz;
+  double* redt = sm + lay.redt;
+  double* thq = sm + lay.thq;
+  double* p1l = sm + lay.p1l;
+  double* cvd = sm + lay.cvd;
+  double* tpl = sm + lay.tpl;
   constexpr bool DSEP = NT >= 3 && FULL;   // D in its own buffer
-  double* Dl = DSEP ? tpl + 8 : Vl;   // MP*LD  D
+  double* Dl = sm + lay.Dl;
   const KPar p = make_kpar(m, ev.theta + 2 * k);
   const long long base = m.offMM + (long long)r * M * M;
   const long long vbase = m.offM + (long long)r * M;
@@ -287,13 +325,18 @@ __device__ void item_bwd_body(const EngineView& ev, const int r, const int k, co
     zl[tid] = 0.0;
   }
   if (tid < MP) al[tid] = (tid < M) ? ev.a[vbase + tid] : 0.0;
-  // The gather of phase 2's inputs runs HERE, beside the staging of the factors, up to M = 32: between the phases, where
-  // the values are used, its memory latency was exposed (12 us of the kernel at the north-star size).  Above M = 32 it
-  // stays between the phases: with the helper inlined in front of phase 1, the FULL variant there (256 VGPRs plus AGPR
-  // spills, D in its own buffer) returned wrong sums, while the same source with the helper kept out of line
-  // (noinline) is correct -- a code-generation matter of that one instantiation, not of the placement; the arrangement
-  // the parity tests have always covered is kept for it (cases M = 33, 40, 48, 64 x all masks in test_gpu_parity.py).
-  constexpr bool GATHER_EARLY = NT <= 2;
+  // The gather of phase 2's inputs runs HERE, beside the staging of the factors: between the phases, where the values are
+  // used, its memory latency was exposed (12 us of the kernel at the north-star size).  (Round 2 kept it between the phases
+  // above M = 32 after an uncommitted intermediate version returned wrong sums there.  That did not reproduce on the
+  // committed source: this arrangement, inlined or not, at -O3 and -O2, passes every M > 32 case x mask against the oracle
+  // (tests/tools/gather_early_diag.*), and its ISA around the gather is faithful -- DESIGN.md section 9.  What the episode
+  // showed is how easily the kernel's hand-counted LDS offsets and the host's size formula drift apart: both now come from
+  // sv_item_bwd_layout.)  SV_GATHER_LATE: diagnosis builds with the old placement.
+#ifdef SV_GATHER_LATE
+  constexpr bool GATHER_EARLY = false;
+#else
+  constexpr bool GATHER_EARLY = true;
+#endif
   if (GATHER_EARLY) gather_item_inputs<MP>(ev, m, pt, r, k, mask, want_zt, p.s2, gs, p1l, cvd, gt, tpl);
 
   if (want_lat) {

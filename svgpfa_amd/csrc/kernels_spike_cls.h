@@ -1,0 +1,449 @@
+// Spike-time pass, class path: the kernels' cosine series (kernels_spike.h header: periodic = Jacobi-Anger, RBF = the
+// periodised Gaussian over the trial's window) turn every sum over spikes the ELBO needs into linear functions of
+// trigonometric moments of the spikes.  The weight of a spike in those moments is c_s = C[n_s, k] -- a function of the
+// spike's NEURON only -- so the moments factor through the UNWEIGHTED per-(trial, neuron) sums
+//     U_c[n][nu] = sum_{s in (trial, neuron nu)} cos(n theta_s),   U_s[n][nu] = ... sin,   (periodic: t_s cos, t_s sin too)
+//     A_n^(k) = sum_nu C[nu, k] U_c[n][nu]                      (a [K_c x N] . [N x NV (H + 1)] product per trial: f64 MFMA)
+//     dC[nu, k] += s2 sum_n c_n (Abar_n U_c[n][nu] + Bbar_n U_s[n][nu])
+// and U depends on the data and the angular frequency only: all latents that share a frequency (a CLASS) share it.
+//   * periodic latents with the same period form a class;
+//   * RBF latents form classes by lengthscale (within a factor 2 of the class's longest): the periodisation identity holds
+//     for every period L >= |W| + sqrt(41.5 / h), so the class uses ONE L per trial (from its longest lengthscale and the
+//     window over all its members' inducing points); a member's series then runs to its own H_k (~ 1.5 L / l_k).
+// A spike then costs 6 fp64 instructions per harmonic and CLASS (8 with the time-weighted moments) instead of 8..10 per
+// harmonic and LATENT (round 2's spike_body_series), and there is no per-spike embedding gather at all.
+//
+// Kernels (launched in this order, all on the spike stream):
+//   k_spike_classes (with the kernel build)  class table; per (trial, class) window / period / harmonics; ser[r][k]
+//   k_spike_pre     (r, k)        W = s2 c_n (Abar_n, Bbar_n): the posterior-mean weights a projected on the harmonics
+//                                 (only when dC is wanted; needs a = Kzz^-1 m from k_prep)
+//   k_spike_cls     (tile, class) U for the tile's <= 64 rows (lane = row = one (trial, neuron) segment or half of one,
+//                                 harmonics in registers), A-moment partials by f64 MFMA through an LDS transpose, dC rows
+//   k_spike_comb    (r, k)        sums the tiles' partials (fixed order) and combines them per inducing point:
+//                                 P0, P1, T of the item -- what k_item_bwd's gather reads
+// (trial, latent) items the series does not serve (short lengthscales, very few inducing points) keep the pair-by-pair
+// pass of kernels_spike.h; ser[r][k] says which.
+// Replaces the reference's K*R Python loop of kernelsMatricesStore.py:208-221, svPosteriorOnLatents.py:265-300 and
+// svEmbedding.py:137-144; Ktz at the spikes is never materialised.
+#pragma once
+#include "engine_common.h"
+#include "kernels_mfma.h"
+
+// ------------------------------------------------------------------------------------------------ k_spike_classes
+// grid = ceil(R / 4) blocks of 256 threads: every block rebuilds the (tiny) class table in LDS, one wavefront per trial
+// then fills the per-trial entries.  Runs behind k_build_reg (needs its Z / theta snapshot and the periodic series tables).
+__global__ __launch_bounds__(256) void k_spike_classes(EngineView ev) {
+  __shared__ SpikeClassTab tab;
+  __shared__ double par[SV_MAX_K];     // per latent: RBF h = 1 / (2 l^2); periodic 4 / period
+  __shared__ double lead[SV_MAX_K];    // per class: RBF h of the leader (its longest lengthscale); periodic 4 / period
+  __shared__ int clsH[SV_MAX_K], clsM[SV_MAX_K];   // per class: periodic harmonics; sum of the members' M
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, K = ev.K, R = ev.R;
+  if (tid == 0) {
+    tab.ncls = 0;
+    for (int k = 0; k < K; ++k) {
+      tab.cls_of[k] = -1;
+      tab.slot_of[k] = 0;
+      const LatentMeta m = ev.meta[k];
+      const KPar p = make_kpar(m, ev.theta + 2 * k);
+      par[k] = (m.ktype == SV_RBF) ? p.h : 4.0 * p.ip;
+    }
+    for (int k = 0; k < K; ++k) {                      // periodic: one class per distinct period
+      if (ev.meta[k].ktype != SV_PERIODIC) continue;
+      const int H = ev.fourH[k];
+      if (H < 0) continue;                             // short lengthscale / few inducing points: pair by pair
+      int g = -1;
+      for (int c = 0; c < tab.ncls; ++c)
+        if (tab.type[c] == SV_PERIODIC && lead[c] == par[k] && tab.nmem[c] < SV_CLS_MAXMEM) { g = c; break; }
+      if (g < 0) {
+        g = tab.ncls++;
+        tab.type[g] = SV_PERIODIC;
+        tab.nmem[g] = 0;
+        lead[g] = par[k];
+        clsH[g] = 0;
+        clsM[g] = 0;
+      }
+      tab.cls_of[k] = g;
+      tab.slot_of[k] = tab.nmem[g];
+      tab.mem[g][tab.nmem[g]++] = k;
+      clsH[g] = H > clsH[g] ? H : clsH[g];
+      clsM[g] += ev.meta[k].M;
+    }
+    if (ev.rbf_series) {                               // RBF: greedy classes from the longest lengthscale down
+      for (;;) {
+        int ld = -1;
+        for (int k = 0; k < K; ++k)
+          if (ev.meta[k].ktype == SV_RBF && tab.cls_of[k] < 0 && par[k] > 0.0 && par[k] < 1e300 && (ld < 0 || par[k] < par[ld]))
+            ld = k;
+        if (ld < 0) break;
+        const int g = tab.ncls++;
+        tab.type[g] = SV_RBF;
+        tab.nmem[g] = 0;
+        lead[g] = par[ld];
+        clsH[g] = 0;
+        clsM[g] = 0;
+        for (int k = 0; k < K; ++k)
+          if (ev.meta[k].ktype == SV_RBF && tab.cls_of[k] < 0 && par[k] > 0.0 && par[k] <= 4.0 * par[ld] &&
+              tab.nmem[g] < SV_CLS_MAXMEM) {
+            tab.cls_of[k] = g;
+            tab.slot_of[k] = tab.nmem[g];
+            tab.mem[g][tab.nmem[g]++] = k;
+            clsM[g] += ev.meta[k].M;
+          }
+      }
+    }
+  }
+  __syncthreads();
+  if (blockIdx.x == 0) {
+    int* dst = (int*)ev.cls;
+    const int* src = (const int*)&tab;
+    for (int i = tid; i < (int)(sizeof(SpikeClassTab) / sizeof(int)); i += 256) dst[i] = src[i];
+  }
+  const int r = blockIdx.x * 4 + wave;
+  if (r >= R) return;
+  for (int k = lane; k < K; k += 64)
+    if (tab.cls_of[k] < 0) ev.ser[r * K + k] = 0;
+  const double PI = 3.14159265358979323846;
+  for (int g = 0; g < tab.ncls; ++g) {
+    double t0 = 0.0, sc = lead[g];
+    int H = clsH[g];
+    if (tab.type[g] == SV_RBF) {
+      // window of the (trial, class): all spike times of the trial and all inducing points of the members
+      double lo = ev.spk_lo[r], hi = ev.spk_hi[r];
+      for (int s = 0; s < tab.nmem[g]; ++s) {
+        const LatentMeta m = ev.meta[tab.mem[g][s]];
+        if (lane < m.M) {
+          const double zj = ev.Zs[m.offM + (long long)r * m.M + lane];
+          lo = fmin(lo, zj);
+          hi = fmax(hi, zj);
+        }
+      }
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) {
+        lo = fmin(lo, __shfl_xor(lo, o, 64));
+        hi = fmax(hi, __shfl_xor(hi, o, 64));
+      }
+      const double L = (hi - lo) + sqrt(41.5 / lead[g]);     // wrapped copies below e^-41.5 = 1e-18 for every member
+      H = 0;
+      for (int s = 0; s < tab.nmem[g]; ++s) {
+        const double q = PI * PI / (par[tab.mem[g][s]] * L * L);   // c_n ~ exp(-q n^2)
+        const double nmax = sqrt(46.0 / q);                        // n c_n / c_0 < 64 e^-46 = 7e-19 beyond
+        if (!(nmax < (double)SV_FH)) H = SV_FH + 1;
+        else H = ((int)nmax + 1 > H) ? (int)nmax + 1 : H;
+      }
+      // per-spike cost of the series (6 instructions per harmonic, rows ~60 % full) against the members' pair loops
+      if (H > SV_FH || 10 * (H + 2) > 21 * clsM[g]) H = -1;
+      t0 = lo;
+      sc = 4.0 / L;
+    }
+    if (lane == 0) {
+      ev.cls_t0[(long long)g * R + r] = t0;
+      ev.cls_sc[(long long)g * R + r] = sc;
+      ev.cls_H[(long long)g * R + r] = H;
+    }
+    if (lane < tab.nmem[g]) ev.ser[r * K + tab.mem[g][lane]] = H >= 0 ? 1 : 0;
+  }
+}
+
+// Series coefficients of latent k on the (trial, class) period: rows c_n | g_n | e_n for n = 0 .. H into cf (LDS,
+// 3 x (SV_FH + 1)); periodic latents copy their table (k_build_reg / periodic_series), RBF latents evaluate
+//   c_n = (2) sqrt(pi / h) / L exp(-pi^2 n^2 / (h L^2)),  g_n = -dc_n/dh = c_n (1/(2h) - pi^2 n^2 / (h^2 L^2)),
+//   e_n = n w c_n / (2 h),  w = 2 pi / L,  L = 4 / sc.     All 64 lanes call it; the caller synchronises.
+__device__ __forceinline__ void cls_coefficients(const EngineView& ev, int k, int ktype, double h, double sc, int H,
+                                                 double* cf) {
+  const int lane = threadIdx.x & 63;
+  constexpr int NF = SV_FH + 2;
+  if (ktype == SV_PERIODIC) {
+    const double* tab = ev.four + (size_t)k * SV_FROWS * NF;
+    for (int n = lane; n <= H; n += 64) {
+      cf[n] = tab[n];
+      cf[(SV_FH + 1) + n] = tab[NF + n];
+      cf[2 * (SV_FH + 1) + n] = tab[2 * NF + n];
+    }
+  } else {
+    const double PI = 3.14159265358979323846;
+    const double L = 4.0 / sc, q = PI * PI / (h * L * L), w = 2.0 * PI / L, c0 = sqrt(PI / h) / L;
+    for (int n = lane; n <= H; n += 64) {
+      const double cn = (n ? 2.0 : 1.0) * c0 * exp(-q * (double)n * (double)n);
+      cf[n] = cn;
+      cf[(SV_FH + 1) + n] = cn * (0.5 / h - q * (double)n * (double)n / h);
+      cf[2 * (SV_FH + 1) + n] = (double)n * w * cn * (0.5 / h);
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ k_spike_pre
+// W[r][k][2 n + {0, 1}] = s2 c_n (Abar_n, Bbar_n),  Abar_n = sum_j a_j cos(n phi_j),  Bbar_n = sum_j a_j sin(n phi_j),
+// phi_j = w (z_j - t0): the posterior mean at a spike is mu_s = sum_n [cos(n theta_s) W_2n + sin(n theta_s) W_2n+1].
+// Entries beyond H are written as zeros (k_spike_cls works in whole register passes).  grid = R K blocks of 64 threads.
+__global__ __launch_bounds__(64) void k_spike_pre(EngineView ev) {
+  __shared__ double red[16 * 65];
+  __shared__ double cf[3 * (SV_FH + 1)];
+  const int item = blockIdx.x, lane = threadIdx.x, K = ev.K, R = ev.R;
+  if (!ev.ser[item]) return;
+  const int r = item / K, k = item % K;
+  const LatentMeta m = ev.meta[k];
+  const int g = ev.cls->cls_of[k];
+  const int H = ev.cls_H[(long long)g * R + r];
+  const double sc = ev.cls_sc[(long long)g * R + r], t0 = ev.cls_t0[(long long)g * R + r];
+  const KPar p = make_kpar(m, ev.theta + 2 * k);
+  cls_coefficients(ev, k, m.ktype, p.h, sc, H, cf);
+  double aj = 0.0, sphi = 0.0, cphi = 1.0;
+  if (lane < m.M) {
+    aj = ev.a[m.offM + (long long)r * m.M + lane];
+    sv_sincos_quarter((ev.Zs[m.offM + (long long)r * m.M + lane] - t0) * sc, sphi, cphi);
+  }
+  double* W = ev.Wb + (long long)item * SV_WCOLS;
+  for (int c = 2 * (H + 1) + lane; c < SV_WCOLS; c += 64) W[c] = 0.0;
+  double cj = 1.0, sj = 0.0;
+  for (int nb = 0; nb <= H; nb += 8) {
+    __syncthreads();                       // cf ready (first round); the previous round's rows are consumed
+#pragma unroll
+    for (int jj = 0; jj < 8; ++jj) {
+      red[(2 * jj + 0) * 65 + lane] = aj * cj;
+      red[(2 * jj + 1) * 65 + lane] = aj * sj;
+      const double tq = cj * cphi - sj * sphi;
+      sj = fma(sj, cphi, cj * sphi);
+      cj = tq;
+    }
+    __syncthreads();
+    // transposed reduction: lane (v, quarter) sums 16 of the 64 lane-partials of row v, the quarters are added by shuffles
+    const int v = lane & 15, qd = lane >> 4;
+    double sum = 0.0;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) sum += red[v * 65 + qd * 16 + e];
+    sum += __shfl_xor(sum, 16, 64);
+    sum += __shfl_xor(sum, 32, 64);
+    const int n = nb + (lane >> 1);
+    if (lane < 16 && n <= H) W[2 * n + (lane & 1)] = p.s2 * cf[n] * sum;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ k_spike_cls
+// One register pass over the rows' spikes: harmonics h0 .. h0 + HB - 1 of every row (lane) of the tile.
+//   acc[NV n + 0] = sum_s cos((h0 + n) theta_s)   [+1] = sin   ([+2], [+3]: the same weighted by t_s, NV = 4)
+// (cos, sin) of the multiples by rotation (error ~ n ulp); a later pass starts from one direct sincos of h0 theta.
+template <int NV, int HB>
+__device__ __forceinline__ void cls_pass(const double* __restrict__ tt, int maxlen, int len, int lane, double t0,
+                                         double sc, int h0, double (&acc)[NV * HB]) {
+#pragma unroll
+  for (int c = 0; c < NV * HB; ++c) acc[c] = 0.0;
+  double tn = (maxlen > 0) ? tt[lane] : 0.0;          // transposed times: row = lane, spike i at [i][lane]
+  for (int i = 0; i < maxlen; ++i) {
+    const double t = tn;
+    if (i + 1 < maxlen) tn = tt[(long long)(i + 1) * 64 + lane];     // next spike's time one iteration ahead
+    if (i < len) {
+      const double ph = (t - t0) * sc;
+      double s1, c1, cn = 1.0, sn = 0.0;
+      sv_sincos_quarter(ph, s1, c1);
+      if (h0 > 0) sv_sincos_quarter(ph * (double)h0, sn, cn);
+#pragma unroll
+      for (int n = 0; n < HB; ++n) {
+        acc[NV * n + 0] += cn;
+        acc[NV * n + 1] += sn;
+        if (NV == 4) {
+          acc[NV * n + 2] = fma(t, cn, acc[NV * n + 2]);
+          acc[NV * n + 3] = fma(t, sn, acc[NV * n + 3]);
+        }
+        const double tq = cn * c1 - sn * s1;          // (cos, sin) of (n + 1) theta: rotation by theta
+        sn = fma(sn, c1, cn * s1);
+        cn = tq;
+      }
+    }
+  }
+}
+
+// What follows a pass, 16 columns at a time: the rows' sums go through a (swizzled, conflict-free) LDS tile
+// Ut[row][16] so that the tile's partial A-moments  Apart[member][col] = sum_rows C[neuron(row), member] U[row][col]
+// come out of 16 v_mfma_f64_16x16x4_f64 (A operand: the gathered embedding weights cg, B operand: U); and, DC, the
+// rows' own dC partials  dcl[member][row] += sum_cols U[row][col] W[member][col]  on the VALU (W is wave-uniform).
+template <int NV, int HB, bool DC>
+__device__ __forceinline__ void cls_flush(const EngineView& ev, const double (&acc)[NV * HB], const double (&cg)[16],
+                                          const SpikeClassTab* __restrict__ cls, int g, int nmem, int tile, int r, int h0,
+                                          int H, double* Ut, double* dcl) {
+  const int lane = threadIdx.x, li = lane & 15, lg = lane >> 4, K = ev.K;
+  const int ncol = NV * (H + 1);           // valid columns of the class's moment rows
+#pragma unroll
+  for (int c0 = 0; c0 < NV * HB; c0 += 16) {
+    if (NV * h0 + c0 < ncol) {             // wave-uniform: whole chunks beyond the last harmonic are skipped
+#pragma unroll
+      for (int c = 0; c < 16; ++c) Ut[lane * 16 + (c ^ li)] = acc[c0 + c];
+      lds_wave_fence();
+      d4 D = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int row = 4 * i + lg;
+        D = __builtin_amdgcn_mfma_f64_16x16x4f64(cg[i], Ut[row * 16 + (li ^ (row & 15))], D, 0, 0, 0);
+      }
+      const int col = NV * h0 + c0 + li;
+      if (col < ncol) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int s = lg + 4 * q;        // f64 accumulator layout: register q holds row (lane >> 4) + 4 q
+          if (s < nmem) ev.Apart[((long long)tile * K + cls->mem[g][s]) * SV_ACOLS + col] = D[q];
+        }
+      }
+      lds_wave_fence();                    // the tile is free for the next chunk
+    }
+  }
+  if (DC) {
+    for (int s = 0; s < nmem; ++s) {
+      const double* __restrict__ Wk = ev.Wb + ((long long)r * K + cls->mem[g][s]) * SV_WCOLS + 2 * h0;
+      double v = 0.0;
+#pragma unroll
+      for (int n = 0; n < HB; ++n) {
+        if (h0 + n <= SV_FH) {             // W rows are SV_FH + 1 harmonics long, zero beyond H
+          v = fma(acc[NV * n + 0], Wk[2 * n + 0], v);
+          v = fma(acc[NV * n + 1], Wk[2 * n + 1], v);
+        }
+      }
+      dcl[s * 64 + lane] = (h0 == 0) ? v : dcl[s * 64 + lane] + v;
+    }
+  }
+}
+
+template <int NV, bool DC>
+__device__ __forceinline__ void cls_item(const EngineView& ev, const double* __restrict__ C, const SpikeClassTab* cls,
+                                         int g, int tile, double* Ut, double* dcl) {
+  constexpr int HBM = (NV == 2) ? 24 : 16;          // largest register pass: 48 / 64 accumulators
+  const int lane = threadIdx.x, li = lane & 15, lg = lane >> 4, K = ev.K, R = ev.R;
+  const SpikeTile tl = ev.tiles[tile];
+  const int r = tl.trial;
+  const int H = ev.cls_H[(long long)g * R + r];
+  if (H < 0) return;                                 // this (trial, class) takes the pair loop
+  const double sc = ev.cls_sc[(long long)g * R + r], t0 = ev.cls_t0[(long long)g * R + r];
+  const int nmem = cls->nmem[g];
+  SpikeRow row{0, 0, 0, 0};
+  if (lane < tl.nrows) row = ev.rows[tl.row0 + lane];
+  // embedding weights in A-operand layout: cg[i] = C[neuron(row 4 i + lg)][member li]
+  double cg[16];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const int rw = 4 * i + lg;
+    const int nu = __shfl(row.neuron, rw, 64);
+    cg[i] = (rw < tl.nrows && li < nmem) ? C[(long long)nu * K + cls->mem[g][li]] : 0.0;
+  }
+  const double* __restrict__ tt = ev.tt + tl.tt_off;
+  for (int h0 = 0; h0 <= H; h0 += HBM) {
+    const int left = H + 1 - h0;
+    if (left > 16 && NV == 2) {
+      double acc[NV * 24];
+      cls_pass<NV, 24>(tt, tl.maxlen, row.len, lane, t0, sc, h0, acc);
+      cls_flush<NV, 24, DC>(ev, acc, cg, cls, g, nmem, tile, r, h0, H, Ut, dcl);
+    } else if (left > 8) {
+      double acc[NV * 16];
+      cls_pass<NV, 16>(tt, tl.maxlen, row.len, lane, t0, sc, h0, acc);
+      cls_flush<NV, 16, DC>(ev, acc, cg, cls, g, nmem, tile, r, h0, H, Ut, dcl);
+    } else {
+      double acc[NV * 8];
+      cls_pass<NV, 8>(tt, tl.maxlen, row.len, lane, t0, sc, h0, acc);
+      cls_flush<NV, 8, DC>(ev, acc, cg, cls, g, nmem, tile, r, h0, H, Ut, dcl);
+    }
+  }
+  if (DC && row.len > 0) {
+    // the row's dC partials: every (trial, neuron, latent) entry of BOTH planes is written on every pass -- a whole
+    // segment writes plane A and clears plane B, the halves of a cut segment write one plane each -- so the planes stay
+    // valid when an item changes between this path and the pair loop; pieces of an oversize segment go to their slot
+    for (int s = 0; s < nmem; ++s) {
+      const int k = cls->mem[g][s];
+      const double v = dcl[s * 64 + lane];
+      const long long o = ((long long)r * ev.N + row.neuron) * K + k;
+      if (row.kind == 0) {
+        ev.gCspk[o] = v;
+        ev.gCspkB[o] = 0.0;
+      } else if (row.kind == 1) {
+        ev.gCspk[o] = v;
+      } else if (row.kind == 2) {
+        ev.gCspkB[o] = v;
+      } else {
+        ev.splitS[(long long)row.slot * K + k] = v;
+      }
+    }
+  }
+}
+
+// Work item = (tile, class); the number of classes is only known on the device, so the grid is a fixed number of
+// single-wave blocks that stride over the items (tiles in the host's cost order, longest first).
+// FULL: Z / theta gradients wanted (periodic classes then carry the time-weighted moments); DC: dC wanted.
+template <bool FULL, bool DC>
+__global__ __launch_bounds__(64) void k_spike_cls(EngineView ev, const double* __restrict__ C) {
+  __shared__ double Ut[64 * 16];
+  __shared__ double dcl[DC ? SV_CLS_MAXMEM * 64 : 1];
+  const SpikeClassTab* cls = ev.cls;
+  const int ncls = cls->ncls;
+  const long long nitems = (long long)ev.ntiles * ncls;
+  for (long long w = blockIdx.x; w < nitems; w += gridDim.x) {
+    const int g = (int)(w % ncls), tile = ev.tile_order[w / ncls];
+    if (FULL && cls->type[g] == SV_PERIODIC) cls_item<4, DC>(ev, C, cls, g, tile, Ut, dcl);
+    else cls_item<2, DC>(ev, C, cls, g, tile, Ut, dcl);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ k_spike_comb
+// Per (trial, latent): the class's moments A_n, B_n (At_n, Bt_n) = the trial's tile partials added in tile order, then per
+// inducing point j (phase phi_j, harmonics by rotation), with Cc = cos(n phi_j) A_n + sin(n phi_j) B_n and
+// Ss = cos(n phi_j) B_n - sin(n phi_j) A_n (kernels_spike.h header):
+//   P0_j = sum_n c_n Cc,  P1_j = sum_n e_n Ss,  T0 = sum_j a_j sum_n g_n Cc,
+//   T1 (periodic) = sum_j a_j sum_n e_n [cos(n phi_j) Bt_n - sin(n phi_j) At_n - z_j Ss]
+// -> P0t / P1t [r][sum M], Tt [r][k][2]: what k_item_bwd's gather reads for this item.  grid = R K blocks of 64 threads.
+template <bool FULL>
+__global__ __launch_bounds__(64) void k_spike_comb(EngineView ev) {
+  __shared__ double Fs[SV_ACOLS];
+  __shared__ double cf[3 * (SV_FH + 1)];
+  const int item = blockIdx.x, lane = threadIdx.x, K = ev.K, R = ev.R;
+  if (!ev.ser[item]) return;
+  const int r = item / K, k = item % K;
+  const LatentMeta m = ev.meta[k];
+  const int M = m.M;
+  const int g = ev.cls->cls_of[k];
+  const int H = ev.cls_H[(long long)g * R + r];
+  const double sc = ev.cls_sc[(long long)g * R + r], t0 = ev.cls_t0[(long long)g * R + r];
+  const KPar p = make_kpar(m, ev.theta + 2 * k);
+  const bool TW = FULL && m.ktype == SV_PERIODIC;
+  const int NV = TW ? 4 : 2, ncol = NV * (H + 1);
+  cls_coefficients(ev, k, m.ktype, p.h, sc, H, cf);
+  const int tl0 = ev.tile_first[r], tl1 = ev.tile_first[r + 1];
+  for (int c = lane; c < ncol; c += 64) {
+    double s = 0.0;
+    for (int t = tl0; t < tl1; ++t) s += ev.Apart[((long long)t * K + k) * SV_ACOLS + c];
+    Fs[c] = s;
+  }
+  __syncthreads();
+  double t0acc = 0.0, t1acc = 0.0;
+  if (lane < M) {
+    const double zj = ev.Zs[m.offM + (long long)r * M + lane], aj = ev.a[m.offM + (long long)r * M + lane];
+    double sphi, cphi;
+    sv_sincos_quarter((zj - t0) * sc, sphi, cphi);
+    const double* cN = cf;
+    const double* gN = cf + (SV_FH + 1);
+    const double* eN = cf + 2 * (SV_FH + 1);
+    double cj = 1.0, sj = 0.0, P0 = 0.0, P1 = 0.0, d0 = 0.0, d1 = 0.0;
+    for (int n = 0; n <= H; ++n) {
+      const double An = Fs[n * NV + 0], Bn = Fs[n * NV + 1];
+      const double Cc = fma(cj, An, sj * Bn), Ss = fma(cj, Bn, -(sj * An));
+      P0 = fma(cN[n], Cc, P0);
+      if (FULL) {
+        const double en = eN[n];
+        P1 = fma(en, Ss, P1);
+        d0 = fma(gN[n], Cc, d0);
+        if (TW) d1 = fma(en, fma(cj, Fs[n * NV + 3], -(sj * Fs[n * NV + 2])) - zj * Ss, d1);
+      }
+      const double tq = cj * cphi - sj * sphi;
+      sj = fma(sj, cphi, cj * sphi);
+      cj = tq;
+    }
+    const long long o = (long long)r * ev.sumM + m.colM + lane;
+    ev.P0t[o] = P0;
+    if (FULL) {
+      ev.P1t[o] = P1;
+      t0acc = aj * d0;
+      t1acc = aj * d1;
+    }
+  }
+  if (FULL) {
+    const double ts0 = wave_sum(t0acc), ts1 = wave_sum(t1acc);
+    if (lane == 0) {
+      ev.Tt[(long long)item * 2 + 0] = ts0;
+      ev.Tt[(long long)item * 2 + 1] = ts1;
+    }
+  }
+}

@@ -1,0 +1,64 @@
+"""CPU tests of the code-generation guard (tests/tools/isa_exec_guard.py, run by __graft_entry__.build()).
+
+ROCm 7.2's compiler was caught placing a register-allocator copy of threadIdx.x at the top of a control-flow join block,
+in front of the `s_or_b64 exec` that re-enables the lanes -- k_item_bwd<3, true> then faulted / returned wrong sums for
+the wave that skipped the branch (profiles/r03_item_bwd_miscompile_evidence.txt).  The guard scans the device assembly
+of every build for that pattern."""
+import glob
+import os
+import sys
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(REPO, "tests", "tools"))
+
+BAD = """
+_Z10k_item_bwdILi3ELb1EEv:
+	s_and_saveexec_b64 s[2:3], vcc
+	s_xor_b64 s[6:7], exec, s[2:3]
+	v_mov_b32_e32 v0, s76
+	s_or_saveexec_b64 s[6:7], s[6:7]
+	s_xor_b64 exec, exec, s[6:7]
+	s_cbranch_execz .LBB17_405
+	v_add_u32_e32 v0, v100, v101
+.LBB17_405:
+	v_writelane_b32 v255, s56, 0
+	v_mov_b32_e32 v224, v154
+	s_nop 0
+	v_writelane_b32 v255, s57, 1
+	s_or_b64 exec, exec, s[6:7]
+	v_div_scale_f64 v[6:7], s[2:3], s[84:85], s[84:85], 1.0
+	s_endpgm
+"""
+GOOD = BAD.replace("\tv_mov_b32_e32 v224, v154\n", "").replace(
+    "\tv_div_scale_f64", "\tv_mov_b32_e32 v224, v154\n\tv_div_scale_f64")
+UNIFORM = BAD.replace("v_mov_b32_e32 v224, v154", "v_mov_b32_e32 v224, s12")     # splat of an SGPR: every lane equal anyway
+
+
+def _scan_text(tmp_path, text):
+    import isa_exec_guard
+    p = tmp_path / "k.s"
+    p.write_text(text)
+    return isa_exec_guard.scan(str(p))
+
+
+def test_guard_flags_the_copy_in_front_of_the_exec_restore(tmp_path):
+    found = _scan_text(tmp_path, BAD)
+    assert len(found) == 1 and found[0][1] == ".LBB17_405" and "v224, v154" in found[0][3]
+
+
+def test_guard_accepts_the_copy_behind_the_exec_restore(tmp_path):
+    assert _scan_text(tmp_path, GOOD) == []
+    assert _scan_text(tmp_path, UNIFORM) == []
+
+
+def test_last_build_is_clean():
+    """The device assembly kept by build() (build/*.s) shows no suspect join prologue.  build() refuses such a library;
+    this repeats the scan so that the round's CPU suite records it."""
+    import __graft_entry__ as ge
+    ge.build()
+    files = sorted(glob.glob(os.path.join(ge.BUILD_DIR, "*gfx950*.s")))
+    if not files:          # library built elsewhere (e.g. on the GPU box from a stale tree): rebuild to get the assembly
+        ge.build(force=True)
+        files = sorted(glob.glob(os.path.join(ge.BUILD_DIR, "*gfx950*.s")))
+    assert files, "build() kept no device assembly"
+    assert ge.check_isa(files) == []

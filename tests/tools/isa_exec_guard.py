@@ -1,0 +1,77 @@
+"""Scan AMDGPU assembly (hipcc -S --cuda-device-only) for the ROCm 7.2 / clang 22 code-generation defect found in round 3
+(DESIGN.md section 9): a register-allocator copy of a VGPR placed at the top of a control-flow JOIN block *in front of*
+the `s_or_b64 exec, exec, s[..]` that re-enables the lanes of the other branch.  The copy then runs under the mask of one
+branch only -- for a wave whose lanes all took the other branch, under exec = 0 -- and the copied value (in the case
+found: threadIdx.x inside k_item_bwd<3, true>) is garbage afterwards.
+
+A block is suspect when it is the target of an `s_cbranch_execz` (a join) and, between its label and its
+`s_or_b64 exec, exec, ...`, among nothing but scalar instructions and SGPR spills (v_writelane / v_readlane ignore EXEC and
+are legitimate there), it holds a vector-register copy (v_mov / v_accvgpr_read / v_accvgpr_write from a vector register).
+
+    python tests/tools/isa_exec_guard.py file.s [...]      exit status 1 if any suspect block is found
+"""
+import re
+import sys
+
+LABEL = re.compile(r"^(\.LBB\d+_\d+|[A-Za-z_][\w$.]*):")
+EXEC_RESTORE = re.compile(r"^\s*s_or_b64\s+exec,\s*exec,")
+EXECZ_TARGET = re.compile(r"^\s*s_cbranch_execz\s+(\.LBB\d+_\d+)")
+# what the register allocator puts at the top of a block: copies and spills
+COPY = re.compile(r"^\s*(v_mov_b32_e32|v_mov_b64_e32|v_accvgpr_write_b32|v_accvgpr_read_b32|v_accvgpr_mov_b32)\s+([av]\[?[\d:]+\]?),\s*([avs]\[?[\d:]+\]?)\s*$")
+PROLOGUE_OK = re.compile(r"^\s*(v_writelane_b32|v_readlane_b32|s_nop|s_mov_b32|s_mov_b64|s_waitcnt|s_load_\w+)\b")
+
+
+def scan(path):
+    with open(path) as fh:
+        lines = fh.read().split("\n")
+    join_targets = set()
+    func = None
+    for line in lines:
+        m = LABEL.match(line)
+        if m and not m.group(1).startswith(".L"):
+            func = m.group(1)
+        t = EXECZ_TARGET.match(line)
+        if t:
+            join_targets.add((func, t.group(1)))
+    findings = []
+    func, block, pending = None, None, []
+    for ln, line in enumerate(lines, 1):
+        m = LABEL.match(line)
+        if m:
+            name = m.group(1)
+            if not name.startswith(".L"):
+                func = name
+            block, pending = (name if (func, name) in join_targets else None), []
+            continue
+        if block is None:
+            continue
+        s = line.split(";", 1)[0]
+        if not s.strip() or s.lstrip().startswith("."):
+            continue
+        if EXEC_RESTORE.match(s):
+            for p in pending:
+                findings.append((func, block) + p)
+            block = None
+            continue
+        c = COPY.match(s)
+        if c and not c.group(3).startswith("s"):          # a copy FROM an SGPR is a uniform rematerialisation: harmless
+            pending.append((ln, s.strip()))
+            continue
+        if c or PROLOGUE_OK.match(s):
+            continue
+        block = None                                       # real code before any exec restore: not a join prologue
+    return findings
+
+
+def main(argv):
+    bad = 0
+    for path in argv:
+        for func, block, ln, ins in scan(path):
+            print(f"{path}:{ln}: {func} {block}: EXEC-dependent copy `{ins}` in front of the join block's exec restore")
+            bad += 1
+    print(f"{bad} suspect instruction(s)")
+    return 1 if bad else 0
+
+
+if __name__ == "__main__":
+    sys.exit(main(sys.argv[1:]))
