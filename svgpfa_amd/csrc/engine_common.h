@@ -80,6 +80,13 @@ struct SpikeRow {
 struct SpikeTile {
   int trial, nrows, maxlen, row0;
   long long tt_off;
+  int id, pad;      // index of the tile in trial order (the order of the partial-moment rows)
+};
+// What the class path needs to know about one (trial, latent) item: harmonics (-1: the pair-by-pair pass serves it), class,
+// phase origin and quarter turns per unit time of the (trial, class).
+struct SpikeItem {
+  int H, cls;
+  double t0, sc;
 };
 // Classes of latents that share the angular frequency of their cosine series; rebuilt with every kernel build.
 struct SpikeClassTab {
@@ -107,6 +114,7 @@ struct EngineView {
   const double* spk_lo;       // R : earliest / latest spike of each trial (window of the RBF kernel's cosine series)
   const double* spk_hi;
   int rbf_series;             // 1: the spike pass may evaluate RBF kernels through their periodised series (default)
+  int per_series;             // 1: ... periodic kernels through their Jacobi-Anger series (default)
   const long long* spk_off;   // R+1
   const long long* seg_off;   // R*N+1 : first spike of (trial, neuron)
   const double* spk_cnt;      // N     : spikes per neuron over all local trials
@@ -129,11 +137,13 @@ struct EngineView {
   SpikeClassTab* cls;                              // device copy of the class table
   double* cls_t0; double* cls_sc; int* cls_H;      // [class][R]: phase origin, quarter turns per unit time, harmonics (-1: pair loop)
   int* ser;                                        // [R][K]: 1 = the class path serves this (trial, latent), 0 = the pair loop
+  SpikeItem* sitem;                                // [R][K]: the same with the (trial, class) parameters
+  int* pair_any;                                   // 1 when some (trial with spikes, latent) is left to the pair loop
   int nrows, ntiles, nsplitS;
   const SpikeRow* rows;
   const SpikeTile* tiles;                          // contiguous per trial
   const int* tile_first;                           // R+1
-  const int* tile_order;                           // tiles, longest first (work order of k_spike_cls)
+  const SpikeTile* tiles_ord;                      // the same tiles, longest first (work order of k_spike_cls)
   const double* tt;                                // transposed spike times of the tiles
   const int* splitS_neuron; const int* splitS_trial;   // oversize pieces of the class path
   double* splitS;                                  // [nsplitS][K]
@@ -292,5 +302,18 @@ __device__ __forceinline__ double block_sum(double x, double* red) {
   __syncthreads();
   double s = 0.0;
   for (int i = 0; i < nw; ++i) s += red[i];
+  return s;
+}
+
+// dC partials of oversize (trial, neuron) segments (usually none): the pair-by-pair pass leaves them per split chunk, the
+// class path per split row; which of the two lists is current for a (trial, latent) follows ev.ser.  Fixed order.
+__device__ __forceinline__ double split_sums(const EngineView& ev, int n, int k) {
+  double s = 0.0;
+  for (int l = 0; l < ev.nsplit; ++l) {
+    const int ch = ev.split_chunks[l];
+    if (ev.chunks[ch].neuron == n && !ev.ser[ev.chunks[ch].trial * ev.K + k]) s += ev.splitPart[(long long)ch * ev.K + k];
+  }
+  for (int l = 0; l < ev.nsplitS; ++l)
+    if (ev.splitS_neuron[l] == n && ev.ser[ev.splitS_trial[l] * ev.K + k]) s += ev.splitS[(long long)l * ev.K + k];
   return s;
 }

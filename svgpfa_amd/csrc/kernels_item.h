@@ -43,7 +43,7 @@ __global__ __launch_bounds__(64) void k_build_reg(EngineView ev, int write_aux, 
     if (lane == 0) {
       const LatentMeta ms = ev.meta[ks];
       const KPar ps = make_kpar(ms, st.theta[ks]);
-      ev.fourH[ks] = (ms.ktype == SV_PERIODIC)
+      ev.fourH[ks] = (ms.ktype == SV_PERIODIC && ev.per_series)
                          ? periodic_series(0.5 * ps.h, ms.M, ev.four + (size_t)ks * SV_FROWS * (SV_FH + 2), &Lt[0][0][0])
                          : -1;
     }

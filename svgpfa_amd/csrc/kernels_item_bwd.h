@@ -105,11 +105,7 @@ __device__ __forceinline__ void fin_cd_group(const EngineView& ev, const double*
           }
           s += (v[0] + v[1]) + (v[2] + v[3]);
         }
-        if (pg == 0)
-          for (int l = 0; l < ev.nsplit; ++l) {
-            const int ch = ev.split_chunks[l];
-            if (ev.chunks[ch].neuron == n) s += ev.splitPart[(long long)ch * K + k];
-          }
+        if (pg == 0) s += split_sums(ev, n, k);
       }
     }
   } else {
@@ -235,11 +231,18 @@ __device__ SV_GATHER_ATTR void gather_item_inputs(const EngineView& ev, const La
                                                    int k, unsigned mask, bool want_zt, double s2, double* gs, double* p1l,
                                                    double* cvd, double* gt, double* tpl) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, NWB = blockDim.x >> 6, M = m.M;
-  const int c0 = ev.chunk_first[r], c1 = (mask & SV_MASK_STATS) ? c0 : ev.chunk_first[r + 1];
+  const bool stats = (mask & SV_MASK_STATS) != 0;
+  const bool cls = !stats && ev.ser[r * ev.K + k] != 0;   // the class path left this item's sums per trial (k_spike_comb)
+  const int c0 = ev.chunk_first[r], c1 = (stats || cls) ? c0 : ev.chunk_first[r + 1];
   if (tid < MP) {
     double p0 = 0.0, p1sum = 0.0, dinv = 0.0;
     if (tid < M) {
-      constexpr int GB = 8;      // chunks per step (a cfg3 trial has 8): 16 independent loads in flight
+      if (cls) {
+        const long long o = (long long)r * ev.sumM + m.colM + tid;
+        p0 = ev.P0t[o];
+        p1sum = want_zt ? ev.P1t[o] : 0.0;
+      }
+      constexpr int GB = 8;      // chunks per step: 16 independent loads in flight
       for (int ch = c0; ch < c1; ch += GB) {
         double v[GB], w[GB];
 #pragma unroll
@@ -269,6 +272,10 @@ __device__ SV_GATHER_ATTR void gather_item_inputs(const EngineView& ev, const La
       }
       tp0 = wave_sum(tp0);
       tp1 = wave_sum(tp1);
+      if (cls) {
+        tp0 = ev.Tt[((long long)r * ev.K + k) * 2 + 0];
+        tp1 = ev.Tt[((long long)r * ev.K + k) * 2 + 1];
+      }
     }
     if (lane == 0) {
       tpl[0] = tp0;
@@ -347,8 +354,13 @@ __device__ void item_bwd_body(const EngineView& ev, const int r, const int k, co
       // The adjoint of kappa(t, Z) at a node is gk = Linv^T [gm ut + 2 gv (Vt Vt^T - I) kt] = gm a + 2 gv D kt with the
       // per-item matrix D = Linv^T (Vt Vt^T - I): one dense M x M x 16 product per tile instead of three triangular ones
       // (T = Vt^T kt, Vt T, Linv^T .).  D is built once per item, one 16-column panel per wavefront, and replaces Vt in LDS.
+      // Every wave builds a panel (NWB >= NT in every launch configuration; waves >= NT repeat panel wave % NT and store
+      // the same values again): no wave-uniform branch around this register-heavy section.  ROCm 7.2's compiler was caught
+      // placing a spill of threadIdx.x at the JOIN of such a branch in front of the exec restore (DESIGN.md section 9,
+      // tests/tools/isa_exec_guard.py), where a wave that skipped the branch loses it.
       d4 Dp[NT];
-      for (int c = wave; c < NT; c += NWB) {     // NWB >= NT in every launch configuration: one panel per wave
+      const int c = wave % NT;
+      {
         d4 P[NT], VV[NT];
 #pragma unroll
         for (int b = 0; b < NT; ++b)
@@ -363,13 +375,10 @@ __device__ void item_bwd_body(const EngineView& ev, const int r, const int k, co
         tri_chain<NT, 1>(Dp, Li, LD, VV, li, lg);
       }
       if (!DSEP) __syncthreads();                                        // every wave is done reading Vt
-      if (wave < NT) {
-        const int c = wave;
 #pragma unroll
-        for (int a = 0; a < NT; ++a)
+      for (int a = 0; a < NT; ++a)
 #pragma unroll
-          for (int q = 0; q < 4; ++q) Dl[(16 * a + 4 * q + lg) * LD + 16 * c + li] = Dp[a][q];
-      }
+        for (int q = 0; q < 4; ++q) Dl[(16 * a + 4 * q + lg) * LD + 16 * c + li] = Dp[a][q];
     }
     __syncthreads();
     d4 gu[NT], dz[NT], GW[NTRI];

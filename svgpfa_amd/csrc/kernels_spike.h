@@ -1,4 +1,7 @@
-// Spike-time pass: the dominant kernel (sum_k R M_k S_r kernel evaluations per ELBO).
+// Spike-time pass, PAIR-BY-PAIR form: the path of the (trial, latent) items whose kernel the class path
+// (kernels_spike_cls.h) cannot serve through a cosine series -- short lengthscales against the trial's window, periodic
+// kernels with beta = 1 / l^2 > 45, very few inducing points -- and of every RBF latent under SVGPFA_RBF_SERIES=0.
+// ev.ser[trial][latent] says which items belong to the class path; they are skipped here.
 //
 // One wavefront per (spike chunk, latent).  Each lane owns SPL (= 8) consecutive spikes of the chunk (times and
 // embedding weights c_s = C[n_s, k] in registers); the inducing points z_j and a_j = (Kzz^-1 m)_j
@@ -24,10 +27,14 @@
 // ids, non-decreasing over the chunk, < 0 = padding at the end): a serial segmented sum inside the lane, ONE wave scan
 // over the lanes' tail partials (sorted keys: the lanes before l whose tail key equals l's head key are exactly those
 // that continue its head segment), then every segment end stores its total -- each neuron has exactly one writer.
-// out2 != nullptr: the chunk's FIRST segment continues a segment of the previous chunk; its sum goes to out2.
+// Two planes per (trial, neuron, latent): outA takes a segment that lies inside the chunk (outB is then cleared) and the
+// first part of a segment cut by the chunk's end (tailcut: the chunk's LAST segment continues in the next chunk, which
+// writes outB); headcont: the chunk's FIRST segment continues one of the previous chunk and goes to outB.  Every entry of
+// both planes that belongs to an existing segment is written on every pass, so the planes stay valid when an item moves
+// between this pass and the class path (which follows the same rule).
 template <int SPL>
-__device__ __forceinline__ void seg_emit_lane(const int (&key)[SPL], const double (&v)[SPL], double* out, double* out2,
-                                              int K, int lane) {
+__device__ __forceinline__ void seg_emit_lane(const int (&key)[SPL], const double (&v)[SPL], double* outA, double* outB,
+                                              bool headcont, bool tailcut, int K, int lane) {
   double run[SPL];
   run[0] = v[0];
 #pragma unroll
@@ -44,12 +51,20 @@ __device__ __forceinline__ void seg_emit_lane(const int (&key)[SPL], const doubl
   const int kprev = __shfl_up(kt, 1, 64);
   const double carry = (lane > 0 && kprev == key[0]) ? tprev : 0.0;
   const int knext = __shfl_down(key[0], 1, 64);
-  const int kfirst = out2 ? __shfl(key[0], 0, 64) : -2;
+  const int kfirst = headcont ? __shfl(key[0], 0, 64) : -2;
 #pragma unroll
   for (int i = 0; i < SPL; ++i) {
     const int kn = (i + 1 < SPL) ? key[i + 1] : ((lane < 63) ? knext : -1);
-    if (key[i] >= 0 && key[i] != kn)
-      ((key[i] == kfirst) ? out2 : out)[(long long)key[i] * K] = run[i] + ((key[i] == key[0]) ? carry : 0.0);
+    if (key[i] >= 0 && key[i] != kn) {
+      const double tot = run[i] + ((key[i] == key[0]) ? carry : 0.0);
+      const long long o = (long long)key[i] * K;
+      if (key[i] == kfirst) {
+        outB[o] = tot;                       // continuation: plane A was written by the previous chunk
+      } else {
+        outA[o] = tot;
+        if (!(tailcut && kn < 0)) outB[o] = 0.0;   // kn < 0: the chunk's last segment
+      }
+    }
   }
 }
 
@@ -205,21 +220,19 @@ __device__ void spike_body_periodic_full(const EngineView& ev, const double* __r
     const long long ob = (long long)r * ev.N * K + k;
 #pragma unroll
     for (int i = 0; i < SPL; ++i) mud[i] *= p.s2;
-    seg_emit_lane<SPL>(nid, mud, ev.gCspk + ob, (c.split & 2) ? ev.gCspkB + ob : nullptr, K, lane);
+    seg_emit_lane<SPL>(nid, mud, ev.gCspk + ob, ev.gCspkB + ob, (c.split & 2) != 0, (c.split & 4) != 0, K, lane);
   }
 }
 
-// Kernels as cosine series: ktil(delta) = sum_n c_n cos(n w delta).
+// Kernels as cosine series (used by the class path, kernels_spike_cls.h): ktil(delta) = sum_n c_n cos(n w delta).
 //   periodic (engine_common.h periodic_series): w = 2 pi / p, c_n = (2) e^-beta I_n(beta), beta = 1 / l^2 -- exact
 //       (Jacobi-Anger), truncated where n c_n < 1e-18; table per latent made at kernel-build time.
-//   RBF: exp(-h delta^2), h = 1 / (2 l^2), on the bounded window W of the item (all spike times of the trial and all its
-//       inducing points) equals its periodisation with period L = |W| + sqrt(41.5 / h) up to the wrapped copies
-//       exp(-h (L - |W|)^2) <= 1e-18, and the periodised Gaussian has the series (Poisson summation)
+//   RBF: exp(-h delta^2), h = 1 / (2 l^2), on the bounded window W of the (trial, class) (all spike times of the trial and
+//       all inducing points of the class's latents) equals its periodisation with period L >= |W| + sqrt(41.5 / h) up to
+//       the wrapped copies exp(-h (L - |W|)^2) <= 1e-18, and the periodised Gaussian has the series (Poisson summation)
 //       c_n = (2) sqrt(pi / h) / L exp(-pi^2 n^2 / (h L^2)),  w = 2 pi / L,  truncated where n c_n < 1e-18.
-//       L and the number of harmonics are chosen per (trial, latent) at run time from the data and the current
-//       lengthscale (H ~ 4.3 L / l: 19 at the north-star shape); short lengthscales fall back to the pair loop.
 // With theta_s = w (t_s - t0), phi_j = w (z_j - t0) every sum over spikes the pass needs follows from the trigonometric
-// moments of the chunk's spikes
+// moments of the spikes
 //     A_n = sum_s c_s cos(n theta_s)   B_n = sum_s c_s sin(n theta_s)   [periodic: At_n, Bt_n = the same weighted by t_s]
 // (with Cc_nj = cos(n phi_j) A_n + sin(n phi_j) B_n,  Ss_nj = cos(n phi_j) B_n - sin(n phi_j) A_n):
 //     P0_j = sum_s c_s ktil        = sum_n c_n Cc_nj
@@ -230,255 +243,13 @@ __device__ void spike_body_periodic_full(const EngineView& ev, const double* __r
 //                                                         RBF      b0 = delta^2:    g_n = -dc_n/dh = c_n (1/(2h) - pi^2 n^2 / (h^2 L^2))
 //     T1   (periodic only) = sum_j a_j sum_n e_n [cos(n phi_j) Bt_n - sin(n phi_j) At_n - z_j Ss_nj]
 //     mu_s = s2 sum_j a_j ktil_sj  = s2 sum_n c_n [cos(n theta_s) Abar_n + sin(n theta_s) Bbar_n],  Abar_n = sum_j a_j cos(n phi_j)
-// A spike costs 8 (RBF) / 10 (periodic) fp64 operations per harmonic (2 / 4 for the moments, 2 for mu, 4 to rotate
-// (cos, sin) to the next harmonic) instead of M exponentials: 14 and 20 harmonics at the north-star shape against
-// 32 x 21..23 instructions.  cos / sin of the multiples come from rotations by theta (error ~ n ulp), not from the
-// three-term recurrence (~ n^2 ulp).  Series values carry an ABSOLUTE error of ~1e-15 of the kernel's maximum (the
-// terms are O(0.3) and cancel where the kernel is small); the sums they feed are dominated by their large terms.
-struct SeriesPar {
-  int H;               // harmonics 0 .. H
-  double sc, t0;       // phase in quarter turns = (t - t0) sc
-  const double* c;     // c_n
-  const double* g;     // T0 weights
-  const double* e;     // P1 weights
-};
-
-// WC = false (only with FULL): the caller wants no embedding gradient (kernel-parameter / inducing-point closures of the
-// EM loop): the posterior mean at the spikes and its per-neuron sums are left out -- the projections Abar / Bbar, two of
-// the 8..10 operations per (spike, harmonic) and the segmented emit.
-template <int KT, bool FULL, int SPL, bool WC = true>
-__device__ void spike_body_series(const EngineView& ev, const double* __restrict__ C, int ch, int k, double* red,
-                                  const SeriesPar sp) {
-  constexpr bool TW = FULL && KT == SV_PERIODIC;      // time-weighted moments (period gradient)
-  constexpr bool MU = FULL && WC;                     // posterior mean at the spikes -> dC
-  constexpr int ROWS = FULL ? 16 : 8;                 // LDS reduction rows per group (value-only: half the LDS, more waves)
-  constexpr int NV = TW ? 4 : 2, JG = ROWS / NV;
-  const int lane = threadIdx.x, H = sp.H;
-  const SpikeChunk c = ev.chunks[ch];
-  const LatentMeta m = ev.meta[k];
-  const int M = m.M, K = ev.K, r = c.trial;
-  const KPar p = make_kpar(m, ev.theta + 2 * k);
-  const double* __restrict__ z = ev.Zs + m.offM + (long long)r * M;
-  const double* __restrict__ a = ev.a + m.offM + (long long)r * M;
-  const double sc = sp.sc;
-  double* Fs = red + ROWS * 65;                  // [SV_FH + 1][NV] moments of the chunk
-  double* AB = Fs + (SV_FH + 1) * 4;             // [SV_FH + 1][2] c_n Abar_n, c_n Bbar_n   (FULL)
-
-  double cw[SPL], tw[TW ? SPL : 1], c1[SPL], s1[SPL], cn[SPL], sn[SPL], mu[MU ? SPL : 1];
-#pragma unroll
-  for (int i = 0; i < SPL; ++i) {
-    const int idx = lane * SPL + i;              // lane owns SPL consecutive spikes
-    const bool ok = idx < c.count;
-    const long long gs = c.start + (ok ? idx : 0);
-    const double t = ev.spk_t[gs];
-    cw[i] = ok ? C[(long long)ev.spk_n[gs] * K + k] : 0.0;
-    if constexpr (TW) tw[i] = cw[i] * t;
-    sv_sincos_quarter((t - sp.t0) * sc, s1[i], c1[i]);
-    cn[i] = 1.0;
-    sn[i] = 0.0;
-    if constexpr (MU) mu[i] = 0.0;
-  }
-  double zj = 0.0, aj = 0.0, sphi = 0.0, cphi = 1.0;
-  if (lane < M) {
-    zj = z[lane];
-    aj = a[lane];
-    sv_sincos_quarter((zj - sp.t0) * sc, sphi, cphi);
-  }
-  // transposed reduction of ROWS LDS rows of 64 lane-partials: lane (v, quarter) sums 16 entries, the quarters are
-  // added by shuffles, lanes < ROWS hold the totals
-  auto reduce_rows = [&]() -> double {
-    const int v = lane & 15, qd = lane >> 4;
-    double sum = 0.0;
-    if (v < ROWS) {
-#pragma unroll
-      for (int e = 0; e < 16; ++e) sum += red[v * 65 + qd * 16 + e];
-    }
-    sum += __shfl_xor(sum, 16, 64);
-    sum += __shfl_xor(sum, 32, 64);
-    return sum;
-  };
-  if constexpr (MU) {
-    // Abar_n, Bbar_n (times c_n): the posterior-mean weights a_j projected on the harmonics of the inducing points
-    double cj = 1.0, sj = 0.0;
-    for (int nb = 0; nb <= H; nb += 8) {
-#pragma unroll
-      for (int jj = 0; jj < 8; ++jj) {
-        red[(2 * jj + 0) * 65 + lane] = aj * cj;
-        red[(2 * jj + 1) * 65 + lane] = aj * sj;
-        const double tq = cj * cphi - sj * sphi;
-        sj = fma(sj, cphi, cj * sphi);
-        cj = tq;
-      }
-      __syncthreads();
-      const double tot = reduce_rows();
-      const int n = nb + (lane >> 1);
-      if (lane < 16 && n <= H) AB[2 * n + (lane & 1)] = sp.c[n] * tot;
-      __syncthreads();
-    }
-  }
-
-  for (int nb = 0; nb <= H; nb += JG) {
-#pragma unroll
-    for (int jj = 0; jj < JG; ++jj) {
-      const int n = nb + jj;
-      double sa = 0.0, sb = 0.0, sat = 0.0, sbt = 0.0;
-      if (n <= H) {
-        double cA = 0.0, cB = 0.0;
-        if constexpr (MU) {
-          cA = AB[2 * n];
-          cB = AB[2 * n + 1];
-        }
-#pragma unroll
-        for (int i = 0; i < SPL; ++i) {
-          sa = fma(cw[i], cn[i], sa);
-          sb = fma(cw[i], sn[i], sb);
-          if constexpr (TW) {
-            sat = fma(tw[i], cn[i], sat);
-            sbt = fma(tw[i], sn[i], sbt);
-          }
-          if constexpr (MU) mu[i] = fma(cn[i], cA, fma(sn[i], cB, mu[i]));
-          const double tq = cn[i] * c1[i] - sn[i] * s1[i];     // (cos, sin) of (n + 1) theta: rotation by theta
-          sn[i] = fma(sn[i], c1[i], cn[i] * s1[i]);
-          cn[i] = tq;
-        }
-      }
-      red[(NV * jj + 0) * 65 + lane] = sa;
-      red[(NV * jj + 1) * 65 + lane] = sb;
-      if constexpr (TW) {
-        red[(NV * jj + 2) * 65 + lane] = sat;
-        red[(NV * jj + 3) * 65 + lane] = sbt;
-      }
-    }
-    __syncthreads();
-    const double tot = reduce_rows();
-    if (lane < ROWS && nb + lane / NV <= H) Fs[nb * NV + lane] = tot;
-    __syncthreads();
-  }
-
-  // per inducing point: combine the moments with the harmonics of its own phase
-  double t0acc = 0.0, t1acc = 0.0;
-  if (lane < M) {
-    double cj = 1.0, sj = 0.0, P0 = 0.0, P1 = 0.0, d0 = 0.0, d1 = 0.0;
-    for (int n = 0; n <= H; ++n) {
-      const double An = Fs[n * NV + 0], Bn = Fs[n * NV + 1];
-      const double Cc = fma(cj, An, sj * Bn), Ss = fma(cj, Bn, -(sj * An));
-      P0 = fma(sp.c[n], Cc, P0);
-      if constexpr (FULL) {
-        const double en = sp.e[n];
-        P1 = fma(en, Ss, P1);
-        d0 = fma(sp.g[n], Cc, d0);
-        if constexpr (TW) d1 = fma(en, fma(cj, Fs[n * NV + 3], -(sj * Fs[n * NV + 2])) - zj * Ss, d1);
-      }
-      const double tq = cj * cphi - sj * sphi;
-      sj = fma(sj, cphi, cj * sphi);
-      cj = tq;
-    }
-    const long long o = (long long)ch * ev.sumM + m.colM + lane;
-    ev.P0[o] = P0;
-    if constexpr (FULL) {
-      ev.P1[o] = P1;
-      t0acc = aj * d0;
-      t1acc = aj * d1;
-    }
-  }
-  if constexpr (FULL) {
-    const double t0 = wave_sum(t0acc), t1 = wave_sum(t1acc);
-    if (lane == 0) {
-      ev.Tpart[((long long)ch * K + k) * 2 + 0] = t0;
-      ev.Tpart[((long long)ch * K + k) * 2 + 1] = t1;
-    }
-  }
-  if constexpr (MU) {
-    // spike part of dC[n, k]: per-neuron sums of mu_s
-    int nid[SPL];
-#pragma unroll
-    for (int i = 0; i < SPL; ++i) {
-      const int idx = lane * SPL + i;
-      nid[i] = (idx < c.count) ? ev.spk_n[c.start + idx] : -1;
-    }
-    if (c.split & 1) {
-      double tot = 0.0;
-#pragma unroll
-      for (int i = 0; i < SPL; ++i) tot += (nid[i] >= 0) ? mu[i] : 0.0;
-      tot = wave_sum(tot);
-      if (lane == 0) ev.splitPart[(long long)ch * K + k] = p.s2 * tot;
-    } else {
-      const long long ob = (long long)r * ev.N * K + k;
-#pragma unroll
-      for (int i = 0; i < SPL; ++i) mu[i] *= p.s2;
-      seg_emit_lane<SPL>(nid, mu, ev.gCspk + ob, (c.split & 2) ? ev.gCspkB + ob : nullptr, K, lane);
-    }
-  }
-}
-
-// RBF: window, period and series of this (trial, latent) item (see above).  Returns H, or -1 for the pair loop.
-// cf: LDS, 3 x (SV_FH + 1) doubles (c_n | g_n | e_n).
-__device__ __forceinline__ int rbf_series_setup(const EngineView& ev, const LatentMeta& m, const KPar& p, int r,
-                                                double* cf, double& sc, double& t0) {
-  const int lane = threadIdx.x, M = m.M;
-  const double* z = ev.Zs + m.offM + (long long)r * M;
-  double lo = ev.spk_lo[r], hi = ev.spk_hi[r];
-  if (lane < M) {
-    const double zj = z[lane];
-    lo = fmin(lo, zj);
-    hi = fmax(hi, zj);
-  }
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) {
-    lo = fmin(lo, __shfl_xor(lo, o, 64));
-    hi = fmax(hi, __shfl_xor(hi, o, 64));
-  }
-  const double PI = 3.14159265358979323846;
-  const double h = p.h;                                  // exp(-h delta^2)
-  const double L = (hi - lo) + sqrt(41.5 / h);           // wrapped copies below e^-41.5 = 1e-18
-  const double q = PI * PI / (h * L * L);                // c_n ~ exp(-q n^2)
-  const double nmax = sqrt(46.0 / q);                    // n c_n / c_0 < 64 e^-46 = 7e-19 beyond
-  if (!(nmax < (double)SV_FH)) return -1;
-  const int H = (int)nmax + 1;
-  if (H > SV_FH || 10 * (H + 2) > 21 * M) return -1;     // per-spike cost of the series against M kernel evaluations
-  const double w = 2.0 * PI / L, c0 = sqrt(PI / h) / L;
-  __syncthreads();                                       // the previous user of this LDS region is done
-  for (int n = lane; n <= H; n += 64) {
-    const double cn = (n ? 2.0 : 1.0) * c0 * exp(-q * (double)n * (double)n);
-    cf[n] = cn;
-    cf[(SV_FH + 1) + n] = cn * (0.5 / h - q * (double)n * (double)n / h);
-    cf[2 * (SV_FH + 1) + n] = (double)n * w * cn * (0.5 / h);
-  }
-  __syncthreads();
-  sc = 4.0 / L;
-  t0 = lo;
-  return H;
-}
+// cos / sin of the multiples come from rotations by theta (error ~ n ulp), not from the three-term recurrence (~ n^2
+// ulp).  Series values carry an ABSOLUTE error of ~1e-15 of the kernel's maximum (the terms are O(0.3) and cancel where
+// the kernel is small); the sums they feed are dominated by their large terms.
 
 template <int KT, bool FULL, int SPL, typename T, bool WC = true>
 __device__ void spike_body(const EngineView& ev, const double* __restrict__ C, int ch, int k,
                            double* red_d) {
-  {   // the kernel through its cosine series where that is short enough.  The series bodies are fp64 in both precision
-      // modes: rotations accumulate ~n ulp, too much in fp32, and they beat the fp32 pair loop anyway; precision mode
-      // "mixed" uses fp32 in the pair loop, i.e. where the series does not apply
-    constexpr int NF = SV_FH + 2;
-    if constexpr (KT == SV_PERIODIC) {
-      const int H = ev.fourH[k];             // made by k_build_reg (periodic_series)
-      if (H >= 0) {
-        const double* tab = ev.four + (size_t)k * SV_FROWS * NF;
-        const KPar p = make_kpar(ev.meta[k], ev.theta + 2 * k);
-        spike_body_series<SV_PERIODIC, FULL, SPL, WC>(ev, C, ch, k, red_d,
-                                                  SeriesPar{H, 4.0 * p.ip, 0.0, tab, tab + NF, tab + 2 * NF});
-        return;
-      }
-    } else if (ev.rbf_series) {
-      const LatentMeta ms = ev.meta[k];
-      const KPar p = make_kpar(ms, ev.theta + 2 * k);
-      double* cf = red_d + (FULL ? 16 : 8) * 65 + (SV_FH + 1) * 6;   // behind the series body's own LDS
-      double sc, t0;
-      const int H = rbf_series_setup(ev, ms, p, ev.chunks[ch].trial, cf, sc, t0);
-      if (H >= 0) {
-        spike_body_series<SV_RBF, FULL, SPL, WC>(ev, C, ch, k, red_d,
-                                             SeriesPar{H, sc, t0, cf, cf + (SV_FH + 1), cf + 2 * (SV_FH + 1)});
-        return;
-      }
-    }
-  }
   if constexpr (KT == SV_PERIODIC && FULL) {
     spike_body_periodic_full<SPL, T>(ev, C, ch, k, red_d);
     return;
@@ -639,36 +410,42 @@ __device__ void spike_body(const EngineView& ev, const double* __restrict__ C, i
       const long long ob = (long long)r * ev.N * K + k;
 #pragma unroll
       for (int i = 0; i < SPL; ++i) mud[i] *= p.s2;
-      seg_emit_lane<SPL>(nid, mud, ev.gCspk + ob, (c.split & 2) ? ev.gCspkB + ob : nullptr, K, lane);
+      seg_emit_lane<SPL>(nid, mud, ev.gCspk + ob, ev.gCspkB + ob, (c.split & 2) != 0, (c.split & 4) != 0, K, lane);
     }
   }
 }
 
-// One launch over all (chunk, latent) work items; the covariance type is resolved per block.  Registers are capped so
-// that 3 waves / SIMD stay resident.
-// WC = false: no embedding gradient wanted (series bodies skip the spike means; the pair-loop fallbacks compute them anyway).
-template <bool FULL, int SPL, typename T = double, bool WC = true>
+// One launch over all (chunk, latent) work items; the covariance type is resolved per item.  Registers are capped so
+// that 3 waves / SIMD stay resident.  Which items remain for this pass is only known on the device (ev.ser), so the grid
+// is a fixed number of single-wave blocks (a multiple of 8) that stride over the items and skip the class path's.
+// WC = false: no embedding gradient wanted (the pair loops compute the spike means anyway).
+template <bool FULL, typename T = double, bool WC = true>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 8))) void k_spike(EngineView ev,
                                                                                          const double* __restrict__ C) {
+  constexpr int SPL = SV_SPL;
   // LDS bounds the waves per CU: RBF full 3 x 8 rows + 4 x 64 (14.5 KB in fp64), periodic full 5 x 4 rows + ~7 x 64 (14 KB),
   // value-only 8 rows; half of that in fp32
   constexpr int LDS_RBF = 3 * SV_SPIKE_JG * 65 + 4 * 64, LDS_PER = 5 * 4 * 65 + 7 * 64 + 32;
-  constexpr int LDS_SER = (FULL ? 16 : 8) * 65 + (SV_FH + 1) * 9 + 8;   // cosine-series body: rows, moments + Abar / Bbar, RBF coefficients
-  constexpr int LDS_FULL = LDS_RBF > LDS_PER ? (LDS_RBF > LDS_SER ? LDS_RBF : LDS_SER) : (LDS_PER > LDS_SER ? LDS_PER : LDS_SER);
-  constexpr int LDS_VAL = SV_SPIKE_JG * 65 + 4 * 64 > LDS_SER ? SV_SPIKE_JG * 65 + 4 * 64 : LDS_SER;
+  constexpr int LDS_FULL = LDS_RBF > LDS_PER ? LDS_RBF : LDS_PER;
+  constexpr int LDS_VAL = SV_SPIKE_JG * 65 + 4 * 64;
   __shared__ double red[FULL ? LDS_FULL : LDS_VAL];
   // Work item = (chunk, latent).  Blocks b and b + 8 share an XCD (and its L2) under the dispatcher's round-robin
-  // placement -- a speed assumption only -- so the grid is re-indexed such that the blocks of one XCD walk a contiguous
+  // placement -- a speed assumption only -- so the items are re-indexed such that the blocks of one XCD walk a contiguous
   // range of chunk-major items: the K blocks that read the same chunk's spike times / neuron ids run on one XCD, back to
-  // back, and all but the first find them in its L2 (the item starts with a chain of dependent global loads).
+  // back, and all but the first find them in its L2 (the item starts with a chain of dependent global loads).  gridDim.x
+  // is a multiple of 8, so w and blockIdx.x name the same XCD.
+  if (!*ev.pair_any) return;                                     // every item is served by the class path
   const int nper = ev.ntype[SV_PERIODIC], nrbf = ev.ntype[SV_RBF], nlat = nper + nrbf;
-  const int nb = gridDim.x, b = blockIdx.x, x = b & 7, q = nb >> 3, rem = nb & 7;
-  const int item = ((x < rem) ? x * (q + 1) : rem * (q + 1) + (x - rem) * q) + (b >> 3);   // bijective for any nb
-  const int ch = item / nlat, slot = item % nlat;
-  if (slot < nper) {
-    spike_body<SV_PERIODIC, FULL, SPL, T, WC>(ev, C, ch, ev.klist[SV_PERIODIC][slot], red);
-  } else {
-    spike_body<SV_RBF, FULL, SPL, T, WC>(ev, C, ch, ev.klist[SV_RBF][slot - nper], red);
+  const long long nb = (long long)ev.nchunks * nlat;
+  for (long long w = blockIdx.x; w < nb; w += gridDim.x) {
+    const long long x = w & 7, q = nb >> 3, rem = nb & 7;
+    const long long item = ((x < rem) ? x * (q + 1) : rem * (q + 1) + (x - rem) * q) + (w >> 3);   // bijective for any nb
+    const int ch = (int)(item / nlat), slot = (int)(item % nlat);
+    const int k = (slot < nper) ? ev.klist[SV_PERIODIC][slot] : ev.klist[SV_RBF][slot - nper];
+    if (ev.ser[ev.chunks[ch].trial * ev.K + k]) continue;        // served by the class path
+    if (slot < nper) spike_body<SV_PERIODIC, FULL, SPL, T, WC>(ev, C, ch, k, red);
+    else spike_body<SV_RBF, FULL, SPL, T, WC>(ev, C, ch, k, red);
+    __syncthreads();                                             // LDS is reused by the next item
   }
 }
 
@@ -723,13 +500,7 @@ __global__ __launch_bounds__(256) void k_mseg_from_dc(EngineView ev) {
       }
       s += (v[0] + v[1]) + (v[2] + v[3]);
     }
-    if (pg == 0) {
-      const int n = id / ev.K, k = id % ev.K;
-      for (int l = 0; l < ev.nsplit; ++l) {
-        const int ch = ev.split_chunks[l];
-        if (ev.chunks[ch].neuron == n) s += ev.splitPart[(long long)ch * ev.K + k];
-      }
-    }
+    if (pg == 0) s += split_sums(ev, id / ev.K, id % ev.K);
   }
   red[pg * SV_FS_OUT + o] = s;
   __syncthreads();

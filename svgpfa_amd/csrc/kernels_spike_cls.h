@@ -35,21 +35,28 @@
 __global__ __launch_bounds__(256) void k_spike_classes(EngineView ev) {
   __shared__ SpikeClassTab tab;
   __shared__ double par[SV_MAX_K];     // per latent: RBF h = 1 / (2 l^2); periodic 4 / period
+  __shared__ int typ[SV_MAX_K], Hk[SV_MAX_K], Mk[SV_MAX_K];
   __shared__ double lead[SV_MAX_K];    // per class: RBF h of the leader (its longest lengthscale); periodic 4 / period
   __shared__ int clsH[SV_MAX_K], clsM[SV_MAX_K];   // per class: periodic harmonics; sum of the members' M
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, K = ev.K, R = ev.R;
+  if (tid < K) {                         // the latents' parameters, in parallel (the grouping below reads LDS only)
+    const LatentMeta m = ev.meta[tid];
+    const KPar p = make_kpar(m, ev.theta + 2 * tid);
+    par[tid] = (m.ktype == SV_RBF) ? p.h : 4.0 * p.ip;
+    typ[tid] = m.ktype;
+    Mk[tid] = m.M;
+    Hk[tid] = (m.ktype == SV_PERIODIC) ? ev.fourH[tid] : 0;
+  }
+  __syncthreads();
   if (tid == 0) {
     tab.ncls = 0;
     for (int k = 0; k < K; ++k) {
       tab.cls_of[k] = -1;
       tab.slot_of[k] = 0;
-      const LatentMeta m = ev.meta[k];
-      const KPar p = make_kpar(m, ev.theta + 2 * k);
-      par[k] = (m.ktype == SV_RBF) ? p.h : 4.0 * p.ip;
     }
     for (int k = 0; k < K; ++k) {                      // periodic: one class per distinct period
-      if (ev.meta[k].ktype != SV_PERIODIC) continue;
-      const int H = ev.fourH[k];
+      if (typ[k] != SV_PERIODIC) continue;
+      const int H = Hk[k];
       if (H < 0) continue;                             // short lengthscale / few inducing points: pair by pair
       int g = -1;
       for (int c = 0; c < tab.ncls; ++c)
@@ -66,14 +73,13 @@ __global__ __launch_bounds__(256) void k_spike_classes(EngineView ev) {
       tab.slot_of[k] = tab.nmem[g];
       tab.mem[g][tab.nmem[g]++] = k;
       clsH[g] = H > clsH[g] ? H : clsH[g];
-      clsM[g] += ev.meta[k].M;
+      clsM[g] += Mk[k];
     }
     if (ev.rbf_series) {                               // RBF: greedy classes from the longest lengthscale down
       for (;;) {
         int ld = -1;
         for (int k = 0; k < K; ++k)
-          if (ev.meta[k].ktype == SV_RBF && tab.cls_of[k] < 0 && par[k] > 0.0 && par[k] < 1e300 && (ld < 0 || par[k] < par[ld]))
-            ld = k;
+          if (typ[k] == SV_RBF && tab.cls_of[k] < 0 && par[k] > 0.0 && par[k] < 1e300 && (ld < 0 || par[k] < par[ld])) ld = k;
         if (ld < 0) break;
         const int g = tab.ncls++;
         tab.type[g] = SV_RBF;
@@ -82,12 +88,11 @@ __global__ __launch_bounds__(256) void k_spike_classes(EngineView ev) {
         clsH[g] = 0;
         clsM[g] = 0;
         for (int k = 0; k < K; ++k)
-          if (ev.meta[k].ktype == SV_RBF && tab.cls_of[k] < 0 && par[k] > 0.0 && par[k] <= 4.0 * par[ld] &&
-              tab.nmem[g] < SV_CLS_MAXMEM) {
+          if (typ[k] == SV_RBF && tab.cls_of[k] < 0 && par[k] > 0.0 && par[k] <= 4.0 * par[ld] && tab.nmem[g] < SV_CLS_MAXMEM) {
             tab.cls_of[k] = g;
             tab.slot_of[k] = tab.nmem[g];
             tab.mem[g][tab.nmem[g]++] = k;
-            clsM[g] += ev.meta[k].M;
+            clsM[g] += Mk[k];
           }
       }
     }
@@ -100,8 +105,14 @@ __global__ __launch_bounds__(256) void k_spike_classes(EngineView ev) {
   }
   const int r = blockIdx.x * 4 + wave;
   if (r >= R) return;
+  const bool has_spikes = ev.spk_off[r + 1] > ev.spk_off[r];
+  bool pair = false;                                   // some item of this trial is left to the pair-by-pair pass
   for (int k = lane; k < K; k += 64)
-    if (tab.cls_of[k] < 0) ev.ser[r * K + k] = 0;
+    if (tab.cls_of[k] < 0) {
+      ev.ser[r * K + k] = 0;
+      ev.sitem[r * K + k] = SpikeItem{-1, -1, 0.0, 0.0};
+      pair = true;
+    }
   const double PI = 3.14159265358979323846;
   for (int g = 0; g < tab.ncls; ++g) {
     double t0 = 0.0, sc = lead[g];
@@ -140,8 +151,14 @@ __global__ __launch_bounds__(256) void k_spike_classes(EngineView ev) {
       ev.cls_sc[(long long)g * R + r] = sc;
       ev.cls_H[(long long)g * R + r] = H;
     }
-    if (lane < tab.nmem[g]) ev.ser[r * K + tab.mem[g][lane]] = H >= 0 ? 1 : 0;
+    if (lane < tab.nmem[g]) {
+      const int k = tab.mem[g][lane];
+      ev.ser[r * K + k] = H >= 0 ? 1 : 0;
+      ev.sitem[r * K + k] = SpikeItem{H, g, t0, sc};
+      if (H < 0) pair = true;
+    }
   }
+  if (has_spikes && __any(pair) && lane == 0) atomicOr(ev.pair_any, 1);
 }
 
 // Series coefficients of latent k on the (trial, class) period: rows c_n | g_n | e_n for n = 0 .. H into cf (LDS,
@@ -176,29 +193,31 @@ __device__ __forceinline__ void cls_coefficients(const EngineView& ev, int k, in
 // phi_j = w (z_j - t0): the posterior mean at a spike is mu_s = sum_n [cos(n theta_s) W_2n + sin(n theta_s) W_2n+1].
 // Entries beyond H are written as zeros (k_spike_cls works in whole register passes).  grid = R K blocks of 64 threads.
 __global__ __launch_bounds__(64) void k_spike_pre(EngineView ev) {
-  __shared__ double red[16 * 65];
+  __shared__ double red[8 * 65];          // 4 harmonics x (cos, sin) per round: small enough for 5 000 blocks to be resident at once
   __shared__ double cf[3 * (SV_FH + 1)];
-  const int item = blockIdx.x, lane = threadIdx.x, K = ev.K, R = ev.R;
-  if (!ev.ser[item]) return;
+  const int item = blockIdx.x, lane = threadIdx.x, K = ev.K;
+  const SpikeItem it = ev.sitem[item];
+  if (it.H < 0) return;
   const int r = item / K, k = item % K;
   const LatentMeta m = ev.meta[k];
-  const int g = ev.cls->cls_of[k];
-  const int H = ev.cls_H[(long long)g * R + r];
-  const double sc = ev.cls_sc[(long long)g * R + r], t0 = ev.cls_t0[(long long)g * R + r];
+  const int H = it.H;
+  const double sc = it.sc, t0 = it.t0;
   const KPar p = make_kpar(m, ev.theta + 2 * k);
-  cls_coefficients(ev, k, m.ktype, p.h, sc, H, cf);
-  double aj = 0.0, sphi = 0.0, cphi = 1.0;
-  if (lane < m.M) {
+  double aj = 0.0, zj = t0;
+  if (lane < m.M) {                        // requested before the coefficients are computed
     aj = ev.a[m.offM + (long long)r * m.M + lane];
-    sv_sincos_quarter((ev.Zs[m.offM + (long long)r * m.M + lane] - t0) * sc, sphi, cphi);
+    zj = ev.Zs[m.offM + (long long)r * m.M + lane];
   }
+  cls_coefficients(ev, k, m.ktype, p.h, sc, H, cf);
+  double sphi = 0.0, cphi = 1.0;
+  if (lane < m.M) sv_sincos_quarter((zj - t0) * sc, sphi, cphi);
   double* W = ev.Wb + (long long)item * SV_WCOLS;
   for (int c = 2 * (H + 1) + lane; c < SV_WCOLS; c += 64) W[c] = 0.0;
   double cj = 1.0, sj = 0.0;
-  for (int nb = 0; nb <= H; nb += 8) {
+  for (int nb = 0; nb <= H; nb += 4) {
     __syncthreads();                       // cf ready (first round); the previous round's rows are consumed
 #pragma unroll
-    for (int jj = 0; jj < 8; ++jj) {
+    for (int jj = 0; jj < 4; ++jj) {
       red[(2 * jj + 0) * 65 + lane] = aj * cj;
       red[(2 * jj + 1) * 65 + lane] = aj * sj;
       const double tq = cj * cphi - sj * sphi;
@@ -206,15 +225,16 @@ __global__ __launch_bounds__(64) void k_spike_pre(EngineView ev) {
       cj = tq;
     }
     __syncthreads();
-    // transposed reduction: lane (v, quarter) sums 16 of the 64 lane-partials of row v, the quarters are added by shuffles
-    const int v = lane & 15, qd = lane >> 4;
+    // transposed reduction: lane (v, eighth) sums 8 of the 64 lane-partials of row v, the eighths are added by shuffles
+    const int v = lane & 7, qd = lane >> 3;
     double sum = 0.0;
 #pragma unroll
-    for (int e = 0; e < 16; ++e) sum += red[v * 65 + qd * 16 + e];
+    for (int e = 0; e < 8; ++e) sum += red[v * 65 + qd * 8 + e];
+    sum += __shfl_xor(sum, 8, 64);
     sum += __shfl_xor(sum, 16, 64);
     sum += __shfl_xor(sum, 32, 64);
     const int n = nb + (lane >> 1);
-    if (lane < 16 && n <= H) W[2 * n + (lane & 1)] = p.s2 * cf[n] * sum;
+    if (lane < 8 && n <= H) W[2 * n + (lane & 1)] = p.s2 * cf[n] * sum;
   }
 }
 
@@ -227,26 +247,40 @@ __device__ __forceinline__ void cls_pass(const double* __restrict__ tt, int maxl
                                          double sc, int h0, double (&acc)[NV * HB]) {
 #pragma unroll
   for (int c = 0; c < NV * HB; ++c) acc[c] = 0.0;
-  double tn = (maxlen > 0) ? tt[lane] : 0.0;          // transposed times: row = lane, spike i at [i][lane]
-  for (int i = 0; i < maxlen; ++i) {
-    const double t = tn;
-    if (i + 1 < maxlen) tn = tt[(long long)(i + 1) * 64 + lane];     // next spike's time one iteration ahead
-    if (i < len) {
-      const double ph = (t - t0) * sc;
-      double s1, c1, cn = 1.0, sn = 0.0;
-      sv_sincos_quarter(ph, s1, c1);
-      if (h0 > 0) sv_sincos_quarter(ph * (double)h0, sn, cn);
+  // transposed times: row = lane, spike i at [i][lane]; four spikes' times are fetched a group ahead (one spike costs
+  // ~0.4 us of issue time: a single load in flight did not cover the memory latency at two waves per SIMD).  The loads
+  // are unconditional -- the host pads tt by one group, a read past the tile's end lands in the next tile or the pad --
+  // so that the four are issued back to back and waited for once (behind a bounds check the compiler waited per load).
+  constexpr int PF = 4;
+  double tn[PF];
 #pragma unroll
-      for (int n = 0; n < HB; ++n) {
-        acc[NV * n + 0] += cn;
-        acc[NV * n + 1] += sn;
-        if (NV == 4) {
-          acc[NV * n + 2] = fma(t, cn, acc[NV * n + 2]);
-          acc[NV * n + 3] = fma(t, sn, acc[NV * n + 3]);
+  for (int u = 0; u < PF; ++u) tn[u] = tt[(long long)u * 64 + lane];
+  for (int i0 = 0; i0 < maxlen; i0 += PF) {
+    double tc[PF];
+#pragma unroll
+    for (int u = 0; u < PF; ++u) tc[u] = tn[u];
+#pragma unroll
+    for (int u = 0; u < PF; ++u) tn[u] = tt[(long long)(i0 + PF + u) * 64 + lane];
+#pragma unroll
+    for (int u = 0; u < PF; ++u) {
+      if (i0 + u < len) {
+        const double t = tc[u];
+        const double ph = (t - t0) * sc;
+        double s1, c1, cn = 1.0, sn = 0.0;
+        sv_sincos_quarter(ph, s1, c1);
+        if (h0 > 0) sv_sincos_quarter(ph * (double)h0, sn, cn);
+#pragma unroll
+        for (int n = 0; n < HB; ++n) {
+          acc[NV * n + 0] += cn;
+          acc[NV * n + 1] += sn;
+          if (NV == 4) {
+            acc[NV * n + 2] = fma(t, cn, acc[NV * n + 2]);
+            acc[NV * n + 3] = fma(t, sn, acc[NV * n + 3]);
+          }
+          const double tq = cn * c1 - sn * s1;          // (cos, sin) of (n + 1) theta: rotation by theta
+          sn = fma(sn, c1, cn * s1);
+          cn = tq;
         }
-        const double tq = cn * c1 - sn * s1;          // (cos, sin) of (n + 1) theta: rotation by theta
-        sn = fma(sn, c1, cn * s1);
-        cn = tq;
       }
     }
   }
@@ -257,11 +291,25 @@ __device__ __forceinline__ void cls_pass(const double* __restrict__ tt, int maxl
 // come out of 16 v_mfma_f64_16x16x4_f64 (A operand: the gathered embedding weights cg, B operand: U); and, DC, the
 // rows' own dC partials  dcl[member][row] += sum_cols U[row][col] W[member][col]  on the VALU (W is wave-uniform).
 template <int NV, int HB, bool DC>
-__device__ __forceinline__ void cls_flush(const EngineView& ev, const double (&acc)[NV * HB], const double (&cg)[16],
-                                          const SpikeClassTab* __restrict__ cls, int g, int nmem, int tile, int r, int h0,
-                                          int H, double* Ut, double* dcl) {
+__device__ __forceinline__ void cls_flush(const EngineView& ev, const double* __restrict__ C, const double (&acc)[NV * HB],
+                                          int neuron, int nrows, int memk, int nmem, int tile, int r, int h0, int H,
+                                          double* Ut, double* dcl) {
   const int lane = threadIdx.x, li = lane & 15, lg = lane >> 4, K = ev.K;
   const int ncol = NV * (H + 1);           // valid columns of the class's moment rows
+  // embedding weights in A-operand layout: cg[i] = C[neuron(row 4 i + lg)][member li]  (unconditional loads from valid
+  // addresses, then masked: padding rows carry neuron 0).  Fetched here, behind the pass, so that they do not occupy 32
+  // registers through it; C (N K doubles) stays in L1 / L2.
+  double cg[16];
+  {
+    const int mk = __shfl(memk, li < nmem ? li : 0, 64);
+    int nu[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) nu[i] = __shfl(neuron, 4 * i + lg, 64);
+#pragma unroll
+    for (int i = 0; i < 16; ++i) cg[i] = C[(long long)nu[i] * K + mk];          // sixteen independent loads in flight
+#pragma unroll
+    for (int i = 0; i < 16; ++i) cg[i] = (4 * i + lg < nrows && li < nmem) ? cg[i] : 0.0;
+  }
 #pragma unroll
   for (int c0 = 0; c0 < NV * HB; c0 += 16) {
     if (NV * h0 + c0 < ncol) {             // wave-uniform: whole chunks beyond the last harmonic are skipped
@@ -279,64 +327,75 @@ __device__ __forceinline__ void cls_flush(const EngineView& ev, const double (&a
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
           const int s = lg + 4 * q;        // f64 accumulator layout: register q holds row (lane >> 4) + 4 q
-          if (s < nmem) ev.Apart[((long long)tile * K + cls->mem[g][s]) * SV_ACOLS + col] = D[q];
+          const int mk = __shfl(memk, s < nmem ? s : 0, 64);
+          if (s < nmem) ev.Apart[((long long)tile * K + mk) * SV_ACOLS + col] = D[q];
         }
       }
       lds_wave_fence();                    // the tile is free for the next chunk
     }
   }
   if (DC) {
+    // W of the members for this pass's harmonics, staged through the (now idle) transpose tile: [member][2 HB], entries
+    // beyond the last harmonic are zeros (k_spike_pre).  Coalesced loads, all in flight, then broadcast reads.
+    constexpr int WP = 2 * HB;                       // doubles per member and pass
+    const int tot = nmem * WP;
+    double wv[(SV_CLS_MAXMEM * WP + 63) / 64];
+#pragma unroll
+    for (int u = 0; u < (SV_CLS_MAXMEM * WP + 63) / 64; ++u) {
+      const int e = u * 64 + lane, sm = (e < tot) ? e / WP : 0, c = (e < tot) ? e % WP : 0;
+      const int mk = __shfl(memk, sm, 64);
+      const int col = 2 * h0 + c;
+      wv[u] = ev.Wb[((long long)r * K + mk) * SV_WCOLS + (col < SV_WCOLS ? col : 0)];
+      if (col >= SV_WCOLS) wv[u] = 0.0;
+    }
+#pragma unroll
+    for (int u = 0; u < (SV_CLS_MAXMEM * WP + 63) / 64; ++u)
+      if (u * 64 + lane < tot) Ut[u * 64 + lane] = wv[u];
+    lds_wave_fence();
     for (int s = 0; s < nmem; ++s) {
-      const double* __restrict__ Wk = ev.Wb + ((long long)r * K + cls->mem[g][s]) * SV_WCOLS + 2 * h0;
+      const double* Wk = Ut + s * WP;
       double v = 0.0;
 #pragma unroll
       for (int n = 0; n < HB; ++n) {
-        if (h0 + n <= SV_FH) {             // W rows are SV_FH + 1 harmonics long, zero beyond H
-          v = fma(acc[NV * n + 0], Wk[2 * n + 0], v);
-          v = fma(acc[NV * n + 1], Wk[2 * n + 1], v);
-        }
+        v = fma(acc[NV * n + 0], Wk[2 * n + 0], v);
+        v = fma(acc[NV * n + 1], Wk[2 * n + 1], v);
       }
       dcl[s * 64 + lane] = (h0 == 0) ? v : dcl[s * 64 + lane] + v;
     }
+    lds_wave_fence();                                // the tile is free for the next pass
   }
 }
 
 template <int NV, bool DC>
 __device__ __forceinline__ void cls_item(const EngineView& ev, const double* __restrict__ C, const SpikeClassTab* cls,
-                                         int g, int tile, double* Ut, double* dcl) {
+                                         int g, int ord, double* Ut, double* dcl) {
   constexpr int HBM = (NV == 2) ? 24 : 16;          // largest register pass: 48 / 64 accumulators
-  const int lane = threadIdx.x, li = lane & 15, lg = lane >> 4, K = ev.K, R = ev.R;
-  const SpikeTile tl = ev.tiles[tile];
-  const int r = tl.trial;
+  const int lane = threadIdx.x, K = ev.K, R = ev.R;
+  const SpikeTile tl = ev.tiles_ord[ord];           // tiles in cost order (a copy: one dependent load less than through an index)
+  const int r = tl.trial, tile = tl.id;
+  // everything the item needs that hangs off (tile, class), requested together
   const int H = ev.cls_H[(long long)g * R + r];
-  if (H < 0) return;                                 // this (trial, class) takes the pair loop
   const double sc = ev.cls_sc[(long long)g * R + r], t0 = ev.cls_t0[(long long)g * R + r];
   const int nmem = cls->nmem[g];
-  SpikeRow row{0, 0, 0, 0};
-  if (lane < tl.nrows) row = ev.rows[tl.row0 + lane];
-  // embedding weights in A-operand layout: cg[i] = C[neuron(row 4 i + lg)][member li]
-  double cg[16];
-#pragma unroll
-  for (int i = 0; i < 16; ++i) {
-    const int rw = 4 * i + lg;
-    const int nu = __shfl(row.neuron, rw, 64);
-    cg[i] = (rw < tl.nrows && li < nmem) ? C[(long long)nu * K + cls->mem[g][li]] : 0.0;
-  }
+  const int memk = cls->mem[g][lane & (SV_CLS_MAXMEM - 1)];     // member list, one entry per lane (read by shuffles)
+  SpikeRow row = ev.rows[tl.row0 + (lane < tl.nrows ? lane : 0)];
+  if (lane >= tl.nrows) row = SpikeRow{0, 0, 0, 0};
+  if (H < 0) return;                                 // this (trial, class) takes the pair loop
   const double* __restrict__ tt = ev.tt + tl.tt_off;
   for (int h0 = 0; h0 <= H; h0 += HBM) {
     const int left = H + 1 - h0;
     if (left > 16 && NV == 2) {
       double acc[NV * 24];
       cls_pass<NV, 24>(tt, tl.maxlen, row.len, lane, t0, sc, h0, acc);
-      cls_flush<NV, 24, DC>(ev, acc, cg, cls, g, nmem, tile, r, h0, H, Ut, dcl);
+      cls_flush<NV, 24, DC>(ev, C, acc, row.neuron, tl.nrows, memk, nmem, tile, r, h0, H, Ut, dcl);
     } else if (left > 8) {
       double acc[NV * 16];
       cls_pass<NV, 16>(tt, tl.maxlen, row.len, lane, t0, sc, h0, acc);
-      cls_flush<NV, 16, DC>(ev, acc, cg, cls, g, nmem, tile, r, h0, H, Ut, dcl);
+      cls_flush<NV, 16, DC>(ev, C, acc, row.neuron, tl.nrows, memk, nmem, tile, r, h0, H, Ut, dcl);
     } else {
       double acc[NV * 8];
       cls_pass<NV, 8>(tt, tl.maxlen, row.len, lane, t0, sc, h0, acc);
-      cls_flush<NV, 8, DC>(ev, acc, cg, cls, g, nmem, tile, r, h0, H, Ut, dcl);
+      cls_flush<NV, 8, DC>(ev, C, acc, row.neuron, tl.nrows, memk, nmem, tile, r, h0, H, Ut, dcl);
     }
   }
   if (DC && row.len > 0) {
@@ -344,7 +403,7 @@ __device__ __forceinline__ void cls_item(const EngineView& ev, const double* __r
     // segment writes plane A and clears plane B, the halves of a cut segment write one plane each -- so the planes stay
     // valid when an item changes between this path and the pair loop; pieces of an oversize segment go to their slot
     for (int s = 0; s < nmem; ++s) {
-      const int k = cls->mem[g][s];
+      const int k = __shfl(memk, s, 64);
       const double v = dcl[s * 64 + lane];
       const long long o = ((long long)r * ev.N + row.neuron) * K + k;
       if (row.kind == 0) {
@@ -363,18 +422,28 @@ __device__ __forceinline__ void cls_item(const EngineView& ev, const double* __r
 
 // Work item = (tile, class); the number of classes is only known on the device, so the grid is a fixed number of
 // single-wave blocks that stride over the items (tiles in the host's cost order, longest first).
-// FULL: Z / theta gradients wanted (periodic classes then carry the time-weighted moments); DC: dC wanted.
-template <bool FULL, bool DC>
-__global__ __launch_bounds__(64) void k_spike_cls(EngineView ev, const double* __restrict__ C) {
+// NV = 4: the classes that carry the time-weighted moments (periodic classes when Z / theta gradients are wanted: `full`);
+// NV = 2: all others.  Two kernels rather than one: the NV = 2 pass needs a third fewer registers.  DC: dC wanted.
+template <int NV, bool DC>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 8))) void k_spike_cls(EngineView ev,
+                                                                                             const double* __restrict__ C,
+                                                                                             int full) {
   __shared__ double Ut[64 * 16];
   __shared__ double dcl[DC ? SV_CLS_MAXMEM * 64 : 1];
   const SpikeClassTab* cls = ev.cls;
   const int ncls = cls->ncls;
-  const long long nitems = (long long)ev.ntiles * ncls;
-  for (long long w = blockIdx.x; w < nitems; w += gridDim.x) {
-    const int g = (int)(w % ncls), tile = ev.tile_order[w / ncls];
-    if (FULL && cls->type[g] == SV_PERIODIC) cls_item<4, DC>(ev, C, cls, g, tile, Ut, dcl);
-    else cls_item<2, DC>(ev, C, cls, g, tile, Ut, dcl);
+  int mine = 0;                                  // classes this kernel serves (scalar loop, ncls <= 32)
+  for (int g = 0; g < ncls; ++g) mine += ((full && cls->type[g] == SV_PERIODIC) == (NV == 4)) ? 1 : 0;
+  const int nitems = ev.ntiles * mine;           // ntiles K < 2^31 is checked by the host
+  for (int w = blockIdx.x; w < nitems; w += gridDim.x) {
+    int j = w % mine, g = 0;
+    for (;; ++g) {
+      if ((full && cls->type[g] == SV_PERIODIC) == (NV == 4)) {
+        if (j == 0) break;
+        --j;
+      }
+    }
+    cls_item<NV, DC>(ev, C, cls, g, w / mine, Ut, dcl);
   }
 }
 
@@ -389,28 +458,38 @@ template <bool FULL>
 __global__ __launch_bounds__(64) void k_spike_comb(EngineView ev) {
   __shared__ double Fs[SV_ACOLS];
   __shared__ double cf[3 * (SV_FH + 1)];
-  const int item = blockIdx.x, lane = threadIdx.x, K = ev.K, R = ev.R;
-  if (!ev.ser[item]) return;
+  const int item = blockIdx.x, lane = threadIdx.x, K = ev.K;
+  const SpikeItem it = ev.sitem[item];
+  if (it.H < 0) return;
   const int r = item / K, k = item % K;
   const LatentMeta m = ev.meta[k];
   const int M = m.M;
-  const int g = ev.cls->cls_of[k];
-  const int H = ev.cls_H[(long long)g * R + r];
-  const double sc = ev.cls_sc[(long long)g * R + r], t0 = ev.cls_t0[(long long)g * R + r];
+  const int H = it.H;
+  const double sc = it.sc, t0 = it.t0;
   const KPar p = make_kpar(m, ev.theta + 2 * k);
   const bool TW = FULL && m.ktype == SV_PERIODIC;
   const int NV = TW ? 4 : 2, ncol = NV * (H + 1);
-  cls_coefficients(ev, k, m.ktype, p.h, sc, H, cf);
   const int tl0 = ev.tile_first[r], tl1 = ev.tile_first[r + 1];
+  double zj = t0, aj = 0.0;
+  if (lane < M) {                          // requested before the coefficients are computed
+    zj = ev.Zs[m.offM + (long long)r * M + lane];
+    aj = ev.a[m.offM + (long long)r * M + lane];
+  }
+  cls_coefficients(ev, k, m.ktype, p.h, sc, H, cf);
   for (int c = lane; c < ncol; c += 64) {
     double s = 0.0;
-    for (int t = tl0; t < tl1; ++t) s += ev.Apart[((long long)t * K + k) * SV_ACOLS + c];
+    for (int t = tl0; t < tl1; t += 8) {            // eight tiles' partials in flight, added in tile order
+      double v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = ev.Apart[((long long)(t + u < tl1 ? t + u : t) * K + k) * SV_ACOLS + c];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) s += (t + u < tl1) ? v[u] : 0.0;
+    }
     Fs[c] = s;
   }
   __syncthreads();
   double t0acc = 0.0, t1acc = 0.0;
   if (lane < M) {
-    const double zj = ev.Zs[m.offM + (long long)r * M + lane], aj = ev.a[m.offM + (long long)r * M + lane];
     double sphi, cphi;
     sv_sincos_quarter((zj - t0) * sc, sphi, cphi);
     const double* cN = cf;

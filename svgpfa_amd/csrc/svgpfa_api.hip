@@ -15,6 +15,7 @@
 #include "kernels_item_bwd.h"
 #include "kernels_mfma.h"
 #include "kernels_spike.h"
+#include "kernels_spike_cls.h"
 
 typedef LatentPtrTable PtrTable;
 
@@ -57,9 +58,10 @@ struct svgpfa_engine {
   // runs alone and its hipEvent duration is comparable with the roofline.  SVGPFA_OVERLAP=0 / 1 forces it off / on.
   int side_stream = -1;
   hipStream_t s_side = nullptr;
-  hipEvent_t ev_prep = nullptr, ev_spk = nullptr;
-  int spl = SV_SPL;                             // spikes per lane of the spike pass: 8, or 4 below small_spike_waves
-  long long small_spike_waves = 0;              // SVGPFA_SMALL_SPIKE_WAVES (half-size chunks measured slower: off)
+  hipEvent_t ev_prep = nullptr, ev_spk = nullptr, ev_build = nullptr, ev_cls = nullptr;
+  bool cls_pending = false;                     // k_spike_classes is in flight on the side stream: its users wait for ev_cls
+  bool cls_valid = false;                       // the class table of the spike pass belongs to the current kernel build
+  int grid_cls = 2048, grid_pair = 2048;        // blocks of the two persistent-style spike kernels (resident waves of the chip)
 };
 
 #define HIPCHK(e, call)                                                                  \
@@ -229,6 +231,21 @@ int svgpfa_create(const svgpfa_dims* d, int device, svgpfa_engine** out) {
   DALLOC(e, v.ellq, (size_t)v.nell);
   DALLOC(e, v.ells, (size_t)v.R * v.K); DALLOC(e, v.gthitem, (size_t)v.R * v.K * 2);
   DALLOC(e, v.Mseg, (size_t)v.N * v.K);
+  // class path of the spike pass: class table, per-(class, trial) parameters, per-(trial, latent) switch and sums
+  DALLOC(e, v.cls, 1);
+  HIPCHK(e, hipMemset(v.cls, 0, sizeof(SpikeClassTab)));
+  DALLOC(e, v.cls_t0, (size_t)v.K * v.R); DALLOC(e, v.cls_sc, (size_t)v.K * v.R); DALLOC(e, v.cls_H, (size_t)v.K * v.R);
+  DALLOC(e, v.ser, (size_t)v.R * v.K);
+  HIPCHK(e, hipMemset(v.ser, 0, sizeof(int) * (size_t)v.R * v.K));
+  DALLOC(e, v.sitem, (size_t)v.R * v.K);
+  HIPCHK(e, hipMemset(v.sitem, 0xff, sizeof(SpikeItem) * (size_t)v.R * v.K));     // H = -1
+  DALLOC(e, v.pair_any, 1);
+  HIPCHK(e, hipMemset(v.pair_any, 0xff, sizeof(int)));
+  DALLOC(e, v.Wb, (size_t)v.R * v.K * SV_WCOLS);
+  DALLOC(e, v.P0t, (size_t)v.R * v.sumM); DALLOC(e, v.P1t, (size_t)v.R * v.sumM); DALLOC(e, v.Tt, (size_t)v.R * v.K * 2);
+  HIPCHK(e, hipMemset(v.P0t, 0, sizeof(double) * (size_t)v.R * v.sumM));   // a recording without spikes never runs the pass
+  HIPCHK(e, hipMemset(v.P1t, 0, sizeof(double) * (size_t)v.R * v.sumM));
+  HIPCHK(e, hipMemset(v.Tt, 0, sizeof(double) * (size_t)v.R * v.K * 2));
   DALLOC(e, v.status, 1);
   HIPCHK(e, hipMemset(v.status, 0, sizeof(int)));
   DALLOC(e, v.fin_ticket, 1);
@@ -239,10 +256,23 @@ int svgpfa_create(const svgpfa_dims* d, int device, svgpfa_engine** out) {
   {
     const char* ov = getenv("SVGPFA_OVERLAP");
     if (ov) e->side_stream = atoi(ov) != 0 ? 1 : 0;
-    const char* sw = getenv("SVGPFA_SMALL_SPIKE_WAVES");
-    if (sw) e->small_spike_waves = atoll(sw);
+    // diagnosis / test switches: kernels of a type pair by pair in the spike pass instead of through their cosine series
+    const char* rs = getenv("SVGPFA_RBF_SERIES");
+    v.rbf_series = (rs && atoi(rs) == 0) ? 0 : 1;
+    const char* ps = getenv("SVGPFA_PERIODIC_SERIES");
+    v.per_series = (ps && atoi(ps) == 0) ? 0 : 1;
   }
-  for (hipEvent_t* ev : {&e->ev_prep, &e->ev_spk})
+  {   // the two spike kernels stride a fixed grid over work whose amount is only known on the device: one block per
+      // resident wave slot of the chip (a multiple of 8 for the pair pass's XCD-aware item order)
+    hipDeviceProp_t prop;
+    HIPCHK(e, hipGetDeviceProperties(&prop, device));
+    int bc = 0, bp = 0;
+    HIPCHK(e, hipOccupancyMaxActiveBlocksPerMultiprocessor(&bc, (const void*)k_spike_cls<4, true>, 64, 0));
+    HIPCHK(e, hipOccupancyMaxActiveBlocksPerMultiprocessor(&bp, (const void*)k_spike<true, double, true>, 64, 0));
+    e->grid_cls = std::max(8, prop.multiProcessorCount * std::max(1, bc));
+    e->grid_pair = std::max(8, (prop.multiProcessorCount * std::max(1, bp)) & ~7);
+  }
+  for (hipEvent_t* ev : {&e->ev_prep, &e->ev_spk, &e->ev_build, &e->ev_cls})
     HIPCHK(e, hipEventCreateWithFlags(ev, hipEventDisableTiming));
 
   int rc = 0;
@@ -270,7 +300,7 @@ void svgpfa_destroy(svgpfa_engine* e) {
   if (e->status_host) (void)hipHostFree(e->status_host);
   for (hipStream_t st : {e->s_side})
     if (st) (void)hipStreamDestroy(st);
-  for (hipEvent_t ev : {e->ev_prep, e->ev_spk})
+  for (hipEvent_t ev : {e->ev_prep, e->ev_spk, e->ev_build, e->ev_cls})
     if (ev) (void)hipEventDestroy(ev);
   for (auto& pr : e->ev_pool) {
     (void)hipEventDestroy(pr.first);
@@ -335,28 +365,17 @@ int svgpfa_set_spikes(svgpfa_engine* e, const int64_t* off, const double* times,
   if (S > 0 && (!times || !neuron)) return SVGPFA_ERR_INVALID;
   if (S > 2000000000LL) FAIL(e, SVGPFA_ERR_UNSUPPORTED, "more than 2e9 spikes on one GPU");
   v.S = (int)S;
-  // granularity of the spike pass: optional half-size chunks for small shards (off by default: measured slower)
-  e->spl = ((S + 459) / 460) * v.K < e->small_spike_waves ? 4 : 8;
-  if (e->precision == SVGPFA_PRECISION_MIXED) {
-    // 8 spikes per lane as in fp64: the cosine-series bodies (fp64 in both modes) keep 6-7 doubles per spike in
-    // registers.  16 per lane gave the fp32 PAIR loop 9 % (per-item overheads weigh more there) but would spill the
-    // series bodies, which most latents take; SVGPFA_SPL_F32=16 is for runs known to fall back to the pair loop
-    e->spl = 8;
-    if (getenv("SVGPFA_SPL_F32")) e->spl = atoi(getenv("SVGPFA_SPL_F32")) == 16 ? 16 : 8;
-  }
-  const long long CHUNK = 64LL * e->spl;
+  const long long CHUNK = SV_SPIKE_CHUNK;
   std::vector<int32_t> nh((size_t)S);
   if (S) HIPCHK(e, hipMemcpy(nh.data(), neuron, sizeof(int32_t) * S, hipMemcpyDeviceToHost));
+  std::vector<double> th((size_t)S);
+  if (S) HIPCHK(e, hipMemcpy(th.data(), times, sizeof(double) * S, hipMemcpyDeviceToHost));
   std::vector<double> tlo((size_t)v.R, 0.0), thi((size_t)v.R, 0.0);   // spike-time window per trial (RBF cosine series)
-  {
-    std::vector<double> th((size_t)S);
-    if (S) HIPCHK(e, hipMemcpy(th.data(), times, sizeof(double) * S, hipMemcpyDeviceToHost));
-    for (int r = 0; r < v.R; ++r) {
-      if (off[r + 1] > off[r]) {
-        auto mm = std::minmax_element(th.begin() + off[r], th.begin() + off[r + 1]);
-        tlo[r] = *mm.first;
-        thi[r] = *mm.second;
-      }
+  for (int r = 0; r < v.R; ++r) {
+    if (off[r + 1] > off[r]) {
+      auto mm = std::minmax_element(th.begin() + off[r], th.begin() + off[r + 1]);
+      tlo[r] = *mm.first;
+      thi[r] = *mm.second;
     }
   }
   std::vector<long long> seg((size_t)v.R * v.N + 1);
@@ -398,6 +417,7 @@ int svgpfa_set_spikes(svgpfa_engine* e, const int64_t* off, const double* times,
           if (cur.count == CHUNK) flush();
         } else {
           cur.count += (int)room;
+          cur.split |= 4;              // this chunk's last segment continues in the next chunk
           flush();
           cur = SpikeChunk{r, (int)(len - room), b + room, 2, -1};
         }
@@ -411,6 +431,95 @@ int svgpfa_set_spikes(svgpfa_engine* e, const int64_t* off, const double* times,
   seg[(size_t)v.R * v.N] = S;
   cfirst[v.R] = (int)chunks.size();
   v.nchunks = (int)chunks.size();
+
+  // ---- class path (kernels_spike_cls.h): rows = (trial, neuron) segments, tiles of <= 64 rows of one trial.  To fill the
+  //      trial's last tile, the longest segments are cut in two (each at most once: a cut segment's halves go to the two
+  //      dC planes); the rows are then sorted by length so that the lanes of a tile run loops of similar length.
+  //      Segments longer than a chunk of the pair pass are oversize in both passes: pieces with slots of their own.
+  std::vector<SpikeRow> rows;
+  std::vector<long long> row_start;
+  std::vector<SpikeTile> tiles;
+  std::vector<int> tfirst(v.R + 1), sS_neuron, sS_trial;
+  long long tt_len = 0;
+  for (int r = 0; r < v.R; ++r) {
+    tfirst[r] = (int)tiles.size();
+    std::vector<std::pair<SpikeRow, long long>> tr;       // rows of this trial with their first spike
+    std::vector<size_t> whole;                            // indices of uncut, cuttable rows
+    for (int n = 0; n < v.N; ++n) {
+      const long long b = seg[(size_t)r * v.N + n], len = seg[(size_t)r * v.N + n + 1] - b;
+      if (len <= 0) continue;
+      if (len > CHUNK) {
+        for (long long c = b; c < b + len; c += CHUNK) {
+          tr.push_back({SpikeRow{(int)std::min<long long>(CHUNK, b + len - c), n, 3, (int)sS_neuron.size()}, c});
+          sS_neuron.push_back(n);
+          sS_trial.push_back(r);
+        }
+      } else {
+        if (len >= 2) whole.push_back(tr.size());
+        tr.push_back({SpikeRow{(int)len, n, 0, 0}, b});
+      }
+    }
+    if (tr.empty()) continue;
+    const size_t target = ((tr.size() + 63) / 64) * 64;
+    std::sort(whole.begin(), whole.end(), [&](size_t a, size_t b2) {
+      return tr[a].first.len != tr[b2].first.len ? tr[a].first.len > tr[b2].first.len : a < b2;
+    });
+    for (size_t w = 0; w < whole.size() && tr.size() < target; ++w) {
+      const size_t i = whole[w];
+      const int len = tr[i].first.len, h1 = (len + 1) / 2;
+      const int n = tr[i].first.neuron;
+      const long long b = tr[i].second;
+      tr[i] = {SpikeRow{h1, n, 1, 0}, b};
+      tr.push_back({SpikeRow{len - h1, n, 2, 0}, b + h1});
+    }
+    std::stable_sort(tr.begin(), tr.end(), [](const std::pair<SpikeRow, long long>& a, const std::pair<SpikeRow, long long>& b2) {
+      return a.first.len > b2.first.len;
+    });
+    for (size_t i0 = 0; i0 < tr.size(); i0 += 64) {
+      const int nr = (int)std::min<size_t>(64, tr.size() - i0);
+      SpikeTile tl{r, nr, tr[i0].first.len, (int)rows.size(), tt_len, (int)tiles.size(), 0};
+      for (int i = 0; i < nr; ++i) {
+        rows.push_back(tr[i0 + i].first);
+        row_start.push_back(tr[i0 + i].second);
+      }
+      tt_len += 64LL * tl.maxlen;
+      tiles.push_back(tl);
+    }
+  }
+  tfirst[v.R] = (int)tiles.size();
+  v.nrows = (int)rows.size();
+  v.ntiles = (int)tiles.size();
+  v.nsplitS = (int)sS_neuron.size();
+  std::vector<double> tt((size_t)(tt_len + 4 * 64), 0.0);   // one prefetch group of padding (k_spike_cls reads ahead)
+  for (const SpikeTile& tl : tiles)
+    for (int l = 0; l < tl.nrows; ++l) {
+      const SpikeRow& rw = rows[tl.row0 + l];
+      const long long b = row_start[tl.row0 + l];
+      for (int i = 0; i < rw.len; ++i) tt[(size_t)(tl.tt_off + 64LL * i + l)] = th[(size_t)(b + i)];
+    }
+  std::vector<SpikeTile> tord(tiles);
+  std::stable_sort(tord.begin(), tord.end(), [](const SpikeTile& a, const SpikeTile& b2) { return a.maxlen > b2.maxlen; });
+  {
+    SpikeRow* drow; SpikeTile* dtile; int* dtf; SpikeTile* dto; double* dtt; int* dsn; int* dst;
+    DALLOC(e, drow, rows.size()); DALLOC(e, dtile, tiles.size()); DALLOC(e, dtf, v.R + 1); DALLOC(e, dto, tiles.size());
+    DALLOC(e, dtt, tt.size()); DALLOC(e, dsn, sS_neuron.size()); DALLOC(e, dst, sS_trial.size());
+    if (!rows.empty()) HIPCHK(e, hipMemcpy(drow, rows.data(), sizeof(SpikeRow) * rows.size(), hipMemcpyHostToDevice));
+    if (!tiles.empty()) {
+      HIPCHK(e, hipMemcpy(dtile, tiles.data(), sizeof(SpikeTile) * tiles.size(), hipMemcpyHostToDevice));
+      HIPCHK(e, hipMemcpy(dto, tord.data(), sizeof(SpikeTile) * tord.size(), hipMemcpyHostToDevice));
+    }
+    HIPCHK(e, hipMemcpy(dtf, tfirst.data(), sizeof(int) * (v.R + 1), hipMemcpyHostToDevice));
+    HIPCHK(e, hipMemcpy(dtt, tt.data(), sizeof(double) * tt.size(), hipMemcpyHostToDevice));
+    if (!sS_neuron.empty()) {
+      HIPCHK(e, hipMemcpy(dsn, sS_neuron.data(), sizeof(int) * sS_neuron.size(), hipMemcpyHostToDevice));
+      HIPCHK(e, hipMemcpy(dst, sS_trial.data(), sizeof(int) * sS_trial.size(), hipMemcpyHostToDevice));
+    }
+    v.rows = drow; v.tiles = dtile; v.tile_first = dtf; v.tiles_ord = dto; v.tt = dtt;
+    v.splitS_neuron = dsn; v.splitS_trial = dst;
+    DALLOC(e, v.splitS, (size_t)std::max(v.nsplitS, 1) * v.K);
+    HIPCHK(e, hipMemset(v.splitS, 0, sizeof(double) * (size_t)std::max(v.nsplitS, 1) * v.K));
+    DALLOC(e, v.Apart, (size_t)std::max(v.ntiles, 1) * v.K * SV_ACOLS);
+  }
 
   double* st; int* sn; long long* so; long long* sg; double* sc; SpikeChunk* dc; int* cf; int* sp;
   DALLOC(e, st, S); DALLOC(e, sn, S); DALLOC(e, so, v.R + 1); DALLOC(e, sg, seg.size());
@@ -436,8 +545,6 @@ int svgpfa_set_spikes(svgpfa_engine* e, const int64_t* off, const double* times,
     HIPCHK(e, hipMemcpy(dlo, tlo.data(), sizeof(double) * v.R, hipMemcpyHostToDevice));
     HIPCHK(e, hipMemcpy(dhi, thi.data(), sizeof(double) * v.R, hipMemcpyHostToDevice));
     v.spk_lo = dlo; v.spk_hi = dhi;
-    const char* rs = getenv("SVGPFA_RBF_SERIES");
-    v.rbf_series = (rs && atoi(rs) == 0) ? 0 : 1;
   }
   v.spk_t = st; v.spk_n = sn; v.spk_off = so; v.seg_off = sg; v.spk_cnt = sc; v.chunks = dc; v.chunk_first = cf;
   DALLOC(e, v.P0, (size_t)v.nchunks * v.sumM); DALLOC(e, v.P1, (size_t)v.nchunks * v.sumM);
@@ -453,6 +560,7 @@ int svgpfa_set_spikes(svgpfa_engine* e, const int64_t* off, const double* times,
   e->have_spikes = true;
   e->have_stats = false;
   e->p0_token = 0;
+  e->cls_valid = false;
   return SVGPFA_OK;
 }
 
@@ -475,6 +583,20 @@ static void launch_build(svgpfa_engine* e, int write_aux, const SnapTable* snap)
   }
 }
 
+// Classes of the spike pass's class path for the current kernel snapshot (needs the spikes' windows): with the kernel build,
+// or before the first spike pass when the spikes arrived after the build.
+// It runs on the side stream, beside whatever follows the kernel build on the main stream (k_prep at least): the spike pass
+// waits for its event.
+static void launch_classes(svgpfa_engine* e) {
+  (void)hipEventRecord(e->ev_build, e->stream);
+  (void)hipStreamWaitEvent(e->s_side, e->ev_build, 0);
+  (void)hipMemsetAsync(e->v.pair_any, 0, sizeof(int), e->s_side);
+  hipLaunchKernelGGL(k_spike_classes, dim3((e->v.R + 3) / 4), dim3(256), 0, e->s_side, e->v);
+  (void)hipEventRecord(e->ev_cls, e->s_side);
+  e->cls_valid = true;
+  e->cls_pending = true;
+}
+
 int svgpfa_build_kernels(svgpfa_engine* e, const double* const* Z, const double* const* theta) {
   if (!e || !Z || !theta) return SVGPFA_ERR_INVALID;
   HIPCHK(e, hipSetDevice(e->device));   // the caller's thread may have another device current
@@ -489,6 +611,8 @@ int svgpfa_build_kernels(svgpfa_engine* e, const double* const* Z, const double*
   launch_build(e, 0, &st);
   e->aux_valid = false;
   e->p0_token = 0;
+  e->cls_valid = false;
+  if (e->have_spikes) launch_classes(e);
   HIPCHK(e, hipGetLastError());
   e->have_kernels = true;
   e->have_stats = false;
@@ -587,28 +711,48 @@ static std::pair<hipEvent_t, hipEvent_t>* timing_begin(svgpfa_engine* e, int slo
   return evp;
 }
 
-// The spike-time pass on stream sk.  full: Z / theta gradient sums wanted too; want_c: the spike means and their per-neuron
-// sums (dC) wanted (only with full).
+// Readers of the class table (ser / sitem / pair_any) on a stream other than the side stream wait for k_spike_classes once.
+static void wait_classes(svgpfa_engine* e, hipStream_t st) {
+  if (!e->cls_pending || st == e->s_side) return;
+  (void)hipStreamWaitEvent(st, e->ev_cls, 0);
+  if (st == e->stream) e->cls_pending = false;
+}
+
+// The spike-time pass on stream sk.  full: Z / theta gradient sums wanted too; want_c: the spike means' per-neuron sums (dC)
+// wanted (only with full).  Class path (cosine series, kernels_spike_cls.h) for the (trial, latent) items it serves, the
+// pair-by-pair pass (kernels_spike.h) for the rest; both stride fixed grids over work lists that live on the device.
 static void launch_spike_pass(svgpfa_engine* e, hipStream_t sk, bool full, bool want_c, const double* C) {
   EngineView& v = e->v;
-  const dim3 gs(v.nchunks * v.K), bs(64);
-  if (e->precision == SVGPFA_PRECISION_MIXED) {
-    if (e->spl == 16) {
-      if (full) hipLaunchKernelGGL((k_spike<true, 16, float>), gs, bs, 0, sk, v, C);
-      else hipLaunchKernelGGL((k_spike<false, 16, float>), gs, bs, 0, sk, v, C);
+  wait_classes(e, sk);
+  const dim3 bs(64);
+  const dim3 gi(v.R * v.K);
+  const dim3 gc((unsigned)std::min<long long>((long long)v.ntiles * v.K, e->grid_cls));
+  if (v.ntiles > 0) {
+    // the classes with time-weighted moments (periodic, when Z / theta gradients are wanted) have a kernel of their own
+    const bool tw = full && v.ntype[SV_PERIODIC] > 0;
+    if (full && want_c) {
+      hipLaunchKernelGGL(k_spike_pre, gi, bs, 0, sk, v);
+      if (tw) hipLaunchKernelGGL((k_spike_cls<4, true>), gc, bs, 0, sk, v, C, 1);
+      hipLaunchKernelGGL((k_spike_cls<2, true>), gc, bs, 0, sk, v, C, 1);
     } else {
-      if (full && !want_c) hipLaunchKernelGGL((k_spike<true, 8, float, false>), gs, bs, 0, sk, v, C);
-      else if (full) hipLaunchKernelGGL((k_spike<true, 8, float>), gs, bs, 0, sk, v, C);
-      else hipLaunchKernelGGL((k_spike<false, 8, float>), gs, bs, 0, sk, v, C);
+      if (tw) hipLaunchKernelGGL((k_spike_cls<4, false>), gc, bs, 0, sk, v, C, 1);
+      hipLaunchKernelGGL((k_spike_cls<2, false>), gc, bs, 0, sk, v, C, full ? 1 : 0);
     }
-  } else if (e->spl == 4) {
-    if (full) hipLaunchKernelGGL((k_spike<true, 4>), gs, bs, 0, sk, v, C);
-    else hipLaunchKernelGGL((k_spike<false, 4>), gs, bs, 0, sk, v, C);
-  } else {
-    // kernel-parameter / inducing-point closures (no embedding gradient): the series bodies skip the spike means
-    if (full && !want_c) hipLaunchKernelGGL((k_spike<true, 8, double, false>), gs, bs, 0, sk, v, C);
-    else if (full) hipLaunchKernelGGL((k_spike<true, 8>), gs, bs, 0, sk, v, C);
-    else hipLaunchKernelGGL((k_spike<false, 8>), gs, bs, 0, sk, v, C);
+  }
+  if (full) hipLaunchKernelGGL(k_spike_comb<true>, gi, bs, 0, sk, v);
+  else hipLaunchKernelGGL(k_spike_comb<false>, gi, bs, 0, sk, v);
+  const long long npair = (long long)v.nchunks * v.K;
+  const dim3 gp((unsigned)std::min<long long>((npair + 7) & ~7LL, e->grid_pair));
+  if (npair > 0) {
+    if (e->precision == SVGPFA_PRECISION_MIXED) {
+      if (full && !want_c) hipLaunchKernelGGL((k_spike<true, float, false>), gp, bs, 0, sk, v, C);
+      else if (full) hipLaunchKernelGGL((k_spike<true, float>), gp, bs, 0, sk, v, C);
+      else hipLaunchKernelGGL((k_spike<false, float>), gp, bs, 0, sk, v, C);
+    } else {
+      if (full && !want_c) hipLaunchKernelGGL((k_spike<true, double, false>), gp, bs, 0, sk, v, C);
+      else if (full) hipLaunchKernelGGL((k_spike<true>), gp, bs, 0, sk, v, C);
+      else hipLaunchKernelGGL((k_spike<false>), gp, bs, 0, sk, v, C);
+    }
   }
 }
 
@@ -632,6 +776,7 @@ int svgpfa_elbo(svgpfa_engine* e, const double* const* mean, const double* const
   const bool want_lat = (mask & (1u | 4u | 8u)) != 0;
   const bool full = (mask & (2u | 4u | 8u)) != 0;
 
+  if (!e->cls_valid) launch_classes(e);   // spikes set after the last kernel build
   launch_prep(e, pt);
   hipStream_t sm = e->stream;
   const bool side = v.nchunks > 0 &&
@@ -658,6 +803,7 @@ int svgpfa_elbo(svgpfa_engine* e, const double* const* mean, const double* const
   if ((rc = launch_quad_ell(e, C, d, (mask & 2u) ? 1 : 0, want_lat ? 1 : 0))) return rc;
   // ---- join the spike pass; per-item adjoints + backward + the fixed-order cross-trial reductions in one kernel
   if (side) HIPCHK(e, hipStreamWaitEvent(sm, e->ev_spk, 0));
+  wait_classes(e, sm);                    // the gather reads ser even when the spike pass was skipped (reused sums)
   std::pair<hipEvent_t, hipEvent_t>* evb = timing_begin(e, 1, sm);
   if (mask & (4u | 8u)) {
     DISPATCH_NT(e->NT, hipLaunchKernelGGL((k_item_bwd<NT_, true>), dim3(v.R * v.K), dim3(64 * e->tile_nw),
@@ -717,6 +863,7 @@ int svgpfa_freeze_stats(svgpfa_engine* e, const double* const* mean, const doubl
   EngineView& v = e->v;
   PtrTable pt;
   if ((rc = fill_ptrs(e, pt, mean, cholvec, nullptr, nullptr, nullptr, 0))) return rc;
+  if (!e->cls_valid) launch_classes(e);
   launch_prep(e, pt);
   if ((rc = launch_times_quad(e))) return rc;
   // the per-neuron sums of the spike means are the spike part of dC, which the spike-time pass makes (cosine series:
@@ -768,6 +915,7 @@ int svgpfa_latent_stats_backward(svgpfa_engine* e, const double* const* mean, co
     }
   }
   const unsigned m2 = mask | SV_MASK_STATS;
+  wait_classes(e, e->stream);
   if (mask & (4u | 8u)) {
     DISPATCH_NT(e->NT, hipLaunchKernelGGL((k_item_bwd<NT_, true>), dim3(v.R * v.K), dim3(64 * e->tile_nw),
                                           lds_item_bwd(NT_, e->tile_nw, true), e->stream, v, pt, m2, (const double*)nullptr,

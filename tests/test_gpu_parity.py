@@ -252,18 +252,35 @@ def test_trials_of_different_length():
         assert rel_err(out["g_theta"][k], ref["g_theta"][k].numpy()) < TOL_A
 
 
-def test_half_size_spike_chunks(monkeypatch):
-    """Optional 4-spikes-per-lane granularity of the spike pass (SVGPFA_SMALL_SPIKE_WAVES): different chunking,
-    same sums to rounding (tolerance 1e-11 relative on the ELBO, 1e-9 on gradients)."""
-    prob = synthetic.make_problem(R=4, N=15, K=3, M=[12, 16, 9], kernels="mix", seed=21, n_quad=60, rate=60.0, jitter=1.0)
+@pytest.mark.parametrize("case", [
+    dict(R=4, N=15, K=3, M=[12, 16, 9], kernels="mix", seed=21, n_quad=60, rate=60.0),      # whole rows and cut halves
+    dict(R=2, N=3, K=4, M=[10, 12, 9, 14], kernels="mix", seed=22, n_quad=40, rate=1300.0),   # oversize segments: split rows / chunks
+    dict(R=3, N=70, K=2, M=[20, 24], kernels="rbf", seed=23, n_quad=40, rate=9.0),            # two tiles per trial, short rows
+], ids=["halves", "oversize", "two-tiles"])
+def test_class_path_against_pair_path(case, monkeypatch):
+    """The spike pass serves a (trial, latent) item either through the class path (cosine series, per-neuron moments,
+    kernels_spike_cls.h) or pair by pair (kernels_spike.h); SVGPFA_RBF_SERIES=0 / SVGPFA_PERIODIC_SERIES=0 force the latter.
+    Same sums to rounding (1e-11 relative on the ELBO, 1e-9 on gradients) for every kind of row -- whole segments, halves of
+    cut segments, pieces of oversize segments -- and against the oracle."""
+    from oracle import svgpfa_oracle as orc
+    prob = synthetic.make_problem(jitter=1.0, **case)
     outs = []
-    for val in ("0", "1000000000"):
-        monkeypatch.setenv("SVGPFA_SMALL_SPIKE_WAVES", val)
+    for val in ("1", "0"):
+        monkeypatch.setenv("SVGPFA_RBF_SERIES", val)
+        monkeypatch.setenv("SVGPFA_PERIODIC_SERIES", val)
         eng, P = _engine(prob)
+        H = eng.series_harmonics()
+        assert all((h != -1) == (val == "1") for h in H), (val, H)
         shared, gm, gc, gz = eng.elbo(P["mean"], P["cholVecs"], P["C"], P["d"], 15)
         eng.sync()
         outs.append([shared.clone()] + [t.clone() for t in gm + gc + gz])
+        for mask in (0, 2, 12):       # value-only pass, dC only, Z / theta without dC: the other variants of both passes
+            sh2 = eng.elbo(P["mean"], P["cholVecs"], P["C"], P["d"], mask)[0]
+            eng.sync()
+            assert abs(float(sh2[0] - shared[0])) <= 1e-11 * abs(float(shared[0])), (val, mask)
         eng.close()
+    ref = orc.elbo_and_grads(orc.from_numpy_problem(prob), 15)
+    assert _close(float(outs[0][0][0]), float(ref["elbo"]), TOL_S)
     assert abs(float(outs[0][0][0] - outs[1][0][0])) <= 1e-11 * abs(float(outs[0][0][0]))
     for a, b in zip(outs[0], outs[1]):
         assert rel_err(b.cpu().numpy(), a.cpu().numpy()) < 1e-9
@@ -405,7 +422,7 @@ def test_cfg4_eight_way_shards_equal_one_engine(monkeypatch):
     shared vectors [ELBO, ELL, KL, dC, dd, dtheta] must sum to the one-engine vector (1e-11 relative: only the order
     of the cross-trial sums differs) and every shard's per-trial gradients must equal the matching slice of the
     one-engine gradients (1e-12 relative to the array maximum)."""
-    for var in ("SVGPFA_OVERLAP", "SVGPFA_TILE_NW", "SVGPFA_ELL_PARTS", "SVGPFA_SMALL_SPIKE_WAVES"):
+    for var in ("SVGPFA_OVERLAP", "SVGPFA_TILE_NW", "SVGPFA_ELL_PARTS"):
         monkeypatch.delenv(var, raising=False)
     prob = synthetic.make_config("cfg3")
     eng, P = _engine(prob)
