@@ -14,14 +14,14 @@ spike count across ranks (total work fixed: "strong" scaling) and every step end
 all-reduce of the shared vector [ELBO, ELL, KL, dC, dd, dtheta].
 
 Rank 0 prints one JSON line.  Extra objects:
-  roofline     : the kernel with the largest device time in this run -- the spike pass k_spike (fp64
-                 VALU bound) or k_item_bwd (f64 MFMA + VALU), within a few per cent of each other at
-                 cfg3; the other one follows as `roofline_second`.  fp64 operations the kernel must
-                 execute per launch -- counted from its instruction mix (PAIR_FLOPS / SERIES_FLOPS /
-                 item_bwd_flops below, FMA = 2, other fp64 arithmetic = 1, ldexp / cvt = 0; DESIGN.md
-                 section 6) -- over its mean device time from hipEvents recorded inside the timed
-                 region on the stream it is launched on, against the 78.6 TFLOP/s fp64 peak; frac <= 1
-                 by construction.  SURVEY 8(d)'s flop-EQUIVALENT convention (24 per kernel evaluation,
+  roofline     : the kernel with the largest device time in this run -- k_item_bwd (f64 MFMA + VALU) since
+                 round 3; the spike pass (class path: k_spike_pre / k_spike_cls / k_spike_comb, plus the
+                 pair-by-pair k_spike for items without a series; fp64 VALU bound) follows as
+                 `roofline_second`.  fp64 operations the kernel(s) must execute per launch -- counted
+                 from the instruction mix (class_path_flops / PAIR_FLOPS / item_bwd_flops below, FMA = 2,
+                 other fp64 arithmetic = 1, ldexp / cvt = 0) -- over the mean device
+                 time from hipEvents recorded inside the timed region on the stream of the launch,
+                 against the 78.6 TFLOP/s fp64 peak; frac <= 1 by construction.  SURVEY 8(d)'s flop-EQUIVALENT convention (24 per kernel evaluation,
                  x3 for value + gradients) is reported beside it as `survey_convention_*`, never
                  as `frac`.
   cpu_baseline : the CPU oracle (oracle/svgpfa_oracle.py, PyTorch-CPU fp64, the reference's
@@ -34,6 +34,8 @@ import math
 import os
 import sys
 import time
+
+import numpy as np
 
 REPO = os.path.dirname(os.path.abspath(__file__))
 if REPO not in sys.path:
@@ -61,52 +63,81 @@ PAIR_FLOPS_F32 = {("exponentialQuadratic", True): 11, ("periodic", True): 17,
 FP32_PEAK_TFLOPS = 157.3  # MI355X fp32 vector peak (MI355X_MICROARCH.md)
 
 
-# Periodic latents whose kernel the pass evaluates through its cosine series (svgpfa_get_series_harmonics: H >= 0): per
-# (spike, harmonic) 4 FMA for the moments + 2 FMA for mu + a rotation (2 mul + 2 FMA) = 18 flops with gradients, 2 FMA +
-# rotation = 10 value-only, for H + 1 harmonics -- instead of M pairs.
-SERIES_FLOPS = {True: 18, False: 10}
-# RBF latents (series_harmonics[k] = -2): the same through the cosine series of the periodised Gaussian, no time-weighted
-# moments: 2 FMA moments + 2 FMA mu + rotation = 14 flops per (spike, harmonic), 10 value-only.
-SERIES_FLOPS_RBF = {True: 14, False: 10}
+# Class path of the spike pass (svgpfa_amd/csrc/kernels_spike_cls.h): latents that share the angular frequency of their
+# cosine series form a class, and a spike costs, per harmonic and CLASS, a rotation (2 mul + 2 FMA = 6 flops) and two adds
+# (8 flops; 12 with the time-weighted moments of a periodic class when Z / theta gradients are wanted).  On top, per
+# (row, member latent, harmonic): 4 flops of the A-moment product (f64 MFMA) and, with dC, 4 flops of the row's dC sum.
+# Per-spike set-up (one sincos, loads) and the harmonics a register pass computes beyond H are NOT counted: a lower
+# bound of the executed operations, so the fraction cannot exceed 1.
+CLASS_FLOPS = {2: 8, 4: 12}
 
 
-def rbf_series_terms(prob, k, r):
-    """Harmonics (H + 1) of the RBF series for trial r of latent k, by the device's rule (kernels_spike.h
-    rbf_series_setup); 0 where the pass falls back to the pair loop."""
+def class_plan(prob, harmonics):
+    """The device's class table (k_spike_classes) re-derived on the host: a list of classes, each
+    dict(type, members, H = [harmonics per trial, -1: pair loop])."""
+    R, K = prob["R"], prob["K"]
     off = prob["spike_offsets"]
-    if off[r + 1] == off[r]:
-        return 0
-    t = prob["spike_times"][off[r]:off[r + 1]]
-    z = prob["Z"][k][r]
-    ls = float(prob["theta"][k][0]) / float(prob.get("lengthscale_scales", [1.0] * prob["K"])[k])
-    h = 0.5 / ls ** 2
-    L = (max(t.max(), z.max()) - min(t.min(), z.min())) + math.sqrt(41.5 / h)
-    q = math.pi ** 2 / (h * L * L)
-    nmax = math.sqrt(46.0 / q)
-    H = int(nmax) + 1
-    if not (nmax < 64) or H > 64 or 10 * (H + 2) > 21 * prob["Ms"][k]:
-        return 0
-    return H + 1
+    ls_sc = prob.get("lengthscale_scales", [1.0] * K)
+    p_sc = prob.get("period_scales", [1.0] * K)
+    classes = []
+    per = {}
+    for k in range(K):                                   # periodic: one class per distinct period (<= 16 members)
+        if prob["kernel_types"][k] != "periodic" or harmonics[k] < 0:
+            continue
+        key = float(prob["theta"][k][1]) / float(p_sc[k])
+        lst = per.setdefault(key, [])
+        if len(lst) < 16:
+            lst.append(k)
+    for key, mem in per.items():
+        classes.append(dict(type="periodic", members=mem, H=[max(harmonics[k] for k in mem)] * R))
+    hs = {k: 0.5 / (float(prob["theta"][k][0]) / float(ls_sc[k])) ** 2
+          for k in range(K) if prob["kernel_types"][k] != "periodic" and harmonics[k] == -2}
+    left = dict(hs)
+    while left:                                          # RBF: greedy from the longest lengthscale, members within x2
+        hmin = min(left.values())
+        mem = [k for k in sorted(left) if left[k] <= 4.0 * hmin][:16]
+        for k in mem:
+            left.pop(k)
+        Hs = []
+        sumM = sum(prob["Ms"][k] for k in mem)
+        for r in range(R):
+            t = prob["spike_times"][off[r]:off[r + 1]]
+            lo, hi = (float(t.min()), float(t.max())) if len(t) else (0.0, 0.0)
+            for k in mem:
+                lo, hi = min(lo, float(prob["Z"][k][r].min())), max(hi, float(prob["Z"][k][r].max()))
+            L = (hi - lo) + math.sqrt(41.5 / hmin)
+            H = 0
+            for k in mem:
+                nmax = math.sqrt(46.0 * hs[k] * L * L) / math.pi
+                H = 65 if not (nmax < 64) else max(H, int(nmax) + 1)
+            Hs.append(-1 if (H > 64 or 10 * (H + 2) > 21 * sumM) else H)
+        classes.append(dict(type="rbf", members=mem, H=Hs))
+    return classes
 
 
-def spike_pass_flops(prob, full, table=None, harmonics=None):
-    """Operations one spike pass must execute, this rank's shard: PAIR_FLOPS x (spike, inducing point) pairs, or
-    SERIES_FLOPS x (spike, harmonic) for the latents evaluated through the cosine series."""
+def spike_pass_flops(prob, full, want_c, table=None, harmonics=None):
+    """Operations one spike pass must execute, this rank's shard: the class path's (CLASS_FLOPS per (spike, harmonic,
+    class) + the per-member products) for the (trial, latent) items it serves, PAIR_FLOPS x (spike, inducing point) pairs
+    for the rest.  Returns (class path flops, pair flops)."""
     table = table or PAIR_FLOPS
-    S = int(prob["spike_offsets"][-1])
-    tot = 0.0
     off = prob["spike_offsets"]
+    Sr = np.diff(off).astype(float)
+    Nrows = prob["N"]                                    # ~ one row per (trial, neuron) with spikes
+    cls_fl, pair_fl = 0.0, 0.0
+    served = np.zeros((prob["R"], prob["K"]), dtype=bool)
+    for c in class_plan(prob, harmonics if harmonics is not None else [-1] * prob["K"]):
+        nv = 4 if (c["type"] == "periodic" and full) else 2
+        for r, H in enumerate(c["H"]):
+            if H < 0:
+                continue
+            served[r, c["members"]] = True
+            cls_fl += Sr[r] * (H + 1) * CLASS_FLOPS[nv]
+            cls_fl += Nrows * len(c["members"]) * (H + 1) * nv * 2                       # A-moment product
+            if want_c:
+                cls_fl += Nrows * len(c["members"]) * (H + 1) * 4                        # dC rows
     for k, (M, t) in enumerate(zip(prob["Ms"], prob["kernel_types"])):
-        H = harmonics[k] if harmonics is not None else -1
-        if H >= 0:
-            tot += S * (H + 1) * SERIES_FLOPS[bool(full)]
-        elif H == -2:
-            for r in range(prob["R"]):
-                nt, Sr = rbf_series_terms(prob, k, r), int(off[r + 1] - off[r])
-                tot += Sr * nt * SERIES_FLOPS_RBF[bool(full)] if nt else Sr * M * table[(t, bool(full))]
-        else:
-            tot += S * M * table[(t, bool(full))]
-    return float(tot)
+        pair_fl += float(Sr[~served[:, k]].sum()) * M * table[(t, bool(full))]
+    return float(cls_fl), float(pair_fl)
 
 
 # k_item_bwd (kernels_item_bwd.h): fp64 operations per (quadrature node, inducing point) of phase 1 on the VALU, from its
@@ -179,9 +210,13 @@ def algorithmic_work(prob, variant):
                                                            for t in prob["kernel_types"])
     bytes_eval = 8 * (S + 2 * R * Q + sum(R * (2 * M + M * (M + 1) // 2) for M in Ms) + N * K + N) \
         + 4 * S + 8 * ngrad + 8
-    # spike pass, compulsory traffic: spike times + neuron ids once per latent type list are NOT counted twice
-    # (algorithmic = once), whitened factors u~ (M), V~ (M^2) in, P0/P1/P2/P3-style partials (4M) out
-    bytes_spike = 12 * S + 8 * sum(R * (M * M + 5 * M) for M in Ms)
+    # spike pass, compulsory traffic of what it actually moves: spike times (8 S; the neuron ids are only used at ingest) and
+    # the row table once, C, Z and a = Kzz^-1 m in; per (trial, latent) the sums P0 / P1 (2 M) and T (2) out; with dC the
+    # two planes of per-(trial, neuron, latent) sums out.  (The class path reads the times once per CLASS: measured
+    # traffic above this figure by that factor is not waste of a kernel, it is the price of separate launches per class.)
+    bytes_spike = 8 * S + 16 * R * N + 8 * (N * K + sum(R * 2 * M for M in Ms)) + 8 * sum(R * (2 * M + 2) for M in Ms)
+    if variant == "all":
+        bytes_spike += 2 * 8 * R * N * K
     return dict(flops_eval=flops_eval, flops_spike=flops_spike, bytes_eval=bytes_eval, bytes_spike=bytes_spike,
                 kernel_evals=T_fwd)
 
@@ -206,9 +241,8 @@ def cpu_baseline(config, variant, sample_trials, reps=3):
     for key in ("Z", "mean", "cholVecs"):
         sub[key] = [a[:ns] for a in sample[key]]
     mask = 15 if variant == "all" else 1
-    # the GPU box exposes every host core, but a 1-GPU job's share is 16 and intra-op threading of these
-    # small fp64 ops does not scale beyond that: use min(16, available)
-    torch.set_num_threads(max(1, min(16, len(os.sched_getaffinity(0)))))
+    # threads = the PHYSICAL cores this process may run on: hyper-thread siblings are counted once
+    torch.set_num_threads(_physical_cores())
     warm = dict(sub)   # tiny warm-up (2 trials) so that one-off torch initialisation is not timed
     warm["R"] = 2
     warm["spike_offsets"] = off[:3].copy()
@@ -234,6 +268,19 @@ def cpu_baseline(config, variant, sample_trials, reps=3):
                        f"(linear in trials; the reference itself is super-linear, SURVEY 3.4)")
 
 
+def _physical_cores():
+    """Distinct (package, core) pairs among the CPUs of this process's affinity mask."""
+    cores = set()
+    for c in os.sched_getaffinity(0):
+        base = "/sys/devices/system/cpu/cpu%d/topology/" % c
+        try:
+            with open(base + "physical_package_id") as f1, open(base + "core_id") as f2:
+                cores.add((f1.read().strip(), f2.read().strip()))
+        except OSError:
+            cores.add(("?", str(c)))
+    return max(1, len(cores))
+
+
 def _cpu_model():
     try:
         with open("/proc/cpuinfo") as fh:
@@ -245,7 +292,7 @@ def _cpu_model():
     return "unknown"
 
 
-def measured_traffic(config, variant, full_mask, prefix="k_spike<"):
+def measured_traffic(config, variant, full_mask, prefix="k_spike"):
     """HBM bytes per launch of the kernel `prefix` from a committed PMC digest (profiles/*_pmc.json, made by
     tests/tools/collect_profiles.sh + digest_profiles.py in separate rocprofv3 --pmc passes of this same
     command).  Counters cannot be read inside the timed run, so the figure comes from a digest -- and only from one
@@ -265,11 +312,16 @@ def measured_traffic(config, variant, full_mask, prefix="k_spike<"):
         tot, n = 0.0, 0     # the spike pass of one evaluation = the k_spike launches of all covariance types
         insts = 0.0
         for k, e in d.get("kernels", {}).items():
-            # the FULL template argument: first of k_spike<FULL, SPL, T, WC>, second of k_item_bwd<NT, FULL>
+            # prefix "k_spike": every kernel of the spike pass (k_spike_pre / _cls / _comb and the pair-by-pair k_spike; the
+            # digest is per config and variant, so they all belong to it); "k_item_bwd<": the FULL template argument (second)
+            # must match the mask
             targs = [a.strip() for a in k[k.find("<") + 1:k.rfind(">")].split(",")] if "<" in k else []
-            full_arg = targs[1 if prefix.startswith("k_item_bwd") else 0] if len(targs) > 1 else ""
-            if k.startswith(prefix) and ((full_arg == "true") == bool(full_mask)) \
-                    and "hbm_read_bytes_raw" in e and "hbm_write_bytes" in e:
+            ok = k.startswith(prefix)
+            if ok and prefix.startswith("k_item_bwd"):
+                ok = len(targs) > 1 and ((targs[1] == "true") == bool(full_mask))
+            if ok and k.startswith("k_spike_classes"):
+                ok = False                      # belongs to the kernel build, not to the pass
+            if ok and "hbm_read_bytes_raw" in e and "hbm_write_bytes" in e:
                 tot += e["hbm_read_bytes_raw"] + e["hbm_write_bytes"]
                 insts += e.get("SQ_INSTS_VALU", 0.0)
                 n += 1
@@ -387,10 +439,18 @@ def main():
         full_pass = bool(mask & 14)
         mixed = args.dtype == "mixed"
         harmonics = eng.series_harmonics()
-        exec_flops = spike_pass_flops(prob, full_pass, PAIR_FLOPS_F32 if mixed else PAIR_FLOPS, harmonics)
-        peak = FP32_PEAK_TFLOPS if mixed else FP64_PEAK_TFLOPS
+        cls_flops, pair_flops = spike_pass_flops(prob, full_pass, bool(mask & 2), PAIR_FLOPS_F32 if mixed else PAIR_FLOPS,
+                                                 harmonics)
+        # the class path is fp64 in both precision modes; only pair-loop items are fp32 in "mixed".  One bound per entry:
+        # the side that has the larger share of the pass's operations names it, each side is priced at its own peak.
         secs = spike_avg_ms * 1e-3
-        achieved = exec_flops / secs / 1e12 if spike_avg_ms > 0 else None
+        pair_peak = FP32_PEAK_TFLOPS if mixed else FP64_PEAK_TFLOPS
+        exec_flops = cls_flops + pair_flops
+        ideal = cls_flops / (FP64_PEAK_TFLOPS * 1e12) + pair_flops / (pair_peak * 1e12)      # seconds at the peaks
+        spike_bound = "valu_fp32" if (mixed and pair_flops > cls_flops) else "valu_fp64"
+        peak = FP32_PEAK_TFLOPS if spike_bound == "valu_fp32" else FP64_PEAK_TFLOPS
+        spike_frac = ideal / secs if spike_avg_ms > 0 else None
+        achieved = spike_frac * peak if spike_frac is not None else None
         conv = work["flops_spike"] / secs / 1e12 if spike_avg_ms > 0 else None
         traffic = measured_traffic(args.config, args.variant, full_pass) if (world == 1 and not mixed) else None
         item_flops = item_bwd_flops(prob, mask)
@@ -425,28 +485,31 @@ def main():
                        "parallelism": f"trials sharded {world}-way by spike count, 1 RCCL all-reduce/step" if world > 1 else "single GPU"},
             "elbo": elbo,
             "roofline": None,
-            "roofline_spike": {"bound": "valu_fp32" if mixed else "valu_fp64", "achieved": achieved, "peak": peak,
-                         "unit": "TFLOP/s", "frac": (achieved / peak) if achieved else None,
+            "roofline_spike": {"bound": spike_bound, "achieved": achieved, "peak": peak,
+                         "unit": "TFLOP/s", "frac": spike_frac,
                          "traffic": traffic[0] if traffic else None,
-                         "traffic_unit": "HBM bytes per spike pass (FETCH_SIZE + WRITE_SIZE of its k_spike launches, separate PMC passes)",
+                         "traffic_unit": "HBM bytes per spike pass (FETCH_SIZE + WRITE_SIZE of its k_spike* launches, separate PMC "
+                                         "passes; FETCH_SIZE under-counts what the Infinity Cache serves, MI355X_MICROARCH.md)",
                          "traffic_source": ("profiles/%s @ csrc %s" % (traffic[1], traffic[3])) if traffic
                          else "none: no committed PMC digest was taken on this device code (csrc %s)" % kernel_source_sha(),
                          "algorithmic_bytes_per_launch": work.get("bytes_spike"),
-                         "kernel": "k_spike<%s%s>" % ("true" if full_pass else "false", ", 8, float" if mixed else ""),
+                         "kernel": "spike pass = k_spike_pre + k_spike_cls<4> + k_spike_cls<2> + k_spike_comb (class path, fp64) "
+                                   "+ k_spike (pair by pair%s)" % (", fp32" if mixed else ""),
                          "kernel_avg_ms": spike_avg_ms, "kernel_launches": launches,
                          "executed_fp64_flops_per_launch": exec_flops,
+                         "class_path_flops_per_launch": cls_flops, "pair_loop_flops_per_launch": pair_flops,
                          "series_harmonics": harmonics,
                          "pair_flops": {"%s/%s" % (t[:3], "full" if f else "value"): v
                                         for (t, f), v in (PAIR_FLOPS_F32 if mixed else PAIR_FLOPS).items()},
-                         "note": "k_spike issues no MFMA: its work is one software 2^y (rndne, sub, 10 FMA, ldexp, cvt) and 3-7 "
-                                 "FMAs per (spike, inducing point) pair on the fp64 VALU; latents whose kernel has a short "
-                                 "cosine series (series_harmonics[k] = H >= 0 periodic, -2 RBF with H per trial) cost 18 / 14 "
-                                 "flops per (spike, harmonic) instead.  `achieved` = fp64 operations the "
-                                 "kernel must execute (FMA = 2, add / mul / rndne = 1, ldexp / cvt = 0; per-spike set-up not "
-                                 "counted) / its hipEvent time; peak = 78.6 TFLOP/s fp64 vector.  survey_convention_* prices a "
-                                 "kernel evaluation at 24 flop-EQUIVALENTS (x3 with gradients) as SURVEY 8(d) does; it is not "
-                                 "a hardware fraction and can exceed the peak.  issued_* prices every VALU instruction the "
-                                 "PMC pass counted as one 64-lane FMA issue slot (an issue-slot figure, not flops).",
+                         "note": "class path: per (spike, harmonic, CLASS of latents sharing an angular frequency) a rotation + "
+                                 "2 adds on the fp64 VALU (8 flops; 12 with time-weighted moments), then per row and member latent "
+                                 "the A-moment product on the f64 MFMA and the dC sum; pair-by-pair items (series_harmonics[k] = -1, "
+                                 "or trials whose window is too long for the lengthscale): one software 2^y + 3-7 FMAs per (spike, "
+                                 "inducing point).  `frac` = time of those operations at the peak of their arithmetic (fp64 78.6, "
+                                 "fp32 157.3 TFLOP/s for pair items in --dtype mixed) / hipEvent time of the whole pass; per-spike "
+                                 "set-up not counted.  survey_convention_* prices a kernel evaluation at 24 flop-EQUIVALENTS (x3 "
+                                 "with gradients) as SURVEY 8(d) does: the class path does not evaluate kernels pair by pair, so "
+                                 "that figure is not a hardware fraction and exceeds the peak.",
                          "survey_convention_flops_eq_per_launch": work["flops_spike"],
                          "survey_convention_tflops_eq": conv,
                          "issued_valu_insts_per_launch": traffic[2] if traffic else None,
@@ -455,14 +518,15 @@ def main():
                          "eval_survey_convention_frac_fp64": work_full["flops_eval"] / world / (ms_per_step * 1e-3) / 1e12 / FP64_PEAK_TFLOPS,
                          "eval_frac_hbm": work_full["bytes_eval"] / world / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS},
         }
-        # `roofline` = the kernel with the largest measured time in THIS run (the spike pass and k_item_bwd are within a
-        # few per cent of each other at cfg3 since the spike pass uses the kernels' cosine series); the other one follows
-        # as `roofline_second`
+        # `roofline` = the larger of the two in THIS run (k_item_bwd since the spike pass took the class path); the other
+        # one follows as `roofline_second`
         spike_first = spike_avg_ms >= item_avg_ms
         out["roofline"] = out.pop("roofline_spike") if spike_first else roof_item
         out["roofline_second"] = roof_item if spike_first else out.pop("roofline_spike")
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.config, args.variant, args.cpu_sample_trials, args.cpu_reps)
+            if args.variant == "all":      # the E-step closure of the same oracle beside it (both variants)
+                out["cpu_baseline_estep"] = cpu_baseline(args.config, "estep", args.cpu_sample_trials, args.cpu_reps)
         print(json.dumps(out), flush=True)
     if use_dist:
         dist.barrier()

@@ -138,7 +138,7 @@ struct EngineView {
   double* cls_t0; double* cls_sc; int* cls_H;      // [class][R]: phase origin, quarter turns per unit time, harmonics (-1: pair loop)
   int* ser;                                        // [R][K]: 1 = the class path serves this (trial, latent), 0 = the pair loop
   SpikeItem* sitem;                                // [R][K]: the same with the (trial, class) parameters
-  int* pair_any;                                   // 1 when some (trial with spikes, latent) is left to the pair loop
+  int* pair_any;                                   // [R]: 1 when some latent of the trial (with spikes) is left to the pair loop
   int nrows, ntiles, nsplitS;
   const SpikeRow* rows;
   const SpikeTile* tiles;                          // contiguous per trial

@@ -415,12 +415,13 @@ __device__ void spike_body(const EngineView& ev, const double* __restrict__ C, i
   }
 }
 
-// One launch over all (chunk, latent) work items; the covariance type is resolved per item.  Registers are capped so
-// that 3 waves / SIMD stay resident.  Which items remain for this pass is only known on the device (ev.ser), so the grid
+// One launch over all (chunk, latent) work items; the covariance type is resolved per item.  Two waves / SIMD: at the cap
+// of three (168 registers) the fp64 FULL variants spilled 42 registers and ran a third slower (0.97 against 0.71 ms for
+// the whole cfg3 pass pair by pair).  Which items remain for this pass is only known on the device (ev.ser), so the grid
 // is a fixed number of single-wave blocks (a multiple of 8) that stride over the items and skip the class path's.
 // WC = false: no embedding gradient wanted (the pair loops compute the spike means anyway).
 template <bool FULL, typename T = double, bool WC = true>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 8))) void k_spike(EngineView ev,
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 8))) void k_spike(EngineView ev,
                                                                                          const double* __restrict__ C) {
   constexpr int SPL = SV_SPL;
   // LDS bounds the waves per CU: RBF full 3 x 8 rows + 4 x 64 (14.5 KB in fp64), periodic full 5 x 4 rows + ~7 x 64 (14 KB),
@@ -434,7 +435,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 8))) void
   // range of chunk-major items: the K blocks that read the same chunk's spike times / neuron ids run on one XCD, back to
   // back, and all but the first find them in its L2 (the item starts with a chain of dependent global loads).  gridDim.x
   // is a multiple of 8, so w and blockIdx.x name the same XCD.
-  if (!*ev.pair_any) return;                                     // every item is served by the class path
+  {   // every item served by the class path (the usual case): leave at once
+    int any = 0;
+    for (int r = threadIdx.x; r < ev.R; r += 64) any |= ev.pair_any[r];
+    if (!__any(any)) return;
+  }
   const int nper = ev.ntype[SV_PERIODIC], nrbf = ev.ntype[SV_RBF], nlat = nper + nrbf;
   const long long nb = (long long)ev.nchunks * nlat;
   for (long long w = blockIdx.x; w < nb; w += gridDim.x) {

@@ -35,67 +35,98 @@
 __global__ __launch_bounds__(256) void k_spike_classes(EngineView ev) {
   __shared__ SpikeClassTab tab;
   __shared__ double par[SV_MAX_K];     // per latent: RBF h = 1 / (2 l^2); periodic 4 / period
-  __shared__ int typ[SV_MAX_K], Hk[SV_MAX_K], Mk[SV_MAX_K];
+  __shared__ int Mk[SV_MAX_K];
+  __shared__ long long offMk[SV_MAX_K];
   __shared__ double lead[SV_MAX_K];    // per class: RBF h of the leader (its longest lengthscale); periodic 4 / period
   __shared__ int clsH[SV_MAX_K], clsM[SV_MAX_K];   // per class: periodic harmonics; sum of the members' M
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, K = ev.K, R = ev.R;
-  if (tid < K) {                         // the latents' parameters, in parallel (the grouping below reads LDS only)
-    const LatentMeta m = ev.meta[tid];
-    const KPar p = make_kpar(m, ev.theta + 2 * tid);
-    par[tid] = (m.ktype == SV_RBF) ? p.h : 4.0 * p.ip;
-    typ[tid] = m.ktype;
-    Mk[tid] = m.M;
-    Hk[tid] = (m.ktype == SV_PERIODIC) ? ev.fourH[tid] : 0;
-  }
-  __syncthreads();
-  if (tid == 0) {
-    tab.ncls = 0;
-    for (int k = 0; k < K; ++k) {
-      tab.cls_of[k] = -1;
-      tab.slot_of[k] = 0;
-    }
-    for (int k = 0; k < K; ++k) {                      // periodic: one class per distinct period
-      if (typ[k] != SV_PERIODIC) continue;
-      const int H = Hk[k];
-      if (H < 0) continue;                             // short lengthscale / few inducing points: pair by pair
-      int g = -1;
-      for (int c = 0; c < tab.ncls; ++c)
-        if (tab.type[c] == SV_PERIODIC && lead[c] == par[k] && tab.nmem[c] < SV_CLS_MAXMEM) { g = c; break; }
-      if (g < 0) {
-        g = tab.ncls++;
-        tab.type[g] = SV_PERIODIC;
-        tab.nmem[g] = 0;
-        lead[g] = par[k];
-        clsH[g] = 0;
-        clsM[g] = 0;
+  // this wave's trial: its loads are requested first, they do not depend on the table
+  const int r = blockIdx.x * 4 + wave;
+  const int rr = r < R ? r : R - 1;
+  const double slo = ev.spk_lo[rr], shi = ev.spk_hi[rr];
+  const bool has_spikes = ev.spk_off[rr + 1] > ev.spk_off[rr];
+  if (wave == 0) {
+    // ---- the class table, one lane per latent (K <= 32), by wave votes: no serial walk through LDS
+    const bool in = lane < K;
+    LatentMeta m = ev.meta[in ? lane : 0];
+    const KPar p = make_kpar(m, ev.theta + 2 * (in ? lane : 0));
+    const double pk = (m.ktype == SV_RBF) ? p.h : 4.0 * p.ip;
+    const int Hl = (in && m.ktype == SV_PERIODIC) ? ev.fourH[lane] : -1;
+    int cls = -1, slot = 0, ncls = 0;
+    // periodic: one class per distinct period (the lowest latent with that period leads it; at most SV_CLS_MAXMEM members,
+    // further ones stay with the pair loop)
+    {
+      const bool el = in && m.ktype == SV_PERIODIC && Hl >= 0;
+      int ld = -1;
+      for (int j = 0; j < K; ++j) {
+        const double pj = __shfl(pk, j, 64);
+        const int ej = __shfl((int)el, j, 64);
+        if (el && ej && pj == pk && ld < 0) ld = j;
       }
-      tab.cls_of[k] = g;
-      tab.slot_of[k] = tab.nmem[g];
-      tab.mem[g][tab.nmem[g]++] = k;
-      clsH[g] = H > clsH[g] ? H : clsH[g];
-      clsM[g] += Mk[k];
-    }
-    if (ev.rbf_series) {                               // RBF: greedy classes from the longest lengthscale down
-      for (;;) {
-        int ld = -1;
-        for (int k = 0; k < K; ++k)
-          if (typ[k] == SV_RBF && tab.cls_of[k] < 0 && par[k] > 0.0 && par[k] < 1e300 && (ld < 0 || par[k] < par[ld])) ld = k;
-        if (ld < 0) break;
-        const int g = tab.ncls++;
-        tab.type[g] = SV_RBF;
-        tab.nmem[g] = 0;
-        lead[g] = par[ld];
-        clsH[g] = 0;
-        clsM[g] = 0;
-        for (int k = 0; k < K; ++k)
-          if (typ[k] == SV_RBF && tab.cls_of[k] < 0 && par[k] > 0.0 && par[k] <= 4.0 * par[ld] && tab.nmem[g] < SV_CLS_MAXMEM) {
-            tab.cls_of[k] = g;
-            tab.slot_of[k] = tab.nmem[g];
-            tab.mem[g][tab.nmem[g]++] = k;
-            clsM[g] += Mk[k];
+      const unsigned long long leaders = __ballot(el && ld == lane);
+      for (int j = 0; j < K; ++j) {                    // members of leader j, in latent order
+        const unsigned long long mem = __ballot(el && ld == j);
+        if ((leaders >> j) & 1ull) {
+          const int g = __popcll(leaders & ((1ull << j) - 1ull));
+          const int sl = __popcll(mem & ((1ull << lane) - 1ull));
+          if (el && ld == j && sl < SV_CLS_MAXMEM) {
+            cls = g;
+            slot = sl;
           }
+        }
+      }
+      ncls = __popcll(leaders);
+      if (el && cls >= 0 && ld == lane) {
+        tab.type[cls] = SV_PERIODIC;
+        lead[cls] = pk;
       }
     }
+    // RBF: greedy classes from the longest lengthscale (smallest h) down, members within a factor 2 of the leader
+    if (ev.rbf_series) {
+      const bool el = in && m.ktype == SV_RBF && pk > 0.0 && pk < 1e300;
+      for (;;) {
+        const bool open = el && cls < 0;
+        double hmin = open ? pk : 1e308;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) hmin = fmin(hmin, __shfl_xor(hmin, o, 64));
+        if (!(hmin < 1e308)) break;
+        const unsigned long long cand = __ballot(open && pk <= 4.0 * hmin);
+        const int sl = __popcll(cand & ((1ull << lane) - 1ull));
+        if (open && pk <= 4.0 * hmin && sl < SV_CLS_MAXMEM) {
+          cls = ncls;
+          slot = sl;
+        }
+        if (lane == 0) {
+          tab.type[ncls] = SV_RBF;
+          lead[ncls] = hmin;
+        }
+        ++ncls;
+      }
+    }
+    if (in) {
+      tab.cls_of[lane] = cls;
+      tab.slot_of[lane] = slot;
+      par[lane] = pk;
+      Mk[lane] = m.M;
+      offMk[lane] = m.offM;
+      if (cls >= 0) tab.mem[cls][slot] = lane;
+    }
+    for (int g = 0; g < ncls; ++g) {                    // per class: members, harmonics (periodic), sum of M
+      const bool mine = in && cls == g;
+      const int nm = __popcll(__ballot(mine));
+      int hh = mine ? Hl : 0, mm = mine ? m.M : 0;
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) {
+        hh = max(hh, __shfl_xor(hh, o, 64));
+        mm += __shfl_xor(mm, o, 64);
+      }
+      if (lane == 0) {
+        tab.nmem[g] = nm;
+        clsH[g] = hh;
+        clsM[g] = mm;
+      }
+    }
+    if (lane == 0) tab.ncls = ncls;
   }
   __syncthreads();
   if (blockIdx.x == 0) {
@@ -103,9 +134,7 @@ __global__ __launch_bounds__(256) void k_spike_classes(EngineView ev) {
     const int* src = (const int*)&tab;
     for (int i = tid; i < (int)(sizeof(SpikeClassTab) / sizeof(int)); i += 256) dst[i] = src[i];
   }
-  const int r = blockIdx.x * 4 + wave;
   if (r >= R) return;
-  const bool has_spikes = ev.spk_off[r + 1] > ev.spk_off[r];
   bool pair = false;                                   // some item of this trial is left to the pair-by-pair pass
   for (int k = lane; k < K; k += 64)
     if (tab.cls_of[k] < 0) {
@@ -119,11 +148,11 @@ __global__ __launch_bounds__(256) void k_spike_classes(EngineView ev) {
     int H = clsH[g];
     if (tab.type[g] == SV_RBF) {
       // window of the (trial, class): all spike times of the trial and all inducing points of the members
-      double lo = ev.spk_lo[r], hi = ev.spk_hi[r];
+      double lo = slo, hi = shi;
       for (int s = 0; s < tab.nmem[g]; ++s) {
-        const LatentMeta m = ev.meta[tab.mem[g][s]];
-        if (lane < m.M) {
-          const double zj = ev.Zs[m.offM + (long long)r * m.M + lane];
+        const int k = tab.mem[g][s];
+        if (lane < Mk[k]) {
+          const double zj = ev.Zs[offMk[k] + (long long)r * Mk[k] + lane];
           lo = fmin(lo, zj);
           hi = fmax(hi, zj);
         }
@@ -158,7 +187,9 @@ __global__ __launch_bounds__(256) void k_spike_classes(EngineView ev) {
       if (H < 0) pair = true;
     }
   }
-  if (has_spikes && __any(pair) && lane == 0) atomicOr(ev.pair_any, 1);
+  // one flag per trial, no reset and no atomics: the pair pass ORs them (k_spike)
+  const bool anyp = __any(pair);
+  if (lane == 0) ev.pair_any[r] = (has_spikes && anyp) ? 1 : 0;
 }
 
 // Series coefficients of latent k on the (trial, class) period: rows c_n | g_n | e_n for n = 0 .. H into cf (LDS,
@@ -255,6 +286,9 @@ __device__ __forceinline__ void cls_pass(const double* __restrict__ tt, int maxl
   double tn[PF];
 #pragma unroll
   for (int u = 0; u < PF; ++u) tn[u] = tt[(long long)u * 64 + lane];
+#if defined(SV_CLS_DIAG) && SV_CLS_DIAG == 2     // diagnosis build: no pass over the spikes (results are wrong)
+  maxlen = 0;
+#endif
   for (int i0 = 0; i0 < maxlen; i0 += PF) {
     double tc[PF];
 #pragma unroll
@@ -296,6 +330,11 @@ __device__ __forceinline__ void cls_flush(const EngineView& ev, const double* __
                                           double* Ut, double* dcl) {
   const int lane = threadIdx.x, li = lane & 15, lg = lane >> 4, K = ev.K;
   const int ncol = NV * (H + 1);           // valid columns of the class's moment rows
+#if defined(SV_CLS_DIAG) && SV_CLS_DIAG == 1     // diagnosis build: no flush (results are wrong), the pass alone is timed
+#pragma unroll
+  for (int c = 0; c < NV * HB; ++c) asm volatile("" ::"v"(acc[c]));
+  return;
+#endif
   // embedding weights in A-operand layout: cg[i] = C[neuron(row 4 i + lg)][member li]  (unconditional loads from valid
   // addresses, then masked: padding rows carry neuron 0).  Fetched here, behind the pass, so that they do not occupy 32
   // registers through it; C (N K doubles) stays in L1 / L2.

@@ -45,6 +45,8 @@ struct svgpfa_engine {
   std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool;  // event pairs, reused
   std::vector<int> ev_slot;                                // which kernel a pair brackets: 0 k_spike, 1 k_item_bwd
   size_t ev_used = 0;
+  double ev_tot[2] = {0.0, 0.0};                           // folded totals per slot (ms) and launches
+  long long ev_cnt[2] = {0, 0};
   std::string err;
   int* status_host = nullptr;  // pinned
   // Launch strategy.  Every kernel is launched ONCE over all latents with the covariance type resolved per block
@@ -57,8 +59,9 @@ struct svgpfa_engine {
   // (R K <= 2048), where every launch under-fills the chip; at full size one stream is kept so that the spike pass
   // runs alone and its hipEvent duration is comparable with the roofline.  SVGPFA_OVERLAP=0 / 1 forces it off / on.
   int side_stream = -1;
-  hipStream_t s_side = nullptr;
-  hipEvent_t ev_prep = nullptr, ev_spk = nullptr, ev_build = nullptr, ev_cls = nullptr;
+  hipStream_t s_side = nullptr, s_side2 = nullptr;   // s_side2: the second class kernel beside the first on small shards
+  hipEvent_t ev_prep = nullptr, ev_spk = nullptr, ev_build = nullptr, ev_cls = nullptr, ev_fork = nullptr, ev_join = nullptr;
+  bool fork_always = false;                     // SVGPFA_FORK=1: the two class kernels on two streams at every size (experiment)
   bool cls_pending = false;                     // k_spike_classes is in flight on the side stream: its users wait for ev_cls
   bool cls_valid = false;                       // the class table of the spike pass belongs to the current kernel build
   int grid_cls = 2048, grid_pair = 2048;        // blocks of the two persistent-style spike kernels (resident waves of the chip)
@@ -239,8 +242,8 @@ int svgpfa_create(const svgpfa_dims* d, int device, svgpfa_engine** out) {
   HIPCHK(e, hipMemset(v.ser, 0, sizeof(int) * (size_t)v.R * v.K));
   DALLOC(e, v.sitem, (size_t)v.R * v.K);
   HIPCHK(e, hipMemset(v.sitem, 0xff, sizeof(SpikeItem) * (size_t)v.R * v.K));     // H = -1
-  DALLOC(e, v.pair_any, 1);
-  HIPCHK(e, hipMemset(v.pair_any, 0xff, sizeof(int)));
+  DALLOC(e, v.pair_any, v.R);
+  HIPCHK(e, hipMemset(v.pair_any, 0xff, sizeof(int) * v.R));
   DALLOC(e, v.Wb, (size_t)v.R * v.K * SV_WCOLS);
   DALLOC(e, v.P0t, (size_t)v.R * v.sumM); DALLOC(e, v.P1t, (size_t)v.R * v.sumM); DALLOC(e, v.Tt, (size_t)v.R * v.K * 2);
   HIPCHK(e, hipMemset(v.P0t, 0, sizeof(double) * (size_t)v.R * v.sumM));   // a recording without spikes never runs the pass
@@ -253,12 +256,15 @@ int svgpfa_create(const svgpfa_dims* d, int device, svgpfa_engine** out) {
   DALLOC(e, v.fin_part, 2 + SV_FIN_NS);
   HIPCHK(e, hipHostMalloc((void**)&e->status_host, sizeof(int)));
   HIPCHK(e, hipStreamCreateWithFlags(&e->s_side, hipStreamNonBlocking));
+  HIPCHK(e, hipStreamCreateWithFlags(&e->s_side2, hipStreamNonBlocking));
   {
     const char* ov = getenv("SVGPFA_OVERLAP");
     if (ov) e->side_stream = atoi(ov) != 0 ? 1 : 0;
     // diagnosis / test switches: kernels of a type pair by pair in the spike pass instead of through their cosine series
     const char* rs = getenv("SVGPFA_RBF_SERIES");
     v.rbf_series = (rs && atoi(rs) == 0) ? 0 : 1;
+    const char* fk = getenv("SVGPFA_FORK");
+    e->fork_always = fk && atoi(fk) != 0;
     const char* ps = getenv("SVGPFA_PERIODIC_SERIES");
     v.per_series = (ps && atoi(ps) == 0) ? 0 : 1;
   }
@@ -272,7 +278,7 @@ int svgpfa_create(const svgpfa_dims* d, int device, svgpfa_engine** out) {
     e->grid_cls = std::max(8, prop.multiProcessorCount * std::max(1, bc));
     e->grid_pair = std::max(8, (prop.multiProcessorCount * std::max(1, bp)) & ~7);
   }
-  for (hipEvent_t* ev : {&e->ev_prep, &e->ev_spk, &e->ev_build, &e->ev_cls})
+  for (hipEvent_t* ev : {&e->ev_prep, &e->ev_spk, &e->ev_build, &e->ev_cls, &e->ev_fork, &e->ev_join})
     HIPCHK(e, hipEventCreateWithFlags(ev, hipEventDisableTiming));
 
   int rc = 0;
@@ -298,9 +304,9 @@ void svgpfa_destroy(svgpfa_engine* e) {
   (void)hipDeviceSynchronize();
   for (void* p : e->allocs) (void)hipFree(p);
   if (e->status_host) (void)hipHostFree(e->status_host);
-  for (hipStream_t st : {e->s_side})
+  for (hipStream_t st : {e->s_side, e->s_side2})
     if (st) (void)hipStreamDestroy(st);
-  for (hipEvent_t ev : {e->ev_prep, e->ev_spk, e->ev_build, e->ev_cls})
+  for (hipEvent_t ev : {e->ev_prep, e->ev_spk, e->ev_build, e->ev_cls, e->ev_fork, e->ev_join})
     if (ev) (void)hipEventDestroy(ev);
   for (auto& pr : e->ev_pool) {
     (void)hipEventDestroy(pr.first);
@@ -590,7 +596,6 @@ static void launch_build(svgpfa_engine* e, int write_aux, const SnapTable* snap)
 static void launch_classes(svgpfa_engine* e) {
   (void)hipEventRecord(e->ev_build, e->stream);
   (void)hipStreamWaitEvent(e->s_side, e->ev_build, 0);
-  (void)hipMemsetAsync(e->v.pair_any, 0, sizeof(int), e->s_side);
   hipLaunchKernelGGL(k_spike_classes, dim3((e->v.R + 3) / 4), dim3(256), 0, e->s_side, e->v);
   (void)hipEventRecord(e->ev_cls, e->s_side);
   e->cls_valid = true;
@@ -696,19 +701,41 @@ static int launch_times_quad(svgpfa_engine* e) {
   return launch_times(e, v.tq, nullptr, v.Q, v.muq, v.varq, (long long)v.K * v.Q, 1LL, (long long)v.Q, 1);
 }
 
-// svgpfa_enable_timing: bracket a kernel with a hipEvent pair on the stream it is launched on
-static std::pair<hipEvent_t, hipEvent_t>* timing_begin(svgpfa_engine* e, int slot, hipStream_t st) {
-  if (!e->timing) return nullptr;
+// svgpfa_enable_timing: bracket a kernel with a hipEvent pair on the stream it is launched on.  Pairs are reused: a query
+// (svgpfa_kernel_ms) folds every recorded pair into per-slot running totals and frees the pool, and so does a full pool
+// (after waiting for its streams), so a long timed run holds at most SV_EV_POOL_MAX pairs.  Returns the pair's index
+// (-1: timing off), never a pointer into the growing vector.
+#define SV_EV_POOL_MAX 4096
+static int fold_events(svgpfa_engine* e) {
+  HIPCHK(e, hipStreamSynchronize(e->stream));
+  for (hipStream_t st : {e->s_side, e->s_side2})
+    if (st) HIPCHK(e, hipStreamSynchronize(st));      // the event pairs live there when the pass is overlapped
+  for (size_t i = 0; i < e->ev_used; ++i) {
+    float ms = 0.f;
+    HIPCHK(e, hipEventElapsedTime(&ms, e->ev_pool[i].first, e->ev_pool[i].second));
+    e->ev_tot[e->ev_slot[i]] += ms;
+    e->ev_cnt[e->ev_slot[i]] += 1;
+  }
+  e->ev_used = 0;
+  return SVGPFA_OK;
+}
+
+static int timing_begin(svgpfa_engine* e, int slot, hipStream_t st) {
+  if (!e->timing) return -1;
+  if (e->ev_used >= SV_EV_POOL_MAX && fold_events(e) != SVGPFA_OK) return -1;
   if (e->ev_used == e->ev_pool.size()) {
     std::pair<hipEvent_t, hipEvent_t> pr;
-    if (hipEventCreate(&pr.first) != hipSuccess || hipEventCreate(&pr.second) != hipSuccess) return nullptr;
+    if (hipEventCreate(&pr.first) != hipSuccess || hipEventCreate(&pr.second) != hipSuccess) return -1;
     e->ev_pool.push_back(pr);
     e->ev_slot.push_back(0);
   }
-  e->ev_slot[e->ev_used] = slot;
-  std::pair<hipEvent_t, hipEvent_t>* evp = &e->ev_pool[e->ev_used++];
-  (void)hipEventRecord(evp->first, st);
-  return evp;
+  const int idx = (int)e->ev_used++;
+  e->ev_slot[idx] = slot;
+  (void)hipEventRecord(e->ev_pool[idx].first, st);
+  return idx;
+}
+static void timing_end(svgpfa_engine* e, int idx, hipStream_t st) {
+  if (idx >= 0) (void)hipEventRecord(e->ev_pool[idx].second, st);
 }
 
 // Readers of the class table (ser / sitem / pair_any) on a stream other than the side stream wait for k_spike_classes once.
@@ -730,13 +757,24 @@ static void launch_spike_pass(svgpfa_engine* e, hipStream_t sk, bool full, bool 
   if (v.ntiles > 0) {
     // the classes with time-weighted moments (periodic, when Z / theta gradients are wanted) have a kernel of their own
     const bool tw = full && v.ntype[SV_PERIODIC] > 0;
+    // small shards (the pass is on the side stream because no kernel fills the chip): the two class kernels side by side
+    const bool fork = tw && (sk == e->s_side || e->fork_always);
+    hipStream_t s4 = fork ? e->s_side2 : sk;
+    if (full && want_c) hipLaunchKernelGGL(k_spike_pre, gi, bs, 0, sk, v);
+    if (fork) {
+      (void)hipEventRecord(e->ev_fork, sk);
+      (void)hipStreamWaitEvent(s4, e->ev_fork, 0);
+    }
     if (full && want_c) {
-      hipLaunchKernelGGL(k_spike_pre, gi, bs, 0, sk, v);
-      if (tw) hipLaunchKernelGGL((k_spike_cls<4, true>), gc, bs, 0, sk, v, C, 1);
+      if (tw) hipLaunchKernelGGL((k_spike_cls<4, true>), gc, bs, 0, s4, v, C, 1);
       hipLaunchKernelGGL((k_spike_cls<2, true>), gc, bs, 0, sk, v, C, 1);
     } else {
-      if (tw) hipLaunchKernelGGL((k_spike_cls<4, false>), gc, bs, 0, sk, v, C, 1);
+      if (tw) hipLaunchKernelGGL((k_spike_cls<4, false>), gc, bs, 0, s4, v, C, 1);
       hipLaunchKernelGGL((k_spike_cls<2, false>), gc, bs, 0, sk, v, C, full ? 1 : 0);
+    }
+    if (fork) {
+      (void)hipEventRecord(e->ev_join, s4);
+      (void)hipStreamWaitEvent(sk, e->ev_join, 0);
     }
   }
   if (full) hipLaunchKernelGGL(k_spike_comb<true>, gi, bs, 0, sk, v);
@@ -793,9 +831,9 @@ int svgpfa_elbo(svgpfa_engine* e, const double* const* mean, const double* const
     // only a value-only pass leaves reusable sums: the full pass accumulates P0 with different roundings, and
     // cached and un-cached evaluations are to stay bit-identical
     e->p0_token = full ? 0 : e->emb_token;
-    std::pair<hipEvent_t, hipEvent_t>* evp = timing_begin(e, 0, sk);
+    const int evp = timing_begin(e, 0, sk);
     launch_spike_pass(e, sk, full, (mask & 2u) != 0, C);
-    if (evp) HIPCHK(e, hipEventRecord(evp->second, sk));
+    timing_end(e, evp, sk);
     if (side) HIPCHK(e, hipEventRecord(e->ev_spk, sk));
   }
   // ---- quadrature chain (f64 MFMA): posterior stats -> ELL term
@@ -804,7 +842,7 @@ int svgpfa_elbo(svgpfa_engine* e, const double* const* mean, const double* const
   // ---- join the spike pass; per-item adjoints + backward + the fixed-order cross-trial reductions in one kernel
   if (side) HIPCHK(e, hipStreamWaitEvent(sm, e->ev_spk, 0));
   wait_classes(e, sm);                    // the gather reads ser even when the spike pass was skipped (reused sums)
-  std::pair<hipEvent_t, hipEvent_t>* evb = timing_begin(e, 1, sm);
+  const int evb = timing_begin(e, 1, sm);
   if (mask & (4u | 8u)) {
     DISPATCH_NT(e->NT, hipLaunchKernelGGL((k_item_bwd<NT_, true>), dim3(v.R * v.K), dim3(64 * e->tile_nw),
                                           lds_item_bwd(NT_, e->tile_nw, true), sm, v, pt, mask, C, d, shared));
@@ -812,7 +850,7 @@ int svgpfa_elbo(svgpfa_engine* e, const double* const* mean, const double* const
     DISPATCH_NT(e->NT, hipLaunchKernelGGL((k_item_bwd<NT_, false>), dim3(v.R * v.K), dim3(64 * e->tile_nw),
                                           lds_item_bwd(NT_, e->tile_nw, false), sm, v, pt, mask, C, d, shared));
   }
-  if (evb) HIPCHK(e, hipEventRecord(evb->second, sm));
+  timing_end(e, evb, sm);
   hipLaunchKernelGGL(k_fin_items, dim3(v.nth_total + SV_FIN_NS), dim3(256), 0, sm, v, mask, shared);
   HIPCHK(e, hipGetLastError());
   return SVGPFA_OK;
@@ -1022,24 +1060,17 @@ int svgpfa_enable_timing(svgpfa_engine* e, int on) {
   if (!e) return SVGPFA_ERR_INVALID;
   e->timing = on != 0;
   e->ev_used = 0;
+  e->ev_tot[0] = e->ev_tot[1] = 0.0;
+  e->ev_cnt[0] = e->ev_cnt[1] = 0;
   return SVGPFA_OK;
 }
 
 int svgpfa_kernel_ms(svgpfa_engine* e, int32_t which, double* total_ms, int32_t* launches) {
   if (!e || !total_ms || !launches || which < 0 || which > 1) return SVGPFA_ERR_INVALID;
-  HIPCHK(e, hipStreamSynchronize(e->stream));
-  if (e->s_side) HIPCHK(e, hipStreamSynchronize(e->s_side));   // the event pairs live there when the pass is overlapped
-  double tot = 0.0;
-  int n = 0;
-  for (size_t i = 0; i < e->ev_used; ++i) {
-    if (e->ev_slot[i] != which) continue;
-    float ms = 0.f;
-    HIPCHK(e, hipEventElapsedTime(&ms, e->ev_pool[i].first, e->ev_pool[i].second));
-    tot += ms;
-    ++n;
-  }
-  *total_ms = tot;
-  *launches = n;
+  int rc = fold_events(e);
+  if (rc) return rc;
+  *total_ms = e->ev_tot[which];
+  *launches = (int32_t)e->ev_cnt[which];
   return SVGPFA_OK;
 }
 

@@ -87,9 +87,12 @@ class Engine:
         if len(tensors) != self.K:
             raise ValueError("expected one tensor per latent")
         ptrs = tuple(t.data_ptr() for t in tensors)
+        # the cache key carries size, dtype and device beside the address: the caching allocator recycles addresses, and a
+        # tensor of another size or type at a recycled address must not ride on the previous tensor's validation
+        key = tuple((t.data_ptr(), t.numel(), t.dtype, t.device, t.is_contiguous()) for t in tensors)
         if slot is not None:
             hit = self._tables.get(slot)
-            if hit is not None and hit[0] == ptrs:
+            if hit is not None and hit[0] == key:
                 return hit[1]
         for k, t in enumerate(tensors):
             self._dev(t)
@@ -97,7 +100,7 @@ class Engine:
                 raise ValueError(f"latent {k}: expected {sizes[k]} elements, got {t.numel()}")
         arr = (ctypes.c_void_p * self.K)(*ptrs)
         if slot is not None:
-            self._tables[slot] = (ptrs, arr)
+            self._tables[slot] = (key, arr)
         return arr
 
     def close(self):
@@ -165,11 +168,12 @@ class Engine:
         mt = self._table(mean, self._szM, "mean")
         ct = self._table(cholvec, self._szP, "chol")
         cd = (C.data_ptr(), d.data_ptr())
-        if self._tables.get("Cd") != cd:
+        cdkey = (cd, C.numel(), d.numel(), C.dtype, d.dtype, C.device, d.device, C.is_contiguous(), d.is_contiguous())
+        if self._tables.get("Cd") != cdkey:
             self._dev(C), self._dev(d)
             if C.numel() != self.N * self.K or d.numel() != self.N:
                 raise ValueError("C must be N x K and d must have N entries")
-            self._tables["Cd"] = cd
+            self._tables["Cd"] = cdkey
         shared = out if out is not None else torch.empty(self.shared_len, dtype=torch.float64, device=self.device)
         g_mean, g_chol, g_Z = grads if grads is not None else self.alloc_grads(grad_mask)
         self._check(self.lib.svgpfa_elbo(self._h, mt, ct, cd[0], cd[1], int(grad_mask), _ptr(shared),

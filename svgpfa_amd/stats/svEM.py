@@ -79,9 +79,9 @@ class SVEM_PyTorch:
                 with open(savePartialFilenamePattern.format(tag), "wb") as f:
                     pickle.dump({"model": model}, f)
 
-        def host_value(t):      # the reference warns inside eval() (svLowerBound.py:51-53); here where the value is read
-            v = t.item()
-            if math.isinf(v):
+        def host_value(t):      # the reference warns inside eval() (svLowerBound.py:51-53); the value eval() returns
+            v = t.item()        # raises that warning itself when an infinite value is read (_BoundValue); values from the
+            if math.isinf(v) and type(t).__name__ != "_BoundValue":      # flat fast path are plain tensors
                 warnings.warn("infinity lower bound detected")
             return v
 

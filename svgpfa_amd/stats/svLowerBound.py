@@ -15,6 +15,9 @@ class keeps the protocol the EM loop relies on (svEM.py:93,106,202,219-263,290):
 Parameter tensors live on the GPU (fp64, contiguous); setInitialParams moves what it is given.
 """
 
+import math
+import warnings
+
 import numpy as np
 import torch
 
@@ -40,6 +43,56 @@ def _pack_group(tensors, device):
         views.append(v)
         o += t.numel()
     return flat, views
+
+
+class _BoundValue(torch.Tensor):
+    """The 0-dim tensor eval() returns.  The reference warns inside eval() when the bound is infinite
+    (svLowerBound.py:51-53) -- a host read per evaluation; here the same warning is raised where the value reaches the
+    host anyway (float(), .item()), so evaluations stay asynchronous and a caller that drives this model with the
+    reference's own svEM.py (float() of every closure value) still sees it."""
+
+    @staticmethod
+    def _checked(v):
+        if isinstance(v, float) and math.isinf(v):
+            warnings.warn("infinity lower bound detected")
+        return v
+
+    def item(self):
+        return _BoundValue._checked(torch.Tensor.item(self))
+
+    def __float__(self):
+        return _BoundValue._checked(float(torch.Tensor.item(self)))
+
+
+class _SumOverRanks(torch.autograd.Function):
+    """y = sum over ranks of x (every rank gets y).  Each rank's own x enters the sum with weight one, so the adjoint of
+    the local x is the adjoint of y."""
+
+    @staticmethod
+    def forward(ctx, model, x):
+        y = x.detach().clone().reshape(1)
+        model._reduce(y)
+        return y.reshape(x.shape)
+
+    @staticmethod
+    def backward(ctx, g):
+        return None, g
+
+
+class _SharedParam(torch.autograd.Function):
+    """Identity on a parameter that every rank holds (C, d, kernel parameters); its gradient is the sum of the ranks'
+    contributions."""
+
+    @staticmethod
+    def forward(ctx, model, p):
+        ctx.model = model
+        return p.view_as(p)
+
+    @staticmethod
+    def backward(ctx, g):
+        g = g.contiguous().clone()
+        ctx.model._reduce(g.view(-1))
+        return None, g
 
 
 class _ELBOFunction(torch.autograd.Function):
@@ -154,23 +207,31 @@ class _LatentStatsFunction(torch.autograd.Function):
             mask |= _lib.GRAD_KERNELS
         if any(need[3 * K:4 * K]):
             mask |= _lib.GRAD_INDPOINTS
-        # the engine returns J^T g_stats - dKL; the node needs J^T g_stats + g_kl dKL = s (J^T (g_stats / s) - dKL), s = -g_kl
-        s = -g_kl
-        z = lambda g, like: (torch.zeros_like(like) if g is None else g) / s
+        # the engine returns E(g) = J^T g_stats - dKL; the node needs J^T g_stats + g_kl dKL:
+        #   g_kl != 0:  s E(g_stats / s) with s = -g_kl  (one engine call; the usual case, loss = ELL - KL has g_kl = -1)
+        #   g_kl == 0 (KL not in the loss, or weighted by 0):  E(g_stats) - E(0)  (two calls; dividing by s would give NaN)
+        # g_kl is read on the host: this node is the general-likelihood path, not the fused hot path.
+        s_host = float(g_kl) if g_kl is not None else 0.0
         muq, varq, mus, vars_ = (torch.empty(eng.R, eng.Q, K, dtype=torch.float64, device=eng.device),) * 2 + \
                                 (torch.empty(eng.S, K, dtype=torch.float64, device=eng.device),) * 2
-        shared, gm, gc, gz = eng.latent_stats_backward(
-            ctx.mean_t, ctx.chol_t, z(g_muq, muq).contiguous(), z(g_varq, varq).contiguous(),
-            z(g_mus, mus).contiguous(), z(g_vars, vars_).contiguous(), mask)
-        gth = eng.split_shared(shared)[5]
-        out = [None]
-        for i in range(4 * K):
-            g = None
-            if need[i]:
-                g = (gm[i] if i < K else gc[i - K] if i < 2 * K else gth[i - 2 * K] if i < 3 * K else gz[i - 3 * K])
-                g = (s * g).reshape(ctx.shapes[i])
-            out.append(g)
-        return tuple(out)
+
+        def engine_grads(scale):
+            z = lambda g, like: (torch.zeros_like(like) if (g is None or scale == 0.0) else g / scale)
+            shared, gm, gc, gz = eng.latent_stats_backward(
+                ctx.mean_t, ctx.chol_t, z(g_muq, muq).contiguous(), z(g_varq, varq).contiguous(),
+                z(g_mus, mus).contiguous(), z(g_vars, vars_).contiguous(), mask)
+            gth = eng.split_shared(shared)[5]
+            return [(gm[i] if i < K else gc[i - K] if i < 2 * K else gth[i - 2 * K] if i < 3 * K else gz[i - 3 * K])
+                    if need[i] else None for i in range(4 * K)]
+
+        if s_host != 0.0:
+            s = -s_host
+            gs = [None if g is None else s * g for g in engine_grads(s)]
+        else:
+            a = [None if g is None else g.clone() for g in engine_grads(1.0)]
+            b = engine_grads(0.0)
+            gs = [None if x is None else x - y for x, y in zip(a, b)]
+        return (None,) + tuple(None if g is None else g.reshape(ctx.shapes[i]) for i, g in enumerate(gs))
 
 
 class SVLowerBound:
@@ -408,8 +469,8 @@ class SVLowerBound:
         theEval = _ELBOFunction.apply(self, *self._mean, *chol, self._C, self._d,
                                       *self._theta(), *self._Z)
         # the reference warns here when the bound is infinite (svLowerBound.py:51-53); reading the value would stall the
-        # host on every evaluation, so the check is made where the value reaches the host anyway (svEM's histories)
-        return theEval
+        # host on every evaluation, so the warning is raised where the value reaches the host (_BoundValue)
+        return theEval.as_subclass(_BoundValue)
 
     def _eval_gauss_hermite(self, chol):
         """ELBO with a caller-supplied link function g and Gauss-Hermite quadrature over the Gaussian posterior of the
@@ -421,18 +482,25 @@ class SVLowerBound:
         Latent statistics and their backward are the engine's; embedding and link are torch on the same GPU."""
         if self._herm is None:
             raise RuntimeError("eLLCalculationParams must hold hermQuadPoints / hermQuadWeights for a non-exponential link")
+        theta, C, d = self._theta(), self._C, self._d
         if self._reduce is not None:
-            raise NotImplementedError("the Gauss-Hermite link is not available with trials sharded over ranks")
-        muq, varq, mus, vars_, kl = _LatentStatsFunction.apply(self, *self._mean, *chol, *self._theta(), *self._Z)
+            # trials sharded over ranks: the shared parameters' gradients are summed over ranks in the backward, the
+            # bound (and its two terms) in the forward; per-trial parameters keep their local gradients
+            theta = [_SharedParam.apply(self, t) for t in theta]
+            C, d = _SharedParam.apply(self, C), _SharedParam.apply(self, d)
+        muq, varq, mus, vars_, kl = _LatentStatsFunction.apply(self, *self._mean, *chol, *theta, *self._Z)
         self._stats_token = None
-        ell = self._gauss_hermite_ell(muq, varq, mus, vars_)
+        ell = self._gauss_hermite_ell(muq, varq, mus, vars_, C, d)
+        if self._reduce is not None:
+            ell, kl = _SumOverRanks.apply(self, ell), _SumOverRanks.apply(self, kl)
         self._last_terms = ((ell - kl).detach(), ell.detach(), kl.detach())
-        return ell - kl
+        return (ell - kl).as_subclass(_BoundValue)
 
-    def _gauss_hermite_ell(self, muq, varq, mus, vars_):
+    def _gauss_hermite_ell(self, muq, varq, mus, vars_, C=None, d=None):
         """Point-process ELL with the Gauss-Hermite link (expectedLogLikelihood.py:215-255) from the latent statistics at
         the quadrature nodes (R x Q x K) and at the spikes (S x K); differentiable in C, d and in the statistics."""
-        C, d = self._C, self._d.reshape(-1)
+        C = self._C if C is None else C
+        d = (self._d if d is None else d).reshape(-1)
         x, w = self._herm
         link = self._link
         eMean = torch.matmul(muq, C.T) + d                       # svEmbedding.py:80-84
@@ -564,8 +632,12 @@ class SVLowerBound:
         if getattr(self, "_link", None) is not None:      # Gauss-Hermite link: the same torch expression as in eval()
             st = self._stats_token
             muq, varq = st["allTimes"]
-            return self._gauss_hermite_ell(muq.detach(), varq.detach(), torch.cat(st["assocTimes"][0]).detach(),
-                                           torch.cat(st["assocTimes"][1]).detach())
+            C, d = self._C, self._d
+            if self._reduce is not None:                  # trials sharded: C, d gradients and the value summed over ranks
+                C, d = _SharedParam.apply(self, C), _SharedParam.apply(self, d)
+            ell = self._gauss_hermite_ell(muq.detach(), varq.detach(), torch.cat(st["assocTimes"][0]).detach(),
+                                          torch.cat(st["assocTimes"][1]).detach(), C, d)
+            return _SumOverRanks.apply(self, ell) if self._reduce is not None else ell
         return _ELLGivenStatsFunction.apply(self, self._C, self._d)
 
     def predictLatents(self, times):

@@ -497,3 +497,82 @@ def test_frozen_stats_equal_full_statistics(name):
             m.flatParams("emb").mul_(1.01)
     with pytest.raises(NotImplementedError):
         m_frozen.evalELLSumAcrossTrialsAndNeurons(svPosteriorOnLatentsStats=s_full)
+
+
+def test_infinite_bound_warns_where_the_value_is_read():
+    """The reference warns inside eval() when the bound is infinite (svLowerBound.py:51-53).  Here eval() stays
+    asynchronous and the tensor it returns raises the same warning when its value reaches the host -- float(), .item() --
+    which is what a caller driving this model with the reference's own svEM.py does with every closure value."""
+    import warnings
+    from svgpfa_amd.stats.svLowerBound import _BoundValue
+    import math
+    prob, _ = load_golden("ragged_small")
+    model = _model(prob)
+    C = model.getSVEmbeddingParams()[0]
+    C.requires_grad_(True)
+    v = model.eval()
+    assert isinstance(v, _BoundValue)
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")
+        assert math.isfinite(float(v)) and math.isfinite((-v).item())      # finite: silent
+    inf = torch.full((), float("inf"), dtype=torch.float64, device=v.device).as_subclass(_BoundValue)
+    with pytest.warns(UserWarning, match="infinity lower bound"):
+        float(inf)
+    with pytest.warns(UserWarning, match="infinity lower bound"):
+        (-inf).item()
+    v.backward()                                                          # still an autograd node
+    assert C.grad is not None and torch.isfinite(C.grad).all()
+
+
+def test_latent_stats_node_without_the_kl_term():
+    """The statistics node carries adjoints of ANY loss built on its outputs: a loss that leaves the KL term out (its
+    adjoint is 0) must give finite gradients -- grad(ELL) = grad(ELL - KL) - grad(-KL) -- not the NaN a division by the
+    KL adjoint would produce."""
+    from svgpfa_amd.stats.svLowerBound import _LatentStatsFunction
+    prob, ref = load_golden("gh_small")
+    model = _build_gh_model(prob, ref, torch.nn.functional.softplus)
+    params = model.getSVPosteriorOnIndPointsParams() + model.getKernelsParams() + model.getIndPointsLocs()
+    for t in params:
+        t.requires_grad_(True)
+    model.buildKernelsMatrices()
+
+    def grads(which):
+        chol = model._chol_vecs()
+        muq, varq, mus, vars_, kl = _LatentStatsFunction.apply(model, *model._mean, *chol, *model._theta(), *model._Z)
+        ell = model._gauss_hermite_ell(muq, varq, mus, vars_)
+        loss = {"ell": ell, "elbo": ell - kl, "mkl": -kl}[which]
+        return [g.clone() for g in torch.autograd.grad(loss, params)]
+
+    g_ell, g_elbo, g_mkl = grads("ell"), grads("elbo"), grads("mkl")
+    for a, b, c in zip(g_ell, g_elbo, g_mkl):
+        assert torch.isfinite(a).all()
+        want = (b - c).cpu().numpy()
+        assert rel_err(a.cpu().numpy(), want) < 1e-9
+
+
+def test_gauss_hermite_model_with_trials_sharded():
+    """The Gauss-Hermite model under trial sharding (the model's _reduce hook = an in-place sum over ranks): the bound and
+    its two terms are summed in the forward, the gradients of the shared parameters (C, d, kernel parameters) in the
+    backward, per-trial parameters keep their local gradients.  Emulated in one process by a reduction that doubles its
+    argument (two ranks holding identical shards): bound and shared gradients double, per-trial gradients do not."""
+    prob, ref = load_golden("gh_small")
+    K = prob["K"]
+    outs = []
+    for shard in (False, True):
+        model = _build_gh_model(prob, ref, torch.nn.functional.softplus)
+        if shard:
+            model._reduce = lambda t: t.mul_(2.0)
+        groups = (model.getSVPosteriorOnIndPointsParams() + model.getSVEmbeddingParams() + model.getKernelsParams()
+                  + model.getIndPointsLocs())
+        for t in groups:
+            t.requires_grad_(True)
+        model.buildKernelsMatrices()
+        val = model.eval()
+        val.backward()
+        outs.append((float(val), [t.grad.clone() for t in groups]))
+    (v1, g1), (v2, g2) = outs
+    assert abs(v2 - 2.0 * v1) <= 1e-12 * abs(v1)
+    shared_idx = set(range(2 * K, 2 * K + 2 + K))                  # C, d, kernel parameters
+    for i, (a, b) in enumerate(zip(g1, g2)):
+        f = 2.0 if i in shared_idx else 1.0
+        assert rel_err(b.cpu().numpy(), f * a.cpu().numpy()) < 1e-12, i
