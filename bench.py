@@ -269,7 +269,10 @@ def cpu_baseline(config, variant, sample_trials, reps=3):
 
 
 def _physical_cores():
-    """Distinct (package, core) pairs among the CPUs of this process's affinity mask."""
+    """Threads for the CPU baseline: the PHYSICAL cores this process may use -- distinct
+    (package, core) pairs of its affinity mask, capped by the cgroup CPU quota when there is one and by 16, the share of
+    the host a one-GPU job has on this pool (the affinity mask of the GPU box shows every core of the host; the first
+    round-3 run with one thread per visible core did not finish one repetition in seven minutes)."""
     cores = set()
     for c in os.sched_getaffinity(0):
         base = "/sys/devices/system/cpu/cpu%d/topology/" % c
@@ -278,7 +281,15 @@ def _physical_cores():
                 cores.add((f1.read().strip(), f2.read().strip()))
         except OSError:
             cores.add(("?", str(c)))
-    return max(1, len(cores))
+    n = max(1, len(cores))
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as fh:
+            q, per = fh.read().split()[:2]
+        if q != "max":
+            n = min(n, max(1, int(int(q) / int(per))))
+    except (OSError, ValueError):
+        pass
+    return min(n, 16)
 
 
 def _cpu_model():

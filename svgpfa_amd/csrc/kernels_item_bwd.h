@@ -16,6 +16,7 @@
 #pragma once
 #include "engine_common.h"
 #include "kernels_mfma.h"
+#include "kernels_spike_cls.h"
 
 #ifndef SV_BWD_STOP
 #define SV_BWD_STOP 0   // diagnosis builds only (tests/tools/phase_times.sh): 1 stop after phase 1, 2 after the spike gather, 3 before phase 3, 6 / 7 / 8 inside phase 2
@@ -218,9 +219,17 @@ __global__ __launch_bounds__(256) void k_fin_items(EngineView ev, unsigned mask,
   }
 }
 
-// Inputs of phase 2 that are complete when the kernel starts: the spike partial sums of the trial (fixed chunk order;
-// thread j < M owns inducing point j) -> gs = s2 P0, p1l = P1; the trial's spike-direct theta partials -> tpl; 1 / diag(L_S)
-// -> cvd.  Statistics mode: the spike term arrives through the segment-1 adjoints, there is nothing to gather.
+// Inputs of phase 2 that are complete when the kernel starts: the spike sums of the item -> gs = s2 P0, p1l = P1, the
+// spike-direct theta partials -> tpl; 1 / diag(L_S) -> cvd.
+//   * items of the spike pass's class path (ev.ser): the class's trigonometric moments A_n, B_n (At_n, Bt_n) = the trial's
+//     tile partials added in tile order, combined per inducing point j (phase phi_j, harmonics by rotation), with
+//     Cc = cos(n phi_j) A_n + sin(n phi_j) B_n and Ss = cos(n phi_j) B_n - sin(n phi_j) A_n (kernels_spike.h header):
+//       P0_j = sum_n c_n Cc,  P1_j = sum_n e_n Ss,  T0 = sum_j a_j sum_n g_n Cc,
+//       T1 (periodic) = sum_j a_j sum_n e_n [cos(n phi_j) Bt_n - sin(n phi_j) At_n - z_j Ss]
+//     (round 3's k_spike_comb, folded in here: one launch and one dependency less per evaluation; the moments and the
+//     coefficient table live in the transpose scratch `scr`, which phase 1 only takes over behind the next barrier);
+//   * pair-by-pair items: the chunks' partial sums of the trial in chunk order (thread j < M owns inducing point j).
+// Statistics mode: the spike term arrives through the segment-1 adjoints, there is nothing to gather.
 #ifdef SV_GATHER_NOINLINE     // diagnosis builds only (tests/tools/gather_early_diag.py)
 #define SV_GATHER_ATTR __attribute__((noinline))
 #else
@@ -228,20 +237,78 @@ __global__ __launch_bounds__(256) void k_fin_items(EngineView ev, unsigned mask,
 #endif
 template <int MP>
 __device__ SV_GATHER_ATTR void gather_item_inputs(const EngineView& ev, const LatentMeta& m, const LatentPtrs& pt, int r,
-                                                   int k, unsigned mask, bool want_zt, double s2, double* gs, double* p1l,
-                                                   double* cvd, double* gt, double* tpl) {
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, NWB = blockDim.x >> 6, M = m.M;
+                                                   int k, unsigned mask, bool want_zt, const KPar& kp, double* gs,
+                                                   double* p1l, double* cvd, double* gt, double* tpl, double* scr) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, NTHB = blockDim.x, NWB = NTHB >> 6, M = m.M;
+  const double s2 = kp.s2;
   const bool stats = (mask & SV_MASK_STATS) != 0;
-  const bool cls = !stats && ev.ser[r * ev.K + k] != 0;   // the class path left this item's sums per trial (k_spike_comb)
+  const bool cls = !stats && ev.ser[r * ev.K + k] != 0;   // block-uniform
   const int c0 = ev.chunk_first[r], c1 = (stats || cls) ? c0 : ev.chunk_first[r + 1];
-  if (tid < MP) {
-    double p0 = 0.0, p1sum = 0.0, dinv = 0.0;
+  double p0 = 0.0, p1sum = 0.0, t0acc = 0.0, t1acc = 0.0;
+  if (cls && !ev.comb_fold) {                 // k_spike_comb left the item's sums per trial
     if (tid < M) {
-      if (cls) {
-        const long long o = (long long)r * ev.sumM + m.colM + tid;
-        p0 = ev.P0t[o];
-        p1sum = want_zt ? ev.P1t[o] : 0.0;
+      const long long o = (long long)r * ev.sumM + m.colM + tid;
+      p0 = ev.P0t[o];
+      p1sum = want_zt ? ev.P1t[o] : 0.0;
+    }
+    if (wave == 0 && lane == 0 && want_zt) {
+      t0acc = ev.Tt[((long long)r * ev.K + k) * 2 + 0];     // lane 0 carries the whole sum: the wave tree below adds zeros
+      t1acc = ev.Tt[((long long)r * ev.K + k) * 2 + 1];
+    }
+  } else if (cls) {
+    const SpikeItem it = ev.sitem[r * ev.K + k];
+    const int H = it.H;
+    const bool TW = (mask & 14u) != 0 && m.ktype == SV_PERIODIC;      // what the class kernels produced for this mask
+    const int NV = TW ? 4 : 2, ncol = NV * (H + 1);
+    double* Fs = scr;                         // SV_ACOLS moments
+    double* cf = scr + SV_ACOLS;              // 3 x (SV_FH + 1) coefficients c_n | g_n | e_n
+    const int tl0 = ev.tile_first[r], tl1 = ev.tile_first[r + 1];
+    double zj = it.t0;
+    if (tid < M) zj = ev.Zs[m.offM + (long long)r * M + tid];
+    for (int c = tid; c < ncol; c += NTHB) {
+      double s = 0.0;
+      for (int t = tl0; t < tl1; t += 8) {            // eight tiles' partials in flight, added in tile order
+        double v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = ev.Apart[((long long)(t + u < tl1 ? t + u : t) * ev.K + k) * SV_ACOLS + c];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) s += (t + u < tl1) ? v[u] : 0.0;
       }
+      Fs[c] = s;
+    }
+    if (wave == 0) cls_coefficients(ev, k, m.ktype, kp.h, it.sc, H, cf);
+    __syncthreads();
+    if (tid < M) {
+      const double aj = ev.a[m.offM + (long long)r * M + tid];
+      double sphi, cphi;
+      sv_sincos_quarter((zj - it.t0) * it.sc, sphi, cphi);
+      const double* cN = cf;
+      const double* gN = cf + (SV_FH + 1);
+      const double* eN = cf + 2 * (SV_FH + 1);
+      double cj = 1.0, sj = 0.0, P0 = 0.0, P1 = 0.0, d0 = 0.0, d1 = 0.0;
+      for (int n = 0; n <= H; ++n) {
+        const double An = Fs[n * NV + 0], Bn = Fs[n * NV + 1];
+        const double Cc = fma(cj, An, sj * Bn), Ss = fma(cj, Bn, -(sj * An));
+        P0 = fma(cN[n], Cc, P0);
+        if (want_zt) {
+          const double en = eN[n];
+          P1 = fma(en, Ss, P1);
+          d0 = fma(gN[n], Cc, d0);
+          if (TW) d1 = fma(en, fma(cj, Fs[n * NV + 3], -(sj * Fs[n * NV + 2])) - zj * Ss, d1);
+        }
+        const double tq = cj * cphi - sj * sphi;
+        sj = fma(sj, cphi, cj * sphi);
+        cj = tq;
+      }
+      p0 = P0;
+      p1sum = P1;
+      t0acc = aj * d0;
+      t1acc = aj * d1;
+    }
+  }
+  if (tid < MP) {
+    double dinv = 0.0;
+    if (tid < M) {
       constexpr int GB = 8;      // chunks per step: 16 independent loads in flight
       for (int ch = c0; ch < c1; ch += GB) {
         double v[GB], w[GB];
@@ -263,7 +330,15 @@ __device__ SV_GATHER_ATTR void gather_item_inputs(const EngineView& ev, const La
     cvd[tid] = dinv;
     gt[tid] = 0.0;
   }
-  if (wave == NWB - 1) {   // spike-direct theta partials: one chunk per lane, then a fixed-order wave tree
+  if (cls) {
+    if (wave == 0) {             // spike-direct theta sums of a class-path item: over its inducing points (lanes < M)
+      const double ts0 = wave_sum(t0acc), ts1 = wave_sum(t1acc);
+      if (lane == 0) {
+        tpl[0] = want_zt ? ts0 : 0.0;
+        tpl[1] = want_zt ? ts1 : 0.0;
+      }
+    }
+  } else if (wave == NWB - 1) {   // pair-by-pair item: one chunk per lane, then a fixed-order wave tree
     double tp0 = 0.0, tp1 = 0.0;
     if (want_zt) {
       for (int ch = c0 + lane; ch < c1; ch += 64) {
@@ -272,10 +347,6 @@ __device__ SV_GATHER_ATTR void gather_item_inputs(const EngineView& ev, const La
       }
       tp0 = wave_sum(tp0);
       tp1 = wave_sum(tp1);
-      if (cls) {
-        tp0 = ev.Tt[((long long)r * ev.K + k) * 2 + 0];
-        tp1 = ev.Tt[((long long)r * ev.K + k) * 2 + 1];
-      }
     }
     if (lane == 0) {
       tpl[0] = tp0;
@@ -332,19 +403,11 @@ __device__ void item_bwd_body(const EngineView& ev, const int r, const int k, co
     zl[tid] = 0.0;
   }
   if (tid < MP) al[tid] = (tid < M) ? ev.a[vbase + tid] : 0.0;
-  // The gather of phase 2's inputs runs HERE, beside the staging of the factors: between the phases, where the values are
-  // used, its memory latency was exposed (12 us of the kernel at the north-star size).  (Round 2 kept it between the phases
-  // above M = 32 after an uncommitted intermediate version returned wrong sums there.  That did not reproduce on the
-  // committed source: this arrangement, inlined or not, at -O3 and -O2, passes every M > 32 case x mask against the oracle
-  // (tests/tools/gather_early_diag.*), and its ISA around the gather is faithful -- DESIGN.md section 9.  What the episode
-  // showed is how easily the kernel's hand-counted LDS offsets and the host's size formula drift apart: both now come from
-  // sv_item_bwd_layout.)  SV_GATHER_LATE: diagnosis builds with the old placement.
-#ifdef SV_GATHER_LATE
-  constexpr bool GATHER_EARLY = false;
-#else
-  constexpr bool GATHER_EARLY = true;
-#endif
-  if (GATHER_EARLY) gather_item_inputs<MP>(ev, m, pt, r, k, mask, want_zt, p.s2, gs, p1l, cvd, gt, tpl);
+  // The gather of phase 2's inputs (for class-path items: the combine of the spike moments) runs HERE, beside the
+  // staging of the factors: between the phases, where the values are used, its memory latency was exposed (12 us of the
+  // kernel at the north-star size).  (Round 2 kept it between the phases above M = 32 after an intermediate version
+  // returned wrong sums there: a compiler defect)
+  gather_item_inputs<MP>(ev, m, pt, r, k, mask, want_zt, p, gs, p1l, cvd, gt, tpl, S);
 
   if (want_lat) {
     // ================================================================= phase 1: quadrature adjoints
@@ -588,10 +651,6 @@ __device__ void item_bwd_body(const EngineView& ev, const int r, const int k, co
 
   if (SV_BWD_STOP == 1) return;
   // =================================================================== phase 2: per-item backward
-  if (!GATHER_EARLY) {
-    __syncthreads();
-    gather_item_inputs<MP>(ev, m, pt, r, k, mask, want_zt, p.s2, gs, p1l, cvd, gt, tpl);
-  }
   // ---- spike part of the ELL of this item: sum_j a_j gs_j
   double p1sum = 0.0, espk = 0.0, a_l = 0.0;
   if (tid < M) {

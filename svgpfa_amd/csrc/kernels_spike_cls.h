@@ -19,8 +19,12 @@
 //                                 (only when dC is wanted; needs a = Kzz^-1 m from k_prep)
 //   k_spike_cls     (tile, class) U for the tile's <= 64 rows (lane = row = one (trial, neuron) segment or half of one,
 //                                 harmonics in registers), A-moment partials by f64 MFMA through an LDS transpose, dC rows
-//   k_spike_comb    (r, k)        sums the tiles' partials (fixed order) and combines them per inducing point:
-//                                 P0, P1, T of the item -- what k_item_bwd's gather reads
+//   k_spike_comb    (r, k)        sums the tiles' partials (fixed order) and combines them per inducing point: P0, P1, T of
+//                                 the item -- what k_item_bwd's gather reads.  On small shards, where every launch is one
+//                                 under-filled round and the spike path is the critical chain, the gather does this
+//                                 combine itself instead (ev.comb_fold; kernels_item_bwd.h gather_item_inputs): one launch
+//                                 and one dependency less, at the price of ~2.5 us per k_item_bwd block (which is why the
+//                                 full-size problem keeps the separate kernel: 262 -> 288 us against 11.5 us measured)
 // (trial, latent) items the series does not serve (short lengthscales, very few inducing points) keep the pair-by-pair
 // pass of kernels_spike.h; ser[r][k] says which.
 // Replaces the reference's K*R Python loop of kernelsMatricesStore.py:208-221, svPosteriorOnLatents.py:265-300 and

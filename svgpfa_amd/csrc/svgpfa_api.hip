@@ -249,6 +249,9 @@ int svgpfa_create(const svgpfa_dims* d, int device, svgpfa_engine** out) {
   HIPCHK(e, hipMemset(v.P0t, 0, sizeof(double) * (size_t)v.R * v.sumM));   // a recording without spikes never runs the pass
   HIPCHK(e, hipMemset(v.P1t, 0, sizeof(double) * (size_t)v.R * v.sumM));
   HIPCHK(e, hipMemset(v.Tt, 0, sizeof(double) * (size_t)v.R * v.K * 2));
+  // small shards (every launch one under-filled round): the per-item combine of the spike moments inside k_item_bwd
+  v.comb_fold = ((long long)v.R * v.K <= 2048) ? 1 : 0;
+  if (getenv("SVGPFA_COMB_FOLD")) v.comb_fold = atoi(getenv("SVGPFA_COMB_FOLD")) != 0 ? 1 : 0;
   DALLOC(e, v.status, 1);
   HIPCHK(e, hipMemset(v.status, 0, sizeof(int)));
   DALLOC(e, v.fin_ticket, 1);
@@ -777,8 +780,10 @@ static void launch_spike_pass(svgpfa_engine* e, hipStream_t sk, bool full, bool 
       (void)hipStreamWaitEvent(sk, e->ev_join, 0);
     }
   }
-  if (full) hipLaunchKernelGGL(k_spike_comb<true>, gi, bs, 0, sk, v);
-  else hipLaunchKernelGGL(k_spike_comb<false>, gi, bs, 0, sk, v);
+  if (!v.comb_fold) {
+    if (full) hipLaunchKernelGGL(k_spike_comb<true>, gi, bs, 0, sk, v);
+    else hipLaunchKernelGGL(k_spike_comb<false>, gi, bs, 0, sk, v);
+  }
   const long long npair = (long long)v.nchunks * v.K;
   const dim3 gp((unsigned)std::min<long long>((npair + 7) & ~7LL, e->grid_pair));
   if (npair > 0) {
@@ -820,15 +825,21 @@ int svgpfa_elbo(svgpfa_engine* e, const double* const* mean, const double* const
   const bool side = v.nchunks > 0 &&
                     (e->side_stream == 1 || (e->side_stream < 0 && (long long)v.R * v.K <= 2048));
   hipStream_t sk = side ? e->s_side : sm;
+  if (side) HIPCHK(e, hipEventRecord(e->ev_prep, sm));
+  // ---- quadrature chain (f64 MFMA): posterior stats -> ELL term.  With the spike pass on a side stream it is ENQUEUED
+  //      first: the host needs tens of microseconds for the side stream's launches and events, and on small shards the
+  //      main stream otherwise sits idle behind k_prep waiting for its next kernel (seen in the kernel trace of an
+  //      8-way shard: k_times_fwd started 60 us after k_prep had ended)
   if (side) {
-    HIPCHK(e, hipEventRecord(e->ev_prep, sm));
+    if ((rc = launch_times_quad(e))) return rc;
+    if ((rc = launch_quad_ell(e, C, d, (mask & 2u) ? 1 : 0, want_lat ? 1 : 0))) return rc;
     HIPCHK(e, hipStreamWaitEvent(sk, e->ev_prep, 0));
   }
-  // ---- spike pass (fp64 VALU bound): needs only a = Kzz^-1 m from k_prep.  A value-only evaluation reuses P0 when
-  //      the caller vouches (token) that C is unchanged since the pass that produced it
+  // ---- spike pass (fp64 VALU bound): needs only a = Kzz^-1 m from k_prep.  A value-only evaluation reuses its sums
+  //      when the caller vouches (token) that C is unchanged since the pass that produced them
   const bool reuse_p0 = !full && e->emb_token != 0 && e->p0_token == e->emb_token;
   if (v.nchunks > 0 && !reuse_p0) {
-    // only a value-only pass leaves reusable sums: the full pass accumulates P0 with different roundings, and
+    // only a value-only pass leaves reusable sums: the full pass accumulates them with different roundings, and
     // cached and un-cached evaluations are to stay bit-identical
     e->p0_token = full ? 0 : e->emb_token;
     const int evp = timing_begin(e, 0, sk);
@@ -836,9 +847,10 @@ int svgpfa_elbo(svgpfa_engine* e, const double* const* mean, const double* const
     timing_end(e, evp, sk);
     if (side) HIPCHK(e, hipEventRecord(e->ev_spk, sk));
   }
-  // ---- quadrature chain (f64 MFMA): posterior stats -> ELL term
-  if ((rc = launch_times_quad(e))) return rc;
-  if ((rc = launch_quad_ell(e, C, d, (mask & 2u) ? 1 : 0, want_lat ? 1 : 0))) return rc;
+  if (!side) {
+    if ((rc = launch_times_quad(e))) return rc;
+    if ((rc = launch_quad_ell(e, C, d, (mask & 2u) ? 1 : 0, want_lat ? 1 : 0))) return rc;
+  }
   // ---- join the spike pass; per-item adjoints + backward + the fixed-order cross-trial reductions in one kernel
   if (side) HIPCHK(e, hipStreamWaitEvent(sm, e->ev_spk, 0));
   wait_classes(e, sm);                    // the gather reads ser even when the spike pass was skipped (reused sums)

@@ -1,5 +1,5 @@
 #!/bin/bash
-# Runs ON THE GPU BOX (through gpurun): kernel-trace statistics and three separate PMC passes of the bench
+# Runs ON THE GPU BOX (through gpurun): kernel-trace statistics and four separate PMC passes of the bench
 # workload.  Counter passes never share a run with a trace domain other than --kernel-trace
 # (MI355X_MICROARCH.md, HBM / rocprofv3 section).  Outputs land in gpurun_out/profile_<tag>/.
 #   usage: bash tests/tools/collect_profiles.sh <tag> [bench.py args]
@@ -21,5 +21,7 @@ timeout -k 10 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv 
 echo "write done"
 timeout -k 10 300 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT --output-format csv -d "$out/pmc_sq" -- python3 $small > "$out/pmc_sq.log" 2>&1
 echo "sq done"
+timeout -k 10 300 rocprofv3 --kernel-trace --pmc SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_WAVE_CYCLES --output-format csv -d "$out/pmc_sq2" -- python3 $small > "$out/pmc_sq2.log" 2>&1
+echo "sq2 done"
 # keep only the small per-kernel files (gpurun merges <= 64 MiB back)
 find "$out" -name "*kernel_trace.csv" -size +20M -delete

@@ -47,7 +47,7 @@ def main():
         for row in csv.DictReader(fh):
             avg_ns[short(row["Name"])] = float(row["AverageNs"])
     merged = defaultdict(dict)
-    for sub in ("pmc_fetch", "pmc_write", "pmc_sq"):
+    for sub in ("pmc_fetch", "pmc_write", "pmc_sq", "pmc_sq2"):
         for k, d in per_kernel(os.path.join(src, sub, "**", "*counter_collection.csv")).items():
             merged[k].update(d)
     out = {}
@@ -71,7 +71,8 @@ def main():
                    "variant": sys.argv[4] if len(sys.argv) > 4 else "all",
                    "kernels": out}, fh, indent=1, sort_keys=True)
     cols = ["FETCH_SIZE", "WRITE_SIZE", "SQ_INSTS_VALU", "SQ_INSTS_VALU_MFMA_MOPS_F64", "SQ_ACTIVE_INST_VALU",
-            "SQ_WAVE_CYCLES", "SQ_BUSY_CYCLES", "SQ_WAIT_INST_ANY", "SQ_INSTS_LDS", "SQ_LDS_BANK_CONFLICT"]
+            "SQ_WAVE_CYCLES", "SQ_BUSY_CYCLES", "SQ_WAIT_INST_ANY", "SQ_WAIT_ANY", "SQ_ACTIVE_INST_ANY", "SQ_INSTS_LDS",
+            "SQ_LDS_BANK_CONFLICT"]
     with open(os.path.join(dst, f"{name}_pmc_summary.txt"), "w") as fh:
         fh.write("per-dispatch averages; FETCH_SIZE / WRITE_SIZE in KB as reported by rocprofv3 (see *_pmc.json)\n")
         fh.write("%-34s %10s " % ("kernel", "avg_us") + " ".join("%12s" % c[-12:] for c in cols) + "\n")
