@@ -357,7 +357,7 @@ __device__ SV_GATHER_ATTR void gather_item_inputs(const EngineView& ev, const La
 
 // ---- phases 1 + 2 --------------------------------------------------------------------------------------------------
 template <int NT, int KT, bool FULL>
-__device__ void item_bwd_body(const EngineView& ev, const int r, const int k, const LatentPtrs pt, unsigned mask,
+__device__ __forceinline__ void item_bwd_body(const EngineView& ev, const int r, const int k, const LatentPtrs pt, unsigned mask,
                               double* sm) {
   constexpr int MP = 16 * NT, LD = MP + 2, NTRI = NT * (NT + 1) / 2, L2S = sv_tr_stride(MP);
   const int tid = threadIdx.x;

@@ -97,7 +97,7 @@ __device__ __forceinline__ void load_factors(const EngineView& ev, const LatentM
 // quadrature statistics use [r][k][q] (os_r = K Q, os_t = 1, os_k = Q): the 16 nodes of a tile are 128 contiguous bytes
 // for this kernel's stores, for the adjoint loads of k_item_bwd and for the ELL kernel's rows.
 template <int NT, int KT>
-__device__ void times_fwd_body(const EngineView& ev, const int r, const int k, const double* times,
+__device__ __forceinline__ void times_fwd_body(const EngineView& ev, const int r, const int k, const double* times,
                                const long long* toff, int nper, double* mu_out, double* var_out, long long os_r,
                                long long os_t, long long os_k, int want_var, double* sm) {
   constexpr int MP = 16 * NT, LD = MP + 2;

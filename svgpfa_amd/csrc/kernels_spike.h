@@ -87,7 +87,7 @@ __device__ __forceinline__ double sv_fma(double a, double b, double c) { return 
 //   sum ck sin(theta - phi) t = cos phi QC - sin phi QD            (-> dtheta_period, minus z_j times the first)
 // (no sin(theta - phi) per pair, no separate sum of ck y).  Five reduction vectors, reduced four inducing points at a time.
 template <int SPL, typename T>
-__device__ void spike_body_periodic_full(const EngineView& ev, const double* __restrict__ C, int ch, int k, double* red_d) {
+__device__ __forceinline__ void spike_body_periodic_full(const EngineView& ev, const double* __restrict__ C, int ch, int k, double* red_d) {
   constexpr int NV = 5, JG = 4;   // 20 rows: 13 KB of LDS per wave (fp64), so that three waves per SIMD fit
   const int lane = threadIdx.x;
   const SpikeChunk c = ev.chunks[ch];
@@ -248,7 +248,7 @@ __device__ void spike_body_periodic_full(const EngineView& ev, const double* __r
 // the kernel is small); the sums they feed are dominated by their large terms.
 
 template <int KT, bool FULL, int SPL, typename T, bool WC = true>
-__device__ void spike_body(const EngineView& ev, const double* __restrict__ C, int ch, int k,
+__device__ __forceinline__ void spike_body(const EngineView& ev, const double* __restrict__ C, int ch, int k,
                            double* red_d) {
   if constexpr (KT == SV_PERIODIC && FULL) {
     spike_body_periodic_full<SPL, T>(ev, C, ch, k, red_d);
