@@ -63,6 +63,8 @@ struct svgpfa_engine {
   hipEvent_t ev_prep = nullptr, ev_spk = nullptr, ev_build = nullptr, ev_cls = nullptr, ev_fork = nullptr, ev_join = nullptr;
   bool fork_always = false;                     // SVGPFA_FORK=1: the two class kernels on two streams at every size (experiment)
   bool cls_pending = false;                     // k_spike_classes is in flight on the side stream: its users wait for ev_cls
+  bool cls_on = true;                           // false: problem too small for the class path's extra launches (set_spikes)
+  double series_min_pairs = 1e7;                // SVGPFA_SERIES_MIN_PAIRS: fewest (spike, inducing point) pairs for the class path
   bool cls_valid = false;                       // the class table of the spike pass belongs to the current kernel build
   int grid_cls = 2048, grid_pair = 2048;        // blocks of the two persistent-style spike kernels (resident waves of the chip)
 };
@@ -266,6 +268,8 @@ int svgpfa_create(const svgpfa_dims* d, int device, svgpfa_engine** out) {
     // diagnosis / test switches: kernels of a type pair by pair in the spike pass instead of through their cosine series
     const char* rs = getenv("SVGPFA_RBF_SERIES");
     v.rbf_series = (rs && atoi(rs) == 0) ? 0 : 1;
+    const char* mp = getenv("SVGPFA_SERIES_MIN_PAIRS");
+    if (mp) e->series_min_pairs = atof(mp);
     const char* fk = getenv("SVGPFA_FORK");
     e->fork_always = fk && atoi(fk) != 0;
     const char* ps = getenv("SVGPFA_PERIODIC_SERIES");
@@ -566,10 +570,14 @@ int svgpfa_set_spikes(svgpfa_engine* e, const int64_t* off, const double* times,
   HIPCHK(e, hipMemset(v.splitPart, 0, sizeof(double) * std::max<size_t>(1, (size_t)v.nchunks * v.K)));
   HIPCHK(e, hipMemset(v.P1, 0, sizeof(double) * std::max<size_t>(1, (size_t)v.nchunks * v.sumM)));
   HIPCHK(e, hipMemset(v.Tpart, 0, sizeof(double) * std::max<size_t>(1, (size_t)v.nchunks * v.K * 2)));
+  // Small problems stay with the single pair-by-pair launch: the class path costs three to four more launches per
+  // evaluation (class table, W, one or two class kernels), which only pays once the pair loop itself takes tens of
+  // microseconds (cfg2, 4e6 pairs: 0.137 ms per evaluation with the class path against 0.11 without)
+  e->cls_on = (double)S * (double)v.sumM >= e->series_min_pairs;
   e->have_spikes = true;
   e->have_stats = false;
   e->p0_token = 0;
-  e->cls_valid = false;
+  e->cls_valid = !e->cls_on;           // nothing to compute when the class path is off: ser stays 0, pair_any stays set
   return SVGPFA_OK;
 }
 
@@ -619,8 +627,8 @@ int svgpfa_build_kernels(svgpfa_engine* e, const double* const* Z, const double*
   launch_build(e, 0, &st);
   e->aux_valid = false;
   e->p0_token = 0;
-  e->cls_valid = false;
-  if (e->have_spikes) launch_classes(e);
+  e->cls_valid = !e->cls_on;
+  if (e->have_spikes && e->cls_on) launch_classes(e);
   HIPCHK(e, hipGetLastError());
   e->have_kernels = true;
   e->have_stats = false;
@@ -757,7 +765,7 @@ static void launch_spike_pass(svgpfa_engine* e, hipStream_t sk, bool full, bool 
   const dim3 bs(64);
   const dim3 gi(v.R * v.K);
   const dim3 gc((unsigned)std::min<long long>((long long)v.ntiles * v.K, e->grid_cls));
-  if (v.ntiles > 0) {
+  if (v.ntiles > 0 && e->cls_on) {
     // the classes with time-weighted moments (periodic, when Z / theta gradients are wanted) have a kernel of their own
     const bool tw = full && v.ntype[SV_PERIODIC] > 0;
     // small shards (the pass is on the side stream because no kernel fills the chip): the two class kernels side by side
@@ -780,7 +788,7 @@ static void launch_spike_pass(svgpfa_engine* e, hipStream_t sk, bool full, bool 
       (void)hipStreamWaitEvent(sk, e->ev_join, 0);
     }
   }
-  if (!v.comb_fold) {
+  if (!v.comb_fold && e->cls_on) {
     if (full) hipLaunchKernelGGL(k_spike_comb<true>, gi, bs, 0, sk, v);
     else hipLaunchKernelGGL(k_spike_comb<false>, gi, bs, 0, sk, v);
   }
@@ -1057,8 +1065,10 @@ int svgpfa_get_series_harmonics(svgpfa_engine* e, int32_t* out_host) {
   if (!e->have_kernels) FAIL(e, SVGPFA_ERR_STATE, "svgpfa_build_kernels has not been called");
   HIPCHK(e, hipMemcpyAsync(out_host, e->v.fourH, sizeof(int32_t) * e->v.K, hipMemcpyDeviceToHost, e->stream));
   HIPCHK(e, hipStreamSynchronize(e->stream));
-  for (int k = 0; k < e->v.K; ++k)
+  for (int k = 0; k < e->v.K; ++k) {
     if (e->meta[k].ktype == SV_RBF && e->have_spikes && e->v.rbf_series) out_host[k] = -2;
+    if (e->have_spikes && !e->cls_on) out_host[k] = -1;      // small problem: every latent pair by pair
+  }
   return SVGPFA_OK;
 }
 

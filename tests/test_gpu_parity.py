@@ -286,6 +286,29 @@ def test_class_path_against_pair_path(case, monkeypatch):
         assert rel_err(b.cpu().numpy(), a.cpu().numpy()) < 1e-9
 
 
+def test_small_problems_take_the_pair_pass(monkeypatch, golden_dir):
+    """Default policy (no SVGPFA_SERIES_MIN_PAIRS): below 1e7 (spike, inducing point) pairs the spike pass is the single
+    pair-by-pair launch -- the class path's extra launches cost more than they save there (cfg2 is launch-bound) -- and
+    series_harmonics() says so.  Same reference outputs as test_cfg2_golden."""
+    monkeypatch.delenv("SVGPFA_SERIES_MIN_PAIRS", raising=False)
+    ref = np.load(golden_dir + "/cfg2.npz")
+    prob = synthetic.make_config("cfg2")
+    eng, P = _engine(prob)
+    assert eng.series_harmonics() == [-1] * prob["K"]
+    out = _eval(eng, P, 15)
+    assert _close(out["elbo"], float(ref["ref_elbo"]), TOL_S)
+    assert rel_err(out["g_C"], ref["g_C"]) < TOL_A
+    for k in range(prob["K"]):
+        assert rel_err(out["g_Z"][k], ref[f"g_Z_{k}"]) < TOL_A
+        assert rel_err(out["g_theta"][k], ref[f"g_theta_{k}"]) < TOL_A
+    eng.close()
+    monkeypatch.setenv("SVGPFA_SERIES_MIN_PAIRS", "0")
+    eng, P = _engine(prob)
+    assert eng.series_harmonics() == [-2] * prob["K"]
+    out2 = _eval(eng, P, 15)
+    assert abs(out2["elbo"] - out["elbo"]) <= 1e-11 * abs(out["elbo"])
+
+
 def test_spike_sum_reuse_token():
     """Value-only evaluations (E-step closure) reuse the spike sums P0 while the caller's token says C is unchanged
     (include/svgpfa.h: svgpfa_set_embedding_token); results must equal the un-cached evaluation bit for bit, and a
