@@ -87,12 +87,14 @@ class Engine:
         if len(tensors) != self.K:
             raise ValueError("expected one tensor per latent")
         ptrs = tuple(t.data_ptr() for t in tensors)
-        # the cache key carries size, dtype and device beside the address: the caching allocator recycles addresses, and a
-        # tensor of another size or type at a recycled address must not ride on the previous tensor's validation
-        key = tuple((t.data_ptr(), t.numel(), t.dtype, t.device, t.is_contiguous()) for t in tensors)
+        # A hit needs the SAME tensor objects at the same addresses.  The cache keeps the validated tensors alive, so neither
+        # their addresses nor their ids can be recycled for a tensor of another size or type (the caching allocator does
+        # recycle addresses: an address-only key would let such a tensor ride on the previous one's validation).  Identity
+        # and address cost ~2 us per table; re-reading size / dtype / device of every tensor cost 5 (x 6 tables per call).
         if slot is not None:
             hit = self._tables.get(slot)
-            if hit is not None and hit[0] == key:
+            if hit is not None and hit[0] == ptrs and len(hit[2]) == len(tensors) and \
+                    all(a is b for a, b in zip(hit[2], tensors)):
                 return hit[1]
         for k, t in enumerate(tensors):
             self._dev(t)
@@ -100,7 +102,7 @@ class Engine:
                 raise ValueError(f"latent {k}: expected {sizes[k]} elements, got {t.numel()}")
         arr = (ctypes.c_void_p * self.K)(*ptrs)
         if slot is not None:
-            self._tables[slot] = (key, arr)
+            self._tables[slot] = (ptrs, arr, list(tensors))
         return arr
 
     def close(self):
@@ -168,12 +170,12 @@ class Engine:
         mt = self._table(mean, self._szM, "mean")
         ct = self._table(cholvec, self._szP, "chol")
         cd = (C.data_ptr(), d.data_ptr())
-        cdkey = (cd, C.numel(), d.numel(), C.dtype, d.dtype, C.device, d.device, C.is_contiguous(), d.is_contiguous())
-        if self._tables.get("Cd") != cdkey:
+        hit = self._tables.get("Cd")
+        if hit is None or hit[0] != cd or hit[1] is not C or hit[2] is not d:      # same objects at the same addresses
             self._dev(C), self._dev(d)
             if C.numel() != self.N * self.K or d.numel() != self.N:
                 raise ValueError("C must be N x K and d must have N entries")
-            self._tables["Cd"] = cdkey
+            self._tables["Cd"] = (cd, C, d)
         shared = out if out is not None else torch.empty(self.shared_len, dtype=torch.float64, device=self.device)
         g_mean, g_chol, g_Z = grads if grads is not None else self.alloc_grads(grad_mask)
         self._check(self.lib.svgpfa_elbo(self._h, mt, ct, cd[0], cd[1], int(grad_mask), _ptr(shared),

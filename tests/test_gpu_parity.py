@@ -619,3 +619,23 @@ def test_rbf_series_and_pairwise_paths(ls, M, trial_len, monkeypatch):
     for k in range(prob["K"]):
         assert rel_err(outs["1"]["g_Z"][k], outs["0"]["g_Z"][k]) < 1e-9
         assert rel_err(outs["1"]["g_theta"][k], outs["0"]["g_theta"][k]) < 1e-9
+
+
+def test_pointer_table_cache_survives_address_recycling():
+    """The engine caches the host arrays of device pointers it hands to the C ABI.  A hit needs the same tensor OBJECTS at the
+    same addresses (the cache keeps them alive): a new, smaller tensor that the caching allocator places at a freed
+    tensor's address is validated again and refused, instead of being read out of bounds."""
+    prob = synthetic.make_problem(R=3, N=5, K=2, M=[9, 10], kernels="mix", seed=1, n_quad=40, rate=8.0)
+    eng, P = _engine(prob)
+    mean = [m.clone() for m in P["mean"]]
+    eng.elbo(mean, P["cholVecs"], P["C"], P["d"], 0)
+    eng.sync()
+    ptr = mean[0].data_ptr()
+    shape = mean[0].shape
+    mean[0] = None
+    small = torch.zeros(shape[0] * shape[1] // 2, dtype=torch.float64, device=P["C"].device)   # may land on the freed block
+    recycled = small.data_ptr() == ptr
+    with pytest.raises(ValueError):
+        eng.elbo([small, mean[1]], P["cholVecs"], P["C"], P["d"], 0)
+    eng.sync()
+    print("address recycled:", recycled)
