@@ -98,6 +98,12 @@ struct SpikeClassTab {
   int slot_of[SV_MAX_K];                 // its index among the members
 };
 
+// svgpfa_build_kernels' inputs: the caller's Z / theta tensors, snapshotted into engine-owned HBM by k_build_reg
+struct SnapTable {
+  const double* Z[SV_MAX_K];
+  const double* theta[SV_MAX_K];
+};
+
 // Everything a kernel needs, passed by value (fits well inside the kernarg segment).
 struct EngineView {
   int R, N, K, Q, S;
@@ -278,9 +284,11 @@ __device__ inline int periodic_series(double beta, int M, double* tab, double* f
   for (int n = 0; n <= SV_FH + 1; ++n) {
     const double ive = f[n] * inv, ivep = f[n + 1] * inv, ivem = (n ? f[n - 1] : f[1]) * inv;
     const double cn = (n ? 2.0 : 1.0) * ive;
-    tab[n] = cn;
-    tab[(SV_FH + 2) + n] = -0.5 * (n ? 2.0 : 1.0) * (0.5 * (ivem + ivep) - ive);   // g_n = -1/2 dc_n / dbeta
-    tab[2 * (SV_FH + 2) + n] = n * cn / beta;
+    if (tab) {                                   // (nullptr: the caller wants H only -- class blocks of k_build_reg)
+      tab[n] = cn;
+      tab[(SV_FH + 2) + n] = -0.5 * (n ? 2.0 : 1.0) * (0.5 * (ivem + ivep) - ive);   // g_n = -1/2 dc_n / dbeta
+      tab[2 * (SV_FH + 2) + n] = n * cn / beta;
+    }
     if (n * cn >= 1e-18 || n == 0) H = n;
   }
   if (H > SV_FH) return -1;

@@ -11,6 +11,7 @@
 //   dELBO/dKzz  = Linv^T At Linv,  At = -(gt ut^T + ut gt^T)/2 + ut ut^T/2 + Gt + (Vt Vt^T - I)/2 - C - C^T,  C = Vt Vt^T Gt
 #pragma once
 #include "engine_common.h"
+#include "spike_cls_common.h"
 
 // ------------------------------------------------------------------------------ k_build_reg
 // Register-resident build for M <= MP (MP = 16 or 32): 64 / MP (trial, latent) items per wavefront.
@@ -23,19 +24,23 @@
 // KernelsMatricesStore getters read them).
 // snap != 0: Z / theta come from the caller's tensors (st) and are snapshotted into engine-owned HBM on the way
 // (reference semantics: later evaluations keep using the matrices of the last buildKernelsMatrices() call).
-struct SnapTable {
-  const double* Z[SV_MAX_K];
-  const double* theta[SV_MAX_K];
-};
+// dynamic LDS of k_build_reg<MP> (bytes); cls: with the class riders, whose series workspace has one row per latent
+__host__ __device__ constexpr size_t sv_build_lds(int MP, int K, bool cls) {
+  const size_t lt = (size_t)64 * MP, rider = cls ? (sizeof(SpikeClassScratch) + 7) / 8 + (size_t)K * (SV_FH + 3) : 0;
+  return 8 * (lt > rider ? lt : rider);
+}
 
 template <int MP>
-__global__ __launch_bounds__(64) void k_build_reg(EngineView ev, int write_aux, int snap, SnapTable st) {
+__global__ __launch_bounds__(64) void k_build_reg(EngineView ev, int write_aux, int snap, SnapTable st, int cls) {
   constexpr int IPW = 64 / MP;
-  __shared__ double Lt[IPW][MP][MP];       // Lt[item][q][i] = L[i][q]  (column-major: conflict-free writes)
+  // Lt[item][q][i] = L[i][q]  (column-major: conflict-free writes); the rider blocks in front use the same bytes
+  extern __shared__ double smraw[];        // max(IPW MP MP, class rider: sv_build_lds) doubles
+  double (*Lt)[MP][MP] = reinterpret_cast<double (*)[MP][MP]>(smraw);
   const int lane = threadIdx.x, sub = lane / MP, i = lane % MP, lbase = lane - i;
   const int rp = (ev.R + IPW - 1) / IPW;
-  const int nx = snap ? ev.K : 0;
-  if ((int)blockIdx.x < nx) {
+  const int nser = snap ? ev.K : 0, ncb = (snap && cls) ? ev.R : 0;
+  const int nx = nser + ncb;
+  if ((int)blockIdx.x < nser) {
     // K extra blocks in front of the item blocks (snap launches only): the cosine series of latent k's periodic kernel
     // for the spike pass (engine_common.h periodic_series) -- a serial recurrence on one lane that runs beside the item
     // blocks instead of lengthening one of them
@@ -44,9 +49,22 @@ __global__ __launch_bounds__(64) void k_build_reg(EngineView ev, int write_aux, 
       const LatentMeta ms = ev.meta[ks];
       const KPar ps = make_kpar(ms, st.theta[ks]);
       ev.fourH[ks] = (ms.ktype == SV_PERIODIC && ev.per_series)
-                         ? periodic_series(0.5 * ps.h, ms.M, ev.four + (size_t)ks * SV_FROWS * (SV_FH + 2), &Lt[0][0][0])
+                         ? periodic_series(0.5 * ps.h, ms.M, ev.four + (size_t)ks * SV_FROWS * (SV_FH + 2), smraw)
                          : -1;
     }
+    return;
+  }
+  if ((int)blockIdx.x < nx) {
+    // R more (cls launches): the spike pass's class table and trial r's entries of it (spike_cls_common.h), from the
+    // caller's Z / theta -- the table depends on nothing this launch computes, and riding here saves the class path a
+    // launch, an event and a cross-stream wait per kernel build
+    SpikeClassScratch& cs = *reinterpret_cast<SpikeClassScratch*>(smraw);
+    double* fws = smraw + (sizeof(SpikeClassScratch) + 7) / 8;
+    const int rc = blockIdx.x - nser;
+    spike_class_table(ev, cs, &st, fws);
+    lds_wave_fence();
+    if (rc == 0) spike_class_store(ev, cs);
+    spike_class_trial(ev, cs, &st, rc);
     return;
   }
   const int bid = blockIdx.x - nx;

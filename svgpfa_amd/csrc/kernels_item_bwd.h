@@ -18,8 +18,12 @@
 #include "kernels_mfma.h"
 #include "kernels_spike_cls.h"
 
+#ifndef SV_BWD_CLK
+#define SV_BWD_CLK 0    // diagnosis builds only: 1 = one thread of one block prints cycle stamps of the phases (device printf)
+#endif
+#define SV_CK(i) do { if (SV_BWD_CLK) ck[i] = clock64(); } while (0)
 #ifndef SV_BWD_STOP
-#define SV_BWD_STOP 0   // diagnosis builds only (tests/tools/phase_times.sh): 1 stop after phase 1, 2 after the spike gather, 3 before phase 3, 6 / 7 / 8 inside phase 2
+#define SV_BWD_STOP 0   // diagnosis builds only (tests/tools/phase_times.sh): 1 stop after phase 1, 2 after the spike gather, 3 before phase 3, 6 / 7 / 8 inside phase 2, 9 / 10 inside phase 1
 #endif
 #define SV_MASK_STATS 16u   // internal mask bit: svgpfa_latent_stats_backward (adjoints at quadrature nodes AND spikes given)
 #define SV_FIN_OUT 8   // outputs per reduction group of phase 3 (8 consecutive doubles = one 64-B segment per trial)
@@ -395,6 +399,8 @@ __device__ __forceinline__ void item_bwd_body(const EngineView& ev, const int r,
   const long long vbase = m.offM + (long long)r * M;
   const bool want_lat = (mask & (1u | 4u | 8u)) != 0;
   const bool want_zt = (mask & (4u | 8u)) != 0;
+  long long ck[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  SV_CK(0);
 
   if (want_lat) {
     load_factors<NT>(ev, m, r, Li, Vl, ul, zl, true);
@@ -407,7 +413,10 @@ __device__ __forceinline__ void item_bwd_body(const EngineView& ev, const int r,
   // staging of the factors: between the phases, where the values are used, its memory latency was exposed (12 us of the
   // kernel at the north-star size).  (Round 2 kept it between the phases above M = 32 after an intermediate version
   // returned wrong sums there: a compiler defect)
+  SV_CK(1);
   gather_item_inputs<MP>(ev, m, pt, r, k, mask, want_zt, p, gs, p1l, cvd, gt, tpl, S);
+  SV_CK(2);
+  if (SV_BWD_STOP == 9) return;      // after the staging of the factors and the gather
 
   if (want_lat) {
     // ================================================================= phase 1: quadrature adjoints
@@ -444,6 +453,8 @@ __device__ __forceinline__ void item_bwd_body(const EngineView& ev, const int r,
         for (int q = 0; q < 4; ++q) Dl[(16 * a + 4 * q + lg) * LD + 16 * c + li] = Dp[a][q];
     }
     __syncthreads();
+    SV_CK(3);
+    if (SV_BWD_STOP == 10) return;   // after the D panels
     d4 gu[NT], dz[NT], GW[NTRI];
 #pragma unroll
     for (int a = 0; a < NT; ++a) {
@@ -488,6 +499,7 @@ __device__ __forceinline__ void item_bwd_body(const EngineView& ev, const int r,
         gm_n = (nn < Qs) ? gmq[nn] : 0.0;
         gv_n = (nn < Qs) ? gvq[nn] : 0.0;
       }
+      if (tile == wave) SV_CK(4);
       double stq = 0.0, ctq = 0.0;
       if (KT == SV_PERIODIC) sv_sincos_quarter(tq * p.q4, stq, ctq);
       int jo = lg;
@@ -506,8 +518,10 @@ __device__ __forceinline__ void item_bwd_body(const EngineView& ev, const int r,
             X0[a][q] = p.s2 * sv_exp2_neg(fma(cs, p.h2, -p.h2));
           }
         }
+      if (tile == wave) SV_CK(5);
       d4 Kw[NT];
       tri_chain<NT, 0>(Kw, Li, LD, X0, li, lg);
+      if (tile == wave) SV_CK(6);
 #pragma unroll
       for (int a = 0; a < NT; ++a)
 #pragma unroll
@@ -550,6 +564,7 @@ __device__ __forceinline__ void item_bwd_body(const EngineView& ev, const int r,
             }
           }
       }
+      if (tile == wave) SV_CK(7);
       // Gt += Kw^T diag(gvar) Kw : contraction over the time index -> transpose through LDS
 #pragma unroll
       for (int a = 0; a < NT; ++a)
@@ -574,8 +589,10 @@ __device__ __forceinline__ void item_bwd_body(const EngineView& ev, const int r,
           }
       }
       lds_wave_fence();
+      if (tile == wave) SV_CK(8);
     }
     }   // node segments
+    SV_CK(9);
 
     // ---- reductions: over the 16 time lanes, then over the wavefronts (fixed order)
 #pragma unroll
@@ -649,6 +666,7 @@ __device__ __forceinline__ void item_bwd_body(const EngineView& ev, const int r,
     if (FULL && !DSEP) stage_matrix<NT>(Vl, ev.Vt + base, M, tid, NTHB);
   }
 
+  SV_CK(10);
   if (SV_BWD_STOP == 1) return;
   // =================================================================== phase 2: per-item backward
   // ---- spike part of the ELL of this item: sum_j a_j gs_j
@@ -853,6 +871,14 @@ __device__ __forceinline__ void item_bwd_body(const EngineView& ev, const int r,
     }
     ev.gthitem[item * 2 + 0] = t0 * p.c0 + thq[0] + p.c0 * tpl[0];
     ev.gthitem[item * 2 + 1] = t1 * p.c1 + thq[1] + p.c1 * tpl[1];
+  }
+  if (SV_BWD_CLK) {
+    SV_CK(11);
+    if (blockIdx.x == 101 && tid == 0) {
+      printf("CLK kt %d:", KT);
+      for (int i = 1; i < 12; ++i) printf(" %lld", ck[i] - ck[0]);
+      printf("\n");
+    }
   }
 }
 

@@ -13,6 +13,7 @@
 // (A-fragment reads are then bank-conflict free: lane -> (l & 15) * LD + (l >> 4)).
 #pragma once
 #include "engine_common.h"
+#include "spike_cls_common.h"
 
 typedef double d4 __attribute__((ext_vector_type(4)));
 
@@ -207,8 +208,10 @@ __global__ __launch_bounds__(256) void k_times_fwd_mfma(EngineView ev, const dou
 // NT wavefronts per item: wave c produces the 16-column panel c of Vt; wave 0 also carries the vector m as an
 // extra panel (column 0) so that ut and a come out of the same tri_chain.  Linv and L_S are staged in LDS with
 // coalesced loads by the whole block.
+// want_w: wave 0 also projects a on the item's cosine series (spike_pre_item: the class path's W, needed when dC is
+// wanted) -- it has a at hand, and the class path is spared a launch behind a cross-stream wait.
 template <int NT>
-__global__ __launch_bounds__(64 * NT) void k_prep_mfma(EngineView ev, LatentPtrTable ptab) {
+__global__ __launch_bounds__(64 * NT) void k_prep_mfma(EngineView ev, LatentPtrTable ptab, int want_w) {
   extern __shared__ double sm[];
   constexpr int MP = 16 * NT, LD = MP + 2, NTH = 64 * NT;
   const int item = blockIdx.x, tid = threadIdx.x, lane = tid & 63, c = tid >> 6, li = lane & 15, lg = lane >> 4;
@@ -219,6 +222,7 @@ __global__ __launch_bounds__(64 * NT) void k_prep_mfma(EngineView ev, LatentPtrT
   double* Li = sm;               // MP*LD
   double* Ls = Li + MP * LD;     // MP*LD
   double* red = Ls + MP * LD;    // NT
+  double* wsc = red + NT;        // 64 + SV_PRE_LDS (want_w)
   const long long base = m.offMM + (long long)r * M * M;
   const long long vbase = m.offM + (long long)r * M;
   const double* cv = pt.cholvec + (long long)r * m.P;
@@ -277,6 +281,7 @@ __global__ __launch_bounds__(64 * NT) void k_prep_mfma(EngineView ev, LatentPtrT
           ev.ut[vbase + i] = U[a][q];
           ev.a[vbase + i] = A[a][q];
           part = fma(U[a][q], U[a][q], part);
+          if (want_w) wsc[i] = A[a][q];
         }
       }
     if (lane < M) part += -2.0 * log(Li[lane * LD + lane]) - 2.0 * log(fabs(Ls[lane * LD + lane]));
@@ -290,6 +295,7 @@ __global__ __launch_bounds__(64 * NT) void k_prep_mfma(EngineView ev, LatentPtrT
     for (int w = 0; w < NT; ++w) tot += red[w];     // fixed panel order
     ev.klpart[item] = 0.5 * (tot - (double)M);
   }
+  if (want_w && c == 0) spike_pre_item(ev, item, r, k, m, (lane < M) ? wsc[lane] : 0.0, wsc + 64);
 }
 
 // ------------------------------------------------------------------------- k_quad_ell_mfma

@@ -32,245 +32,32 @@
 #pragma once
 #include "engine_common.h"
 #include "kernels_mfma.h"
+#include "spike_cls_common.h"
 
 // ------------------------------------------------------------------------------------------------ k_spike_classes
-// grid = ceil(R / 4) blocks of 256 threads: every block rebuilds the (tiny) class table in LDS, one wavefront per trial
-// then fills the per-trial entries.  Runs behind k_build_reg (needs its Z / theta snapshot and the periodic series tables).
+// The class table and the per-trial entries for the engine's kernel SNAPSHOT, when the spikes arrived after the kernel
+// build (else the class blocks of k_build_reg made them): grid = ceil(R / 4) blocks of 256 threads, every block rebuilds
+// the (tiny) table in LDS, one wavefront per trial then fills the per-trial entries.
 __global__ __launch_bounds__(256) void k_spike_classes(EngineView ev) {
-  __shared__ SpikeClassTab tab;
-  __shared__ double par[SV_MAX_K];     // per latent: RBF h = 1 / (2 l^2); periodic 4 / period
-  __shared__ int Mk[SV_MAX_K];
-  __shared__ long long offMk[SV_MAX_K];
-  __shared__ double lead[SV_MAX_K];    // per class: RBF h of the leader (its longest lengthscale); periodic 4 / period
-  __shared__ int clsH[SV_MAX_K], clsM[SV_MAX_K];   // per class: periodic harmonics; sum of the members' M
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, K = ev.K, R = ev.R;
-  // this wave's trial: its loads are requested first, they do not depend on the table
+  __shared__ SpikeClassScratch cs;
+  const int wave = threadIdx.x >> 6, R = ev.R;
   const int r = blockIdx.x * 4 + wave;
-  const int rr = r < R ? r : R - 1;
-  const double slo = ev.spk_lo[rr], shi = ev.spk_hi[rr];
-  const bool has_spikes = ev.spk_off[rr + 1] > ev.spk_off[rr];
-  if (wave == 0) {
-    // ---- the class table, one lane per latent (K <= 32), by wave votes: no serial walk through LDS
-    const bool in = lane < K;
-    LatentMeta m = ev.meta[in ? lane : 0];
-    const KPar p = make_kpar(m, ev.theta + 2 * (in ? lane : 0));
-    const double pk = (m.ktype == SV_RBF) ? p.h : 4.0 * p.ip;
-    const int Hl = (in && m.ktype == SV_PERIODIC) ? ev.fourH[lane] : -1;
-    int cls = -1, slot = 0, ncls = 0;
-    // periodic: one class per distinct period (the lowest latent with that period leads it; at most SV_CLS_MAXMEM members,
-    // further ones stay with the pair loop)
-    {
-      const bool el = in && m.ktype == SV_PERIODIC && Hl >= 0;
-      int ld = -1;
-      for (int j = 0; j < K; ++j) {
-        const double pj = __shfl(pk, j, 64);
-        const int ej = __shfl((int)el, j, 64);
-        if (el && ej && pj == pk && ld < 0) ld = j;
-      }
-      const unsigned long long leaders = __ballot(el && ld == lane);
-      for (int j = 0; j < K; ++j) {                    // members of leader j, in latent order
-        const unsigned long long mem = __ballot(el && ld == j);
-        if ((leaders >> j) & 1ull) {
-          const int g = __popcll(leaders & ((1ull << j) - 1ull));
-          const int sl = __popcll(mem & ((1ull << lane) - 1ull));
-          if (el && ld == j && sl < SV_CLS_MAXMEM) {
-            cls = g;
-            slot = sl;
-          }
-        }
-      }
-      ncls = __popcll(leaders);
-      if (el && cls >= 0 && ld == lane) {
-        tab.type[cls] = SV_PERIODIC;
-        lead[cls] = pk;
-      }
-    }
-    // RBF: greedy classes from the longest lengthscale (smallest h) down, members within a factor 2 of the leader
-    if (ev.rbf_series) {
-      const bool el = in && m.ktype == SV_RBF && pk > 0.0 && pk < 1e300;
-      for (;;) {
-        const bool open = el && cls < 0;
-        double hmin = open ? pk : 1e308;
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) hmin = fmin(hmin, __shfl_xor(hmin, o, 64));
-        if (!(hmin < 1e308)) break;
-        const unsigned long long cand = __ballot(open && pk <= 4.0 * hmin);
-        const int sl = __popcll(cand & ((1ull << lane) - 1ull));
-        if (open && pk <= 4.0 * hmin && sl < SV_CLS_MAXMEM) {
-          cls = ncls;
-          slot = sl;
-        }
-        if (lane == 0) {
-          tab.type[ncls] = SV_RBF;
-          lead[ncls] = hmin;
-        }
-        ++ncls;
-      }
-    }
-    if (in) {
-      tab.cls_of[lane] = cls;
-      tab.slot_of[lane] = slot;
-      par[lane] = pk;
-      Mk[lane] = m.M;
-      offMk[lane] = m.offM;
-      if (cls >= 0) tab.mem[cls][slot] = lane;
-    }
-    for (int g = 0; g < ncls; ++g) {                    // per class: members, harmonics (periodic), sum of M
-      const bool mine = in && cls == g;
-      const int nm = __popcll(__ballot(mine));
-      int hh = mine ? Hl : 0, mm = mine ? m.M : 0;
-#pragma unroll
-      for (int o = 32; o > 0; o >>= 1) {
-        hh = max(hh, __shfl_xor(hh, o, 64));
-        mm += __shfl_xor(mm, o, 64);
-      }
-      if (lane == 0) {
-        tab.nmem[g] = nm;
-        clsH[g] = hh;
-        clsM[g] = mm;
-      }
-    }
-    if (lane == 0) tab.ncls = ncls;
-  }
+  if (wave == 0) spike_class_table(ev, cs, nullptr, nullptr);
   __syncthreads();
-  if (blockIdx.x == 0) {
-    int* dst = (int*)ev.cls;
-    const int* src = (const int*)&tab;
-    for (int i = tid; i < (int)(sizeof(SpikeClassTab) / sizeof(int)); i += 256) dst[i] = src[i];
-  }
-  if (r >= R) return;
-  bool pair = false;                                   // some item of this trial is left to the pair-by-pair pass
-  for (int k = lane; k < K; k += 64)
-    if (tab.cls_of[k] < 0) {
-      ev.ser[r * K + k] = 0;
-      ev.sitem[r * K + k] = SpikeItem{-1, -1, 0.0, 0.0};
-      pair = true;
-    }
-  const double PI = 3.14159265358979323846;
-  for (int g = 0; g < tab.ncls; ++g) {
-    double t0 = 0.0, sc = lead[g];
-    int H = clsH[g];
-    if (tab.type[g] == SV_RBF) {
-      // window of the (trial, class): all spike times of the trial and all inducing points of the members
-      double lo = slo, hi = shi;
-      for (int s = 0; s < tab.nmem[g]; ++s) {
-        const int k = tab.mem[g][s];
-        if (lane < Mk[k]) {
-          const double zj = ev.Zs[offMk[k] + (long long)r * Mk[k] + lane];
-          lo = fmin(lo, zj);
-          hi = fmax(hi, zj);
-        }
-      }
-#pragma unroll
-      for (int o = 32; o > 0; o >>= 1) {
-        lo = fmin(lo, __shfl_xor(lo, o, 64));
-        hi = fmax(hi, __shfl_xor(hi, o, 64));
-      }
-      const double L = (hi - lo) + sqrt(41.5 / lead[g]);     // wrapped copies below e^-41.5 = 1e-18 for every member
-      H = 0;
-      for (int s = 0; s < tab.nmem[g]; ++s) {
-        const double q = PI * PI / (par[tab.mem[g][s]] * L * L);   // c_n ~ exp(-q n^2)
-        const double nmax = sqrt(46.0 / q);                        // n c_n / c_0 < 64 e^-46 = 7e-19 beyond
-        if (!(nmax < (double)SV_FH)) H = SV_FH + 1;
-        else H = ((int)nmax + 1 > H) ? (int)nmax + 1 : H;
-      }
-      // per-spike cost of the series (6 instructions per harmonic, rows ~60 % full) against the members' pair loops
-      if (H > SV_FH || 10 * (H + 2) > 21 * clsM[g]) H = -1;
-      t0 = lo;
-      sc = 4.0 / L;
-    }
-    if (lane == 0) {
-      ev.cls_t0[(long long)g * R + r] = t0;
-      ev.cls_sc[(long long)g * R + r] = sc;
-      ev.cls_H[(long long)g * R + r] = H;
-    }
-    if (lane < tab.nmem[g]) {
-      const int k = tab.mem[g][lane];
-      ev.ser[r * K + k] = H >= 0 ? 1 : 0;
-      ev.sitem[r * K + k] = SpikeItem{H, g, t0, sc};
-      if (H < 0) pair = true;
-    }
-  }
-  // one flag per trial, no reset and no atomics: the pair pass ORs them (k_spike)
-  const bool anyp = __any(pair);
-  if (lane == 0) ev.pair_any[r] = (has_spikes && anyp) ? 1 : 0;
-}
-
-// Series coefficients of latent k on the (trial, class) period: rows c_n | g_n | e_n for n = 0 .. H into cf (LDS,
-// 3 x (SV_FH + 1)); periodic latents copy their table (k_build_reg / periodic_series), RBF latents evaluate
-//   c_n = (2) sqrt(pi / h) / L exp(-pi^2 n^2 / (h L^2)),  g_n = -dc_n/dh = c_n (1/(2h) - pi^2 n^2 / (h^2 L^2)),
-//   e_n = n w c_n / (2 h),  w = 2 pi / L,  L = 4 / sc.     All 64 lanes call it; the caller synchronises.
-__device__ __forceinline__ void cls_coefficients(const EngineView& ev, int k, int ktype, double h, double sc, int H,
-                                                 double* cf) {
-  const int lane = threadIdx.x & 63;
-  constexpr int NF = SV_FH + 2;
-  if (ktype == SV_PERIODIC) {
-    const double* tab = ev.four + (size_t)k * SV_FROWS * NF;
-    for (int n = lane; n <= H; n += 64) {
-      cf[n] = tab[n];
-      cf[(SV_FH + 1) + n] = tab[NF + n];
-      cf[2 * (SV_FH + 1) + n] = tab[2 * NF + n];
-    }
-  } else {
-    const double PI = 3.14159265358979323846;
-    const double L = 4.0 / sc, q = PI * PI / (h * L * L), w = 2.0 * PI / L, c0 = sqrt(PI / h) / L;
-    for (int n = lane; n <= H; n += 64) {
-      const double cn = (n ? 2.0 : 1.0) * c0 * exp(-q * (double)n * (double)n);
-      cf[n] = cn;
-      cf[(SV_FH + 1) + n] = cn * (0.5 / h - q * (double)n * (double)n / h);
-      cf[2 * (SV_FH + 1) + n] = (double)n * w * cn * (0.5 / h);
-    }
-  }
+  if (blockIdx.x == 0 && wave == 1) spike_class_store(ev, cs);
+  if (r < R) spike_class_trial(ev, cs, nullptr, r);
 }
 
 // ------------------------------------------------------------------------------------------------ k_spike_pre
-// W[r][k][2 n + {0, 1}] = s2 c_n (Abar_n, Bbar_n),  Abar_n = sum_j a_j cos(n phi_j),  Bbar_n = sum_j a_j sin(n phi_j),
-// phi_j = w (z_j - t0): the posterior mean at a spike is mu_s = sum_n [cos(n theta_s) W_2n + sin(n theta_s) W_2n+1].
-// Entries beyond H are written as zeros (k_spike_cls works in whole register passes).  grid = R K blocks of 64 threads.
+// W of every (trial, latent) item (spike_pre_item) when k_prep_mfma did not make it (statistics calls).  grid = R K blocks
+// of 64 threads.
 __global__ __launch_bounds__(64) void k_spike_pre(EngineView ev) {
-  __shared__ double red[8 * 65];          // 4 harmonics x (cos, sin) per round: small enough for 5 000 blocks to be resident at once
-  __shared__ double cf[3 * (SV_FH + 1)];
+  __shared__ double scratch[SV_PRE_LDS];
   const int item = blockIdx.x, lane = threadIdx.x, K = ev.K;
-  const SpikeItem it = ev.sitem[item];
-  if (it.H < 0) return;
   const int r = item / K, k = item % K;
   const LatentMeta m = ev.meta[k];
-  const int H = it.H;
-  const double sc = it.sc, t0 = it.t0;
-  const KPar p = make_kpar(m, ev.theta + 2 * k);
-  double aj = 0.0, zj = t0;
-  if (lane < m.M) {                        // requested before the coefficients are computed
-    aj = ev.a[m.offM + (long long)r * m.M + lane];
-    zj = ev.Zs[m.offM + (long long)r * m.M + lane];
-  }
-  cls_coefficients(ev, k, m.ktype, p.h, sc, H, cf);
-  double sphi = 0.0, cphi = 1.0;
-  if (lane < m.M) sv_sincos_quarter((zj - t0) * sc, sphi, cphi);
-  double* W = ev.Wb + (long long)item * SV_WCOLS;
-  for (int c = 2 * (H + 1) + lane; c < SV_WCOLS; c += 64) W[c] = 0.0;
-  double cj = 1.0, sj = 0.0;
-  for (int nb = 0; nb <= H; nb += 4) {
-    __syncthreads();                       // cf ready (first round); the previous round's rows are consumed
-#pragma unroll
-    for (int jj = 0; jj < 4; ++jj) {
-      red[(2 * jj + 0) * 65 + lane] = aj * cj;
-      red[(2 * jj + 1) * 65 + lane] = aj * sj;
-      const double tq = cj * cphi - sj * sphi;
-      sj = fma(sj, cphi, cj * sphi);
-      cj = tq;
-    }
-    __syncthreads();
-    // transposed reduction: lane (v, eighth) sums 8 of the 64 lane-partials of row v, the eighths are added by shuffles
-    const int v = lane & 7, qd = lane >> 3;
-    double sum = 0.0;
-#pragma unroll
-    for (int e = 0; e < 8; ++e) sum += red[v * 65 + qd * 8 + e];
-    sum += __shfl_xor(sum, 8, 64);
-    sum += __shfl_xor(sum, 16, 64);
-    sum += __shfl_xor(sum, 32, 64);
-    const int n = nb + (lane >> 1);
-    if (lane < 8 && n <= H) W[2 * n + (lane & 1)] = p.s2 * cf[n] * sum;
-  }
+  const double aj = (lane < m.M) ? ev.a[m.offM + (long long)r * m.M + lane] : 0.0;
+  spike_pre_item(ev, item, r, k, m, aj, scratch);
 }
 
 // ------------------------------------------------------------------------------------------------ k_spike_cls

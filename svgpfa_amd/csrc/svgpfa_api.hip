@@ -53,21 +53,46 @@ struct svgpfa_engine {
   // (wave-uniform branch): measured faster than one launch per type for the per-item kernels (+3 % on cfg3: fewer
   // launches, shorter grid tails) and, since both types of the spike pass fit 3 waves / SIMD, for the spike pass too
   // (+1.5 %; its grid lists the longer periodic work items first).
-  // Spike pass on a side stream beside the quadrature chain (two cross-stream edges: prep -> spike, spike -> bwd).
-  // Measured with the current kernels (cfg3, ms per evaluation, one stream -> side stream): 1-way 1.219 -> 1.183,
-  // 2-way 0.664 -> 0.648, 4-way 0.384 -> 0.355, 8-way 0.236 -> 0.230.  Default (-1): on for small shards
-  // (R K <= 2048), where every launch under-fills the chip; at full size one stream is kept so that the spike pass
-  // runs alone and its hipEvent duration is comparable with the roofline.  SVGPFA_OVERLAP=0 / 1 forces it off / on.
+  // Two chains between k_prep and k_item_bwd: the spike pass and the quadrature chain (k_times_fwd -> k_quad_ell).  On small
+  // shards (default -1: R K <= 2048), where every launch under-fills the chip, the quadrature chain runs on a side stream
+  // (two cross-stream edges: prep -> times, quad_ell -> bwd) and the second class kernel of the spike pass on another; at
+  // full size one stream is kept, so that the spike pass runs alone and its hipEvent duration is comparable with the
+  // roofline.  SVGPFA_OVERLAP=0 / 1 forces it off / on.  (Round 2 measured, ms per evaluation of cfg3, one stream -> two:
+  // 1-way 1.219 -> 1.183, 2-way 0.664 -> 0.648, 4-way 0.384 -> 0.355, 8-way 0.236 -> 0.230.)
   int side_stream = -1;
-  hipStream_t s_side = nullptr, s_side2 = nullptr;   // s_side2: the second class kernel beside the first on small shards
-  hipEvent_t ev_prep = nullptr, ev_spk = nullptr, ev_build = nullptr, ev_cls = nullptr, ev_fork = nullptr, ev_join = nullptr;
+  hipStream_t s_side = nullptr, s_side2 = nullptr;   // quadrature chain / second class kernel on small shards
+  hipEvent_t ev_prep = nullptr, ev_quad = nullptr, ev_fork = nullptr, ev_join = nullptr;
   bool fork_always = false;                     // SVGPFA_FORK=1: the two class kernels on two streams at every size (experiment)
-  bool cls_pending = false;                     // k_spike_classes is in flight on the side stream: its users wait for ev_cls
   bool cls_on = true;                           // false: problem too small for the class path's extra launches (set_spikes)
   double series_min_pairs = 1e7;                // SVGPFA_SERIES_MIN_PAIRS: fewest (spike, inducing point) pairs for the class path
   bool cls_valid = false;                       // the class table of the spike pass belongs to the current kernel build
   int grid_cls = 2048, grid_pair = 2048;        // blocks of the two persistent-style spike kernels (resident waves of the chip)
+  // Graph launch of one ELBO evaluation (small shards: the evaluation's ten-odd launches, three streams and six events cost the
+  // host ~0.1 ms, more than the kernels take).  The launch sequence is captured once per (gradient mask, pointer set,
+  // with / without the class table's kernel, with / without the spike pass) on a private stream and replayed with one
+  // hipGraphLaunch into the caller's stream.  SVGPFA_GRAPH=1 turns it on; off by default: on this runtime a replay's
+  // dependency edges cost what the events of the plain launches cost (8-way shard of cfg3 0.186 plain / 0.190 replayed,
+  // 4-way 0.264 / 0.247, cfg2 0.080 / 0.075 ms per evaluation), it only halves the host's time per evaluation.
+  int graph_mode = -1;
+  hipStream_t s_cap = nullptr;
+  struct GraphSlot {
+    std::vector<uint64_t> key;
+    hipGraphExec_t exec = nullptr;
+    uint64_t used = 0;
+  };
+  std::vector<GraphSlot> graphs;
+  std::vector<std::vector<uint64_t>> graph_seen;   // keys evaluated once with plain launches: a graph is recorded at a key's second sight
+  uint64_t graph_clock = 0;
+  int64_t graph_replays = 0;
 };
+#define SV_GRAPH_SLOTS 8
+
+static void drop_graphs(svgpfa_engine* e) {
+  for (auto& g : e->graphs)
+    if (g.exec) (void)hipGraphExecDestroy(g.exec);
+  e->graphs.clear();
+  e->graph_seen.clear();
+}
 
 #define HIPCHK(e, call)                                                                  \
   do {                                                                                   \
@@ -142,7 +167,7 @@ static size_t lds_qell_mfma(const svgpfa_engine* e, int role) { return lds_qell_
   }
 static size_t lds_prep_mfma(int NT) {
   size_t MP = 16 * NT, LD = MP + 2;
-  return (2 * MP * LD + NT) * 8;
+  return (2 * MP * LD + NT + 64 + SV_PRE_LDS) * 8;
 }
 
 template <typename F>
@@ -225,7 +250,10 @@ int svgpfa_create(const svgpfa_dims* d, int device, svgpfa_engine** out) {
   e->ell_nw = 4;
   if (getenv("SVGPFA_ELL_NW")) e->ell_nw = std::min(8, std::max(1, atoi(getenv("SVGPFA_ELL_NW"))));
   e->tile_nw = ((long long)v.R * v.K >= 512 && e->NT <= 2) ? 2 : 4;
-  if (getenv("SVGPFA_TILE_NW")) e->tile_nw = atoi(getenv("SVGPFA_TILE_NW")) == 2 && e->NT <= 2 ? 2 : 4;
+  if (getenv("SVGPFA_TILE_NW")) {
+    const int nw = atoi(getenv("SVGPFA_TILE_NW"));
+    e->tile_nw = (nw >= 2 && nw <= 4 && nw >= e->NT) ? nw : 4;
+  }
   e->ell_lc[0] = qell_chunk(e, 0);
   e->ell_lc[1] = qell_chunk(e, 1);
   if (e->ell_lc[0] <= 0 || e->ell_lc[1] <= 0)
@@ -262,6 +290,8 @@ int svgpfa_create(const svgpfa_dims* d, int device, svgpfa_engine** out) {
   HIPCHK(e, hipHostMalloc((void**)&e->status_host, sizeof(int)));
   HIPCHK(e, hipStreamCreateWithFlags(&e->s_side, hipStreamNonBlocking));
   HIPCHK(e, hipStreamCreateWithFlags(&e->s_side2, hipStreamNonBlocking));
+  HIPCHK(e, hipStreamCreateWithFlags(&e->s_cap, hipStreamNonBlocking));
+  if (getenv("SVGPFA_GRAPH")) e->graph_mode = atoi(getenv("SVGPFA_GRAPH")) != 0 ? 1 : 0;
   {
     const char* ov = getenv("SVGPFA_OVERLAP");
     if (ov) e->side_stream = atoi(ov) != 0 ? 1 : 0;
@@ -285,7 +315,7 @@ int svgpfa_create(const svgpfa_dims* d, int device, svgpfa_engine** out) {
     e->grid_cls = std::max(8, prop.multiProcessorCount * std::max(1, bc));
     e->grid_pair = std::max(8, (prop.multiProcessorCount * std::max(1, bp)) & ~7);
   }
-  for (hipEvent_t* ev : {&e->ev_prep, &e->ev_spk, &e->ev_build, &e->ev_cls, &e->ev_fork, &e->ev_join})
+  for (hipEvent_t* ev : {&e->ev_prep, &e->ev_quad, &e->ev_fork, &e->ev_join})
     HIPCHK(e, hipEventCreateWithFlags(ev, hipEventDisableTiming));
 
   int rc = 0;
@@ -311,9 +341,10 @@ void svgpfa_destroy(svgpfa_engine* e) {
   (void)hipDeviceSynchronize();
   for (void* p : e->allocs) (void)hipFree(p);
   if (e->status_host) (void)hipHostFree(e->status_host);
-  for (hipStream_t st : {e->s_side, e->s_side2})
+  drop_graphs(e);
+  for (hipStream_t st : {e->s_side, e->s_side2, e->s_cap})
     if (st) (void)hipStreamDestroy(st);
-  for (hipEvent_t ev : {e->ev_prep, e->ev_spk, e->ev_build, e->ev_cls, e->ev_fork, e->ev_join})
+  for (hipEvent_t ev : {e->ev_prep, e->ev_quad, e->ev_fork, e->ev_join})
     if (ev) (void)hipEventDestroy(ev);
   for (auto& pr : e->ev_pool) {
     (void)hipEventDestroy(pr.first);
@@ -352,6 +383,7 @@ int svgpfa_sync(svgpfa_engine* e) {
 int svgpfa_set_reg(svgpfa_engine* e, double eps) {
   if (!e) return SVGPFA_ERR_INVALID;
   e->v.reg = eps;
+  drop_graphs(e);     // captured launches carry the view by value
   return SVGPFA_OK;
 }
 
@@ -583,34 +615,33 @@ int svgpfa_set_spikes(svgpfa_engine* e, const int64_t* off, const double* times,
 
 // write_aux: also store Kzz and L (getter path).  Register-resident kernel, 4 / 2 / 1 items per wave.
 // snap != nullptr: read Z / theta from the caller's tensors and snapshot them in the same launch.
-static void launch_build(svgpfa_engine* e, int write_aux, const SnapTable* snap) {
+static void launch_build(svgpfa_engine* e, int write_aux, const SnapTable* snap, bool cls = false) {
   EngineView& v = e->v;
   SnapTable none;
   memset(&none, 0, sizeof none);
-  const int extra = snap ? v.K : 0;     // K blocks in front of the item blocks compute the periodic kernels' cosine series
+  // in front of the item blocks: K blocks compute the periodic kernels' cosine series, R more (cls) the spike pass's class
+  // table and per-trial entries
+  const int extra = snap ? v.K + (cls ? v.R : 0) : 0;
+  const int c = (snap && cls) ? 1 : 0;
   if (e->Mmax <= 16) {
-    hipLaunchKernelGGL(k_build_reg<16>, dim3(v.K * ((v.R + 3) / 4) + extra), dim3(64), 0, e->stream, v, write_aux,
-                       snap ? 1 : 0, snap ? *snap : none);
+    hipLaunchKernelGGL(k_build_reg<16>, dim3(v.K * ((v.R + 3) / 4) + extra), dim3(64), sv_build_lds(16, v.K, c), e->stream, v,
+                       write_aux, snap ? 1 : 0, snap ? *snap : none, c);
   } else if (e->Mmax <= 32) {
-    hipLaunchKernelGGL(k_build_reg<32>, dim3(v.K * ((v.R + 1) / 2) + extra), dim3(64), 0, e->stream, v, write_aux,
-                       snap ? 1 : 0, snap ? *snap : none);
+    hipLaunchKernelGGL(k_build_reg<32>, dim3(v.K * ((v.R + 1) / 2) + extra), dim3(64), sv_build_lds(32, v.K, c), e->stream, v,
+                       write_aux, snap ? 1 : 0, snap ? *snap : none, c);
   } else {   // M <= 64 (checked at creation): one item per wave, 64 rows, 256 VGPRs of matrix data
-    hipLaunchKernelGGL(k_build_reg<64>, dim3(v.K * v.R + extra), dim3(64), 0, e->stream, v, write_aux, snap ? 1 : 0,
-                       snap ? *snap : none);
+    hipLaunchKernelGGL(k_build_reg<64>, dim3(v.K * v.R + extra), dim3(64), sv_build_lds(64, v.K, c), e->stream, v, write_aux,
+                       snap ? 1 : 0, snap ? *snap : none, c);
   }
 }
 
-// Classes of the spike pass's class path for the current kernel snapshot (needs the spikes' windows): with the kernel build,
-// or before the first spike pass when the spikes arrived after the build.
-// It runs on the side stream, beside whatever follows the kernel build on the main stream (k_prep at least): the spike pass
-// waits for its event.
+// Classes of the spike pass's class path for the current kernel snapshot (needs the spikes' windows): they ride in the
+// kernel build's launch (launch_build); this separate kernel serves a build that ran before the spikes were set.
+static bool graph_default(const svgpfa_engine* e) { return !e->timing && e->graph_mode == 1; }
+
 static void launch_classes(svgpfa_engine* e) {
-  (void)hipEventRecord(e->ev_build, e->stream);
-  (void)hipStreamWaitEvent(e->s_side, e->ev_build, 0);
-  hipLaunchKernelGGL(k_spike_classes, dim3((e->v.R + 3) / 4), dim3(256), 0, e->s_side, e->v);
-  (void)hipEventRecord(e->ev_cls, e->s_side);
+  hipLaunchKernelGGL(k_spike_classes, dim3((e->v.R + 3) / 4), dim3(256), 0, e->stream, e->v);
   e->cls_valid = true;
-  e->cls_pending = true;
 }
 
 int svgpfa_build_kernels(svgpfa_engine* e, const double* const* Z, const double* const* theta) {
@@ -624,11 +655,11 @@ int svgpfa_build_kernels(svgpfa_engine* e, const double* const* Z, const double*
     st.Z[k] = Z[k];
     st.theta[k] = theta[k];
   }
-  launch_build(e, 0, &st);
+  const bool cls = e->have_spikes && e->cls_on;
+  launch_build(e, 0, &st, cls);
   e->aux_valid = false;
   e->p0_token = 0;
-  e->cls_valid = !e->cls_on;
-  if (e->have_spikes && e->cls_on) launch_classes(e);
+  e->cls_valid = cls || !e->cls_on;
   HIPCHK(e, hipGetLastError());
   e->have_kernels = true;
   e->have_stats = false;
@@ -663,7 +694,7 @@ static int fill_ptrs(svgpfa_engine* e, PtrTable& pt, const double* const* mean, 
   return SVGPFA_OK;
 }
 
-static int launch_quad_ell(svgpfa_engine* e, const double* C, const double* d, int want_cd, int want_lat) {
+static int launch_quad_ell(svgpfa_engine* e, hipStream_t st, const double* C, const double* d, int want_cd, int want_lat) {
   EngineView& v = e->v;
   // role 0 (dC, dd and the ELL value) always runs: its column sums give sum E; role 1 (latent adjoints) rides in the
   // same launch when some latent-side gradient is wanted
@@ -672,18 +703,18 @@ static int launch_quad_ell(svgpfa_engine* e, const double* C, const double* d, i
   if (want_lat) {
     const size_t l2 = std::max(lds_qell_mfma(e, 0), lds_qell_mfma(e, 1));
     if (f32) {
-      DISPATCH_KS(e->KKT, hipLaunchKernelGGL((k_quad_ell_mfma<KS_, 2, float>), dim3(2 * gm.x), bm, l2, e->stream, v, C, d,
+      DISPATCH_KS(e->KKT, hipLaunchKernelGGL((k_quad_ell_mfma<KS_, 2, float>), dim3(2 * gm.x), bm, l2, st, v, C, d,
                                              want_cd, 1, e->ell_parts, e->ell_lc[0], e->ell_lc[1]));
     } else {
-      DISPATCH_KS(e->KKT, hipLaunchKernelGGL((k_quad_ell_mfma<KS_, 2, double>), dim3(2 * gm.x), bm, l2, e->stream, v, C, d,
+      DISPATCH_KS(e->KKT, hipLaunchKernelGGL((k_quad_ell_mfma<KS_, 2, double>), dim3(2 * gm.x), bm, l2, st, v, C, d,
                                              want_cd, 1, e->ell_parts, e->ell_lc[0], e->ell_lc[1]));
     }
   } else {
     if (f32) {
-      DISPATCH_KS(e->KKT, hipLaunchKernelGGL((k_quad_ell_mfma<KS_, 0, float>), gm, bm, lds_qell_mfma(e, 0), e->stream, v, C,
+      DISPATCH_KS(e->KKT, hipLaunchKernelGGL((k_quad_ell_mfma<KS_, 0, float>), gm, bm, lds_qell_mfma(e, 0), st, v, C,
                                              d, want_cd, 1, e->ell_parts, e->ell_lc[0], e->ell_lc[1]));
     } else {
-      DISPATCH_KS(e->KKT, hipLaunchKernelGGL((k_quad_ell_mfma<KS_, 0, double>), gm, bm, lds_qell_mfma(e, 0), e->stream, v, C,
+      DISPATCH_KS(e->KKT, hipLaunchKernelGGL((k_quad_ell_mfma<KS_, 0, double>), gm, bm, lds_qell_mfma(e, 0), st, v, C,
                                              d, want_cd, 1, e->ell_parts, e->ell_lc[0], e->ell_lc[1]));
     }
   }
@@ -691,25 +722,27 @@ static int launch_quad_ell(svgpfa_engine* e, const double* C, const double* d, i
   return SVGPFA_OK;
 }
 
-static int launch_times(svgpfa_engine* e, const double* times, const long long* toff, int nper, double* mu,
+static int launch_times(svgpfa_engine* e, hipStream_t st, const double* times, const long long* toff, int nper, double* mu,
                         double* var, long long os_r, long long os_t, long long os_k, int want_var) {
   EngineView& v = e->v;
   DISPATCH_NT(e->NT, hipLaunchKernelGGL((k_times_fwd_mfma<NT_>), dim3(v.R * v.K), dim3(256),
-                                        lds_times_mfma(NT_), e->stream, v, times, toff, nper, mu, var, os_r, os_t, os_k,
+                                        lds_times_mfma(NT_), st, v, times, toff, nper, mu, var, os_r, os_t, os_k,
                                         want_var));
   HIPCHK(e, hipGetLastError());
   return SVGPFA_OK;
 }
 
-static void launch_prep(svgpfa_engine* e, const PtrTable& pt) {   // one wavefront per 16-column panel
+// one wavefront per 16-column panel; want_w: the class path's W rides along (needs a valid class table)
+static void launch_prep(svgpfa_engine* e, const PtrTable& pt, bool want_w = false) {
   EngineView& v = e->v;
-  DISPATCH_NT(e->NT, hipLaunchKernelGGL(k_prep_mfma<NT_>, dim3(v.R * v.K), dim3(64 * NT_), lds_prep_mfma(NT_), e->stream, v, pt));
+  DISPATCH_NT(e->NT, hipLaunchKernelGGL(k_prep_mfma<NT_>, dim3(v.R * v.K), dim3(64 * NT_), lds_prep_mfma(NT_), e->stream, v, pt,
+                                        want_w ? 1 : 0));
 }
 
 // quadrature statistics into the engine's [r][k][q] buffers
-static int launch_times_quad(svgpfa_engine* e) {
+static int launch_times_quad(svgpfa_engine* e, hipStream_t st) {
   EngineView& v = e->v;
-  return launch_times(e, v.tq, nullptr, v.Q, v.muq, v.varq, (long long)v.K * v.Q, 1LL, (long long)v.Q, 1);
+  return launch_times(e, st, v.tq, nullptr, v.Q, v.muq, v.varq, (long long)v.K * v.Q, 1LL, (long long)v.Q, 1);
 }
 
 // svgpfa_enable_timing: bracket a kernel with a hipEvent pair on the stream it is launched on.  Pairs are reused: a query
@@ -749,32 +782,34 @@ static void timing_end(svgpfa_engine* e, int idx, hipStream_t st) {
   if (idx >= 0) (void)hipEventRecord(e->ev_pool[idx].second, st);
 }
 
-// Readers of the class table (ser / sitem / pair_any) on a stream other than the side stream wait for k_spike_classes once.
-static void wait_classes(svgpfa_engine* e, hipStream_t st) {
-  if (!e->cls_pending || st == e->s_side) return;
-  (void)hipStreamWaitEvent(st, e->ev_cls, 0);
-  if (st == e->stream) e->cls_pending = false;
-}
-
 // The spike-time pass on stream sk.  full: Z / theta gradient sums wanted too; want_c: the spike means' per-neuron sums (dC)
-// wanted (only with full).  Class path (cosine series, kernels_spike_cls.h) for the (trial, latent) items it serves, the
-// pair-by-pair pass (kernels_spike.h) for the rest; both stride fixed grids over work lists that live on the device.
-static void launch_spike_pass(svgpfa_engine* e, hipStream_t sk, bool full, bool want_c, const double* C) {
+// wanted (only with full); have_w: k_prep made the class path's W (else k_spike_pre does, here).  Class path (cosine
+// series, kernels_spike_cls.h) for the (trial, latent) items it serves, the pair-by-pair pass (kernels_spike.h) for the
+// rest; both stride fixed grids over work lists that live on the device.
+// fork: the class kernel of the time-weighted moments on s_side2, beside the other one (small shards); ev_w is an event on
+// the stream that made W and the class table's inputs (recorded by the caller behind k_prep when have_w).
+static void launch_spike_pass(svgpfa_engine* e, hipStream_t sk, bool full, bool want_c, const double* C, bool have_w,
+                              bool may_fork, hipEvent_t ev_w) {
   EngineView& v = e->v;
-  wait_classes(e, sk);
   const dim3 bs(64);
   const dim3 gi(v.R * v.K);
   const dim3 gc((unsigned)std::min<long long>((long long)v.ntiles * v.K, e->grid_cls));
+  bool joined = true;
   if (v.ntiles > 0 && e->cls_on) {
     // the classes with time-weighted moments (periodic, when Z / theta gradients are wanted) have a kernel of their own
     const bool tw = full && v.ntype[SV_PERIODIC] > 0;
-    // small shards (the pass is on the side stream because no kernel fills the chip): the two class kernels side by side
-    const bool fork = tw && (sk == e->s_side || e->fork_always);
+    const bool fork = tw && (may_fork || e->fork_always);
     hipStream_t s4 = fork ? e->s_side2 : sk;
-    if (full && want_c) hipLaunchKernelGGL(k_spike_pre, gi, bs, 0, sk, v);
+    if (full && want_c && !have_w) hipLaunchKernelGGL(k_spike_pre, gi, bs, 0, sk, v);
     if (fork) {
-      (void)hipEventRecord(e->ev_fork, sk);
-      (void)hipStreamWaitEvent(s4, e->ev_fork, 0);
+      // (both forks of a capture start at its origin stream and join it again: a stream forked from a forked stream and
+      // joined back to THAT sends hipStreamEndCapture of the HIP runtime bundled with PyTorch 2.10 (ROCm 7.0) into endless
+      // recursion -- tests/tools/hipgraph_probe, pattern D)
+      if (!(have_w && ev_w)) {
+        (void)hipEventRecord(e->ev_fork, sk);
+        ev_w = e->ev_fork;
+      }
+      (void)hipStreamWaitEvent(s4, ev_w, 0);
     }
     if (full && want_c) {
       if (tw) hipLaunchKernelGGL((k_spike_cls<4, true>), gc, bs, 0, s4, v, C, 1);
@@ -785,10 +820,12 @@ static void launch_spike_pass(svgpfa_engine* e, hipStream_t sk, bool full, bool 
     }
     if (fork) {
       (void)hipEventRecord(e->ev_join, s4);
-      (void)hipStreamWaitEvent(sk, e->ev_join, 0);
+      joined = false;
     }
   }
   if (!v.comb_fold && e->cls_on) {
+    if (!joined) (void)hipStreamWaitEvent(sk, e->ev_join, 0);
+    joined = true;
     if (full) hipLaunchKernelGGL(k_spike_comb<true>, gi, bs, 0, sk, v);
     else hipLaunchKernelGGL(k_spike_comb<false>, gi, bs, 0, sk, v);
   }
@@ -805,6 +842,8 @@ static void launch_spike_pass(svgpfa_engine* e, hipStream_t sk, bool full, bool 
       else hipLaunchKernelGGL((k_spike<false>), gp, bs, 0, sk, v, C);
     }
   }
+  // (combine folded into k_item_bwd's gather: the forked kernel is joined behind the pair kernel, which does not need it)
+  if (!joined) (void)hipStreamWaitEvent(sk, e->ev_join, 0);
 }
 
 static int check_ready(svgpfa_engine* e) {
@@ -814,54 +853,46 @@ static int check_ready(svgpfa_engine* e) {
   return SVGPFA_OK;
 }
 
-int svgpfa_elbo(svgpfa_engine* e, const double* const* mean, const double* const* cholvec, const double* C,
-                const double* d, unsigned mask, double* shared, double* const* g_mean,
-                double* const* g_cholvec, double* const* g_Z) {
-  if (!e || !C || !d || !shared) return SVGPFA_ERR_INVALID;
-  HIPCHK(e, hipSetDevice(e->device));
-  int rc;
-  if ((rc = check_ready(e))) return rc;
+// The launches of one ELBO evaluation, main chain on e->stream (the capture stream when a graph is being recorded).
+struct ElboPlan {
+  unsigned mask;
+  bool want_lat, full, side, run_spike;
+};
+static int enqueue_elbo(svgpfa_engine* e, const PtrTable& pt, const ElboPlan& pl, const double* C, const double* d,
+                        double* shared) {
   EngineView& v = e->v;
-  PtrTable pt;
-  if ((rc = fill_ptrs(e, pt, mean, cholvec, g_mean, g_cholvec, g_Z, mask))) return rc;
-  const bool want_lat = (mask & (1u | 4u | 8u)) != 0;
-  const bool full = (mask & (2u | 4u | 8u)) != 0;
-
+  const unsigned mask = pl.mask;
+  int rc;
   if (!e->cls_valid) launch_classes(e);   // spikes set after the last kernel build
-  launch_prep(e, pt);
+  // the class path's W rides in k_prep when this evaluation's spike pass wants dC
+  const bool have_w = pl.run_spike && pl.full && (mask & 2u) && e->cls_on && v.ntiles > 0;
+  launch_prep(e, pt, have_w);
   hipStream_t sm = e->stream;
-  const bool side = v.nchunks > 0 &&
-                    (e->side_stream == 1 || (e->side_stream < 0 && (long long)v.R * v.K <= 2048));
-  hipStream_t sk = side ? e->s_side : sm;
-  if (side) HIPCHK(e, hipEventRecord(e->ev_prep, sm));
-  // ---- quadrature chain (f64 MFMA): posterior stats -> ELL term.  With the spike pass on a side stream it is ENQUEUED
-  //      first: the host needs tens of microseconds for the side stream's launches and events, and on small shards the
-  //      main stream otherwise sits idle behind k_prep waiting for its next kernel (seen in the kernel trace of an
-  //      8-way shard: k_times_fwd started 60 us after k_prep had ended)
-  if (side) {
-    if ((rc = launch_times_quad(e))) return rc;
-    if ((rc = launch_quad_ell(e, C, d, (mask & 2u) ? 1 : 0, want_lat ? 1 : 0))) return rc;
-    HIPCHK(e, hipStreamWaitEvent(sk, e->ev_prep, 0));
+  // Small shards (pl.side): every kernel is one under-filled round, so the quadrature chain (f64 MFMA: posterior stats ->
+  // ELL term) runs on a side stream beside the spike pass.  The SPIKE pass stays on the main stream, in front of
+  // k_item_bwd: it is the longer chain on such shards, and a wait for an event that completed long ago costs a few
+  // microseconds where a wait at the end of the critical chain costs 15-20 (kernel trace of an 8-way shard of cfg3).
+  hipStream_t sq = pl.side ? e->s_side : sm;
+  if (pl.side) {
+    HIPCHK(e, hipEventRecord(e->ev_prep, sm));
+    HIPCHK(e, hipStreamWaitEvent(sq, e->ev_prep, 0));
+    if ((rc = launch_times_quad(e, sq))) return rc;
+    if ((rc = launch_quad_ell(e, sq, C, d, (mask & 2u) ? 1 : 0, pl.want_lat ? 1 : 0))) return rc;
+    HIPCHK(e, hipEventRecord(e->ev_quad, sq));
   }
-  // ---- spike pass (fp64 VALU bound): needs only a = Kzz^-1 m from k_prep.  A value-only evaluation reuses its sums
-  //      when the caller vouches (token) that C is unchanged since the pass that produced them
-  const bool reuse_p0 = !full && e->emb_token != 0 && e->p0_token == e->emb_token;
-  if (v.nchunks > 0 && !reuse_p0) {
-    // only a value-only pass leaves reusable sums: the full pass accumulates them with different roundings, and
-    // cached and un-cached evaluations are to stay bit-identical
-    e->p0_token = full ? 0 : e->emb_token;
-    const int evp = timing_begin(e, 0, sk);
-    launch_spike_pass(e, sk, full, (mask & 2u) != 0, C);
-    timing_end(e, evp, sk);
-    if (side) HIPCHK(e, hipEventRecord(e->ev_spk, sk));
+  // ---- spike pass (fp64 VALU bound): needs only a = Kzz^-1 m (and W) from k_prep
+  if (pl.run_spike) {
+    const int evp = timing_begin(e, 0, sm);
+    launch_spike_pass(e, sm, pl.full, (mask & 2u) != 0, C, have_w, pl.side, pl.side ? e->ev_prep : nullptr);
+    timing_end(e, evp, sm);
   }
-  if (!side) {
-    if ((rc = launch_times_quad(e))) return rc;
-    if ((rc = launch_quad_ell(e, C, d, (mask & 2u) ? 1 : 0, want_lat ? 1 : 0))) return rc;
+  if (!pl.side) {
+    if ((rc = launch_times_quad(e, sm))) return rc;
+    if ((rc = launch_quad_ell(e, sm, C, d, (mask & 2u) ? 1 : 0, pl.want_lat ? 1 : 0))) return rc;
+  } else {
+    HIPCHK(e, hipStreamWaitEvent(sm, e->ev_quad, 0));     // join the quadrature chain
   }
-  // ---- join the spike pass; per-item adjoints + backward + the fixed-order cross-trial reductions in one kernel
-  if (side) HIPCHK(e, hipStreamWaitEvent(sm, e->ev_spk, 0));
-  wait_classes(e, sm);                    // the gather reads ser even when the spike pass was skipped (reused sums)
+  // ---- per-item adjoints + backward + the fixed-order cross-trial reductions in one kernel
   const int evb = timing_begin(e, 1, sm);
   if (mask & (4u | 8u)) {
     DISPATCH_NT(e->NT, hipLaunchKernelGGL((k_item_bwd<NT_, true>), dim3(v.R * v.K), dim3(64 * e->tile_nw),
@@ -876,6 +907,103 @@ int svgpfa_elbo(svgpfa_engine* e, const double* const* mean, const double* const
   return SVGPFA_OK;
 }
 
+// One evaluation as one hipGraphLaunch (see svgpfa_engine::graphs).  Captured on a private stream -- the caller's may be
+// the null stream, which cannot be captured -- and replayed into the caller's.
+static int graph_elbo(svgpfa_engine* e, const PtrTable& pt, const ElboPlan& pl, const double* C, const double* d,
+                      double* shared) {
+  hipStream_t user = e->stream;
+  const bool need_cls = !e->cls_valid;
+  std::vector<uint64_t> key;
+  key.reserve(8 + 5 * (size_t)e->v.K);
+  key.push_back(pl.mask);
+  key.push_back((need_cls ? 1u : 0u) | (pl.run_spike ? 2u : 0u));
+  key.push_back((uint64_t)(uintptr_t)C);
+  key.push_back((uint64_t)(uintptr_t)d);
+  key.push_back((uint64_t)(uintptr_t)shared);
+  for (int k = 0; k < e->v.K; ++k)
+    for (const void* q : {(const void*)pt.p[k].mean, (const void*)pt.p[k].cholvec, (const void*)pt.p[k].g_mean,
+                          (const void*)pt.p[k].g_cholvec, (const void*)pt.p[k].g_Z})
+      key.push_back((uint64_t)(uintptr_t)q);
+  svgpfa_engine::GraphSlot* slot = nullptr;
+  for (auto& g : e->graphs)
+    if (g.key == key) slot = &g;
+  if (!slot && std::find(e->graph_seen.begin(), e->graph_seen.end(), key) == e->graph_seen.end()) {
+    // first sight of this pointer set (a caller that allocates its outputs per call never repeats one): plain launches
+    if (e->graph_seen.size() >= SV_GRAPH_SLOTS) e->graph_seen.erase(e->graph_seen.begin());
+    e->graph_seen.push_back(std::move(key));
+    return enqueue_elbo(e, pt, pl, C, d, shared);
+  }
+  if (!slot) {
+    e->stream = e->s_cap;
+    hipError_t st = hipStreamBeginCapture(e->s_cap, hipStreamCaptureModeRelaxed);
+    if (st != hipSuccess) {
+      e->stream = user;
+      e->err = std::string("hipStreamBeginCapture: ") + hipGetErrorString(st);
+      return SVGPFA_ERR_HIP;
+    }
+    const int rc = enqueue_elbo(e, pt, pl, C, d, shared);
+    hipGraph_t g = nullptr;
+    st = hipStreamEndCapture(e->s_cap, &g);
+    e->stream = user;
+    if (rc) {
+      if (g) (void)hipGraphDestroy(g);
+      return rc;
+    }
+    if (st != hipSuccess) {
+      e->err = std::string("hipStreamEndCapture: ") + hipGetErrorString(st);
+      return SVGPFA_ERR_HIP;
+    }
+    hipGraphExec_t ex = nullptr;
+    st = hipGraphInstantiate(&ex, g, nullptr, nullptr, 0);
+    (void)hipGraphDestroy(g);
+    if (st != hipSuccess) {
+      e->err = std::string("hipGraphInstantiate: ") + hipGetErrorString(st);
+      return SVGPFA_ERR_HIP;
+    }
+    if (e->graphs.size() >= SV_GRAPH_SLOTS) {     // least recently used out
+      size_t lru = 0;
+      for (size_t i = 1; i < e->graphs.size(); ++i)
+        if (e->graphs[i].used < e->graphs[lru].used) lru = i;
+      (void)hipGraphExecDestroy(e->graphs[lru].exec);
+      e->graphs.erase(e->graphs.begin() + lru);
+    }
+    e->graphs.emplace_back();
+    slot = &e->graphs.back();
+    slot->key = std::move(key);
+    slot->exec = ex;
+  }
+  slot->used = ++e->graph_clock;
+  e->cls_valid = true;
+  HIPCHK(e, hipGraphLaunch(slot->exec, user));
+  e->graph_replays += 1;
+  return SVGPFA_OK;
+}
+
+int svgpfa_elbo(svgpfa_engine* e, const double* const* mean, const double* const* cholvec, const double* C,
+                const double* d, unsigned mask, double* shared, double* const* g_mean,
+                double* const* g_cholvec, double* const* g_Z) {
+  if (!e || !C || !d || !shared) return SVGPFA_ERR_INVALID;
+  HIPCHK(e, hipSetDevice(e->device));
+  int rc;
+  if ((rc = check_ready(e))) return rc;
+  EngineView& v = e->v;
+  PtrTable pt;
+  if ((rc = fill_ptrs(e, pt, mean, cholvec, g_mean, g_cholvec, g_Z, mask))) return rc;
+  ElboPlan pl;
+  pl.mask = mask;
+  pl.want_lat = (mask & (1u | 4u | 8u)) != 0;
+  pl.full = (mask & (2u | 4u | 8u)) != 0;
+  pl.side = v.nchunks > 0 && (e->side_stream == 1 || (e->side_stream < 0 && (long long)v.R * v.K <= 2048));
+  // A value-only evaluation reuses the spike pass's sums when the caller vouches (token) that C is unchanged since the pass
+  // that produced them.  Only a value-only pass leaves reusable sums: the full pass accumulates them with different
+  // roundings, and cached and un-cached evaluations are to stay bit-identical
+  const bool reuse_p0 = !pl.full && e->emb_token != 0 && e->p0_token == e->emb_token;
+  pl.run_spike = v.nchunks > 0 && !reuse_p0;
+  if (pl.run_spike) e->p0_token = pl.full ? 0 : e->emb_token;
+  if (graph_default(e)) return graph_elbo(e, pt, pl, C, d, shared);
+  return enqueue_elbo(e, pt, pl, C, d, shared);
+}
+
 int svgpfa_latent_stats(svgpfa_engine* e, const double* const* mean, const double* const* cholvec,
                         double* mu_quad, double* var_quad, double* mu_spk, double* var_spk) {
   if (!e) return SVGPFA_ERR_INVALID;
@@ -886,8 +1014,8 @@ int svgpfa_latent_stats(svgpfa_engine* e, const double* const* mean, const doubl
   PtrTable pt;
   if ((rc = fill_ptrs(e, pt, mean, cholvec, nullptr, nullptr, nullptr, 0))) return rc;
   launch_prep(e, pt);
-  if ((rc = launch_times_quad(e))) return rc;
-  if ((rc = launch_times(e, v.spk_t, v.spk_off, 0, v.muspk, v.varspk, 0LL, 1LL, (long long)v.S, 1))) return rc;
+  if ((rc = launch_times_quad(e, e->stream))) return rc;
+  if ((rc = launch_times(e, e->stream, v.spk_t, v.spk_off, 0, v.muspk, v.varspk, 0LL, 1LL, (long long)v.S, 1))) return rc;
   {   // lanes per segment: about a quarter of the mean number of spikes per (trial, neuron), a power of two <= 32
     const long long seg = (long long)v.S / std::max(1LL, (long long)v.R * v.N);
     int gs = 1;
@@ -923,10 +1051,10 @@ int svgpfa_freeze_stats(svgpfa_engine* e, const double* const* mean, const doubl
   if ((rc = fill_ptrs(e, pt, mean, cholvec, nullptr, nullptr, nullptr, 0))) return rc;
   if (!e->cls_valid) launch_classes(e);
   launch_prep(e, pt);
-  if ((rc = launch_times_quad(e))) return rc;
+  if ((rc = launch_times_quad(e, e->stream))) return rc;
   // the per-neuron sums of the spike means are the spike part of dC, which the spike-time pass makes (cosine series:
   // ~0.3 ms at the north-star size against 2 ms for the posterior mean and variance at every spike)
-  if (v.nchunks > 0) launch_spike_pass(e, e->stream, true, true, C);
+  if (v.nchunks > 0) launch_spike_pass(e, e->stream, true, true, C, false, false, nullptr);
   e->p0_token = 0;                     // that pass overwrote the reusable spike sums
   hipLaunchKernelGGL(k_mseg_from_dc, dim3((v.N * v.K + SV_FS_OUT - 1) / SV_FS_OUT), dim3(256), 0, e->stream, v);
   HIPCHK(e, hipGetLastError());
@@ -973,7 +1101,6 @@ int svgpfa_latent_stats_backward(svgpfa_engine* e, const double* const* mean, co
     }
   }
   const unsigned m2 = mask | SV_MASK_STATS;
-  wait_classes(e, e->stream);
   if (mask & (4u | 8u)) {
     DISPATCH_NT(e->NT, hipLaunchKernelGGL((k_item_bwd<NT_, true>), dim3(v.R * v.K), dim3(64 * e->tile_nw),
                                           lds_item_bwd(NT_, e->tile_nw, true), e->stream, v, pt, m2, (const double*)nullptr,
@@ -995,7 +1122,7 @@ int svgpfa_ell_given_stats(svgpfa_engine* e, const double* C, const double* d, i
   if (!e->have_stats) FAIL(e, SVGPFA_ERR_STATE, "svgpfa_latent_stats has not been called since the last data / kernel change");
   EngineView& v = e->v;
   int rc;
-  if ((rc = launch_quad_ell(e, C, d, want_grad ? 1 : 0, 0))) return rc;
+  if ((rc = launch_quad_ell(e, e->stream, C, d, want_grad ? 1 : 0, 0))) return rc;
   int nout = v.N * v.K + v.N;
   hipLaunchKernelGGL(k_finalize_stats, dim3((nout + SV_FS_OUT - 1) / SV_FS_OUT + 1), dim3(256), 0, e->stream, v, C, d, want_grad,
                      out);
@@ -1013,7 +1140,7 @@ int svgpfa_predict(svgpfa_engine* e, const double* const* mean, const double* co
   int rc;
   if ((rc = fill_ptrs(e, pt, mean, cholvec, nullptr, nullptr, nullptr, 0))) return rc;
   launch_prep(e, pt);
-  if ((rc = launch_times(e, times, nullptr, (int)T, mu, var ? var : mu, (long long)T * v.K, (long long)v.K, 1LL,
+  if ((rc = launch_times(e, e->stream, times, nullptr, (int)T, mu, var ? var : mu, (long long)T * v.K, (long long)v.K, 1LL,
                          var ? 1 : 0)))
     return rc;
   HIPCHK(e, hipGetLastError());
@@ -1077,6 +1204,8 @@ int svgpfa_set_embedding_token(svgpfa_engine* e, uint64_t token) {
   e->emb_token = token;
   return SVGPFA_OK;
 }
+
+int64_t svgpfa_graph_replays(const svgpfa_engine* e) { return e ? e->graph_replays : 0; }
 
 int svgpfa_enable_timing(svgpfa_engine* e, int on) {
   if (!e) return SVGPFA_ERR_INVALID;

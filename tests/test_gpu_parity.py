@@ -639,3 +639,48 @@ def test_pointer_table_cache_survives_address_recycling():
         eng.elbo([small, mean[1]], P["cholVecs"], P["C"], P["d"], 0)
     eng.sync()
     print("address recycled:", recycled)
+
+
+@pytest.mark.parametrize("kernels", ["mix", "rbf"])
+def test_graph_replay_is_bit_identical_to_plain_launches(monkeypatch, kernels):
+    """With SVGPFA_GRAPH=1 an engine replays a recorded HIP graph from the second evaluation with the same buffers on
+    (include/svgpfa.h: svgpfa_graph_replays; off by default).  Same bits as the plain launch sequence (SVGPFA_GRAPH=0) for every variant the graph key tells
+    apart -- gradient masks, evaluations right after a kernel build (the class table's kernel inside the graph) and later
+    ones, spike sums reused under a token -- with the parameter VALUES changing between replays."""
+    prob = synthetic.make_problem(R=6, N=12, K=3, M=[10, 14, 8], kernels=kernels, seed=31, n_quad=40, rate=25.0, jitter=1.0)
+    seqs, replays = {}, {}
+    for mode in ("0", "1", None):
+        if mode is None:
+            monkeypatch.delenv("SVGPFA_GRAPH")
+        else:
+            monkeypatch.setenv("SVGPFA_GRAPH", mode)
+        eng, P = _engine(prob)
+        seq = []
+        for mask in (15, 1, 0, 3):
+            shared = torch.empty(eng.shared_len, dtype=torch.float64, device=P["C"].device)
+            grads = eng.alloc_grads(mask)
+            for it in range(5):
+                P["mean"][0].mul_(1.0 + 0.01 * it)
+                P["C"].mul_(1.0 - 0.002 * it)
+                if it == 3:
+                    P["Z"][1].add_(0.003)
+                if it >= 3:
+                    eng.build_kernels(P["Z"], P["theta"])
+                eng.elbo(P["mean"], P["cholVecs"], P["C"], P["d"], mask, out=shared, grads=grads)
+                eng.sync()
+                seq.append([shared.clone()] + [t.clone() for g in grads if g is not None for t in g])
+        shared = torch.empty(eng.shared_len, dtype=torch.float64, device=P["C"].device)
+        eng.set_embedding_token(77)
+        for it in range(4):
+            P["mean"][1].mul_(0.99)
+            eng.elbo(P["mean"], P["cholVecs"], P["C"], P["d"], 0, out=shared, grads=(None, None, None))
+            eng.sync()
+            seq.append([shared.clone()])
+        seqs[mode], replays[mode] = seq, eng.graph_replays()
+        eng.close()
+    assert replays["0"] == 0 and replays["1"] >= 12 and replays[None] == 0, replays
+    for other in ("1", None):
+        for a, b in zip(seqs["0"], seqs[other]):
+            for x, y in zip(a, b):
+                assert torch.equal(x, y)
+    assert float(seqs["0"][0][0][0]) != float(seqs["0"][1][0][0])
