@@ -407,6 +407,12 @@ def main():
         if use_dist:
             allreduce_shared(shared)   # RCCL sum of [ELBO, ELL, KL, dC, dd, dtheta]
 
+    # Python's cyclic collector, left alone, runs a full (generation 2) pass over everything torch's import left on the heap
+    # some tens of evaluations into the loop -- 40 ms, 400 steps' worth at cfg2 (tests/tools/step_jitter.py).  The heap as
+    # it is now is frozen (never scanned again); what the loop itself allocates stays collectable.
+    import gc
+    gc.collect()
+    gc.freeze()
     # one-off initialisation outside the W + K protocol: first launches load the code objects and create the RCCL
     # communicator channels lazily, and the GPU leaves its idle clocks only after some tens of milliseconds of work
     # (a 20-step run right behind engine set-up measured 0.88 ms per step against 0.84 ms once the clocks had settled);

@@ -155,6 +155,7 @@ struct EngineView {
   double* splitS;                                  // [nsplitS][K]
   double* Apart;                                   // [ntiles][K][SV_ACOLS] A-moment partials
   double* Wb;                                      // [R][K][SV_WCOLS] posterior-mean weights on the harmonics
+  double* Ub;                                      // [ntiles][K][SV_WCOLS][64] the rows' cos / sin moments (small shards only)
   double* P0t; double* P1t; double* Tt;            // [R][sumM] x 2, [R][K][2]: spike sums of class-path items (k_spike_comb)
   int comb_fold;                                   // 1: k_item_bwd's gather combines the moments itself (small shards)
   double* muspk;                                   // [K][S] (stats API only)
@@ -281,14 +282,19 @@ __device__ inline int periodic_series(double beta, int M, double* tab, double* f
   sum += fc;
   const double inv = 1.0 / sum;
   int H = 0;
+  if (!tab) {                                    // H only (class riders / k_spike_classes): no table, no divisions
+    for (int n = 1; n <= SV_FH + 1; ++n)
+      if (n * (2.0 * (f[n] * inv)) >= 1e-18) H = n;
+    if (H > SV_FH) return -1;
+    if (12 * (H + 2) > 23 * M) return -1;
+    return H;
+  }
   for (int n = 0; n <= SV_FH + 1; ++n) {
     const double ive = f[n] * inv, ivep = f[n + 1] * inv, ivem = (n ? f[n - 1] : f[1]) * inv;
     const double cn = (n ? 2.0 : 1.0) * ive;
-    if (tab) {                                   // (nullptr: the caller wants H only -- class blocks of k_build_reg)
-      tab[n] = cn;
-      tab[(SV_FH + 2) + n] = -0.5 * (n ? 2.0 : 1.0) * (0.5 * (ivem + ivep) - ive);   // g_n = -1/2 dc_n / dbeta
-      tab[2 * (SV_FH + 2) + n] = n * cn / beta;
-    }
+    tab[n] = cn;
+    tab[(SV_FH + 2) + n] = -0.5 * (n ? 2.0 : 1.0) * (0.5 * (ivem + ivep) - ive);   // g_n = -1/2 dc_n / dbeta
+    tab[2 * (SV_FH + 2) + n] = n * cn / beta;
     if (n * cn >= 1e-18 || n == 0) H = n;
   }
   if (H > SV_FH) return -1;

@@ -35,17 +35,26 @@
 #include "spike_cls_common.h"
 
 // ------------------------------------------------------------------------------------------------ k_spike_classes
-// The class table and the per-trial entries for the engine's kernel SNAPSHOT, when the spikes arrived after the kernel
-// build (else the class blocks of k_build_reg made them): grid = ceil(R / 4) blocks of 256 threads, every block rebuilds
-// the (tiny) table in LDS, one wavefront per trial then fills the per-trial entries.
-__global__ __launch_bounds__(256) void k_spike_classes(EngineView ev) {
+// The class table and the per-trial entries in a launch of their own: for the engine's kernel SNAPSHOT when the spikes
+// arrived after the kernel build (snap = 0; else the class blocks of k_build_reg made them), or from the caller's Z / theta
+// on the spike stream of small shards, beside the kernel build (snap = 1).  grid = ceil(R / 4) blocks of 256 threads,
+// every block rebuilds the (tiny) table in LDS, one wavefront per trial then fills the per-trial entries.
+__global__ __launch_bounds__(256) void k_spike_classes(EngineView ev, int snap, SnapTable st) {
   __shared__ SpikeClassScratch cs;
+  __shared__ double fws[SV_MAX_K * (SV_FH + 3)];
   const int wave = threadIdx.x >> 6, R = ev.R;
   const int r = blockIdx.x * 4 + wave;
-  if (wave == 0) spike_class_table(ev, cs, nullptr, nullptr);
+  // (two call sites each: behind a select between &st and nullptr the compiler copies the table to scratch memory)
+  if (wave == 0) {
+    if (snap) spike_class_table(ev, cs, &st, fws);
+    else spike_class_table(ev, cs, nullptr, nullptr);
+  }
   __syncthreads();
   if (blockIdx.x == 0 && wave == 1) spike_class_store(ev, cs);
-  if (r < R) spike_class_trial(ev, cs, nullptr, r);
+  if (r < R) {
+    if (snap) spike_class_trial(ev, cs, &st, r);
+    else spike_class_trial(ev, cs, nullptr, r);
+  }
 }
 
 // ------------------------------------------------------------------------------------------------ k_spike_pre
@@ -115,9 +124,11 @@ __device__ __forceinline__ void cls_pass(const double* __restrict__ tt, int maxl
 // Ut[row][16] so that the tile's partial A-moments  Apart[member][col] = sum_rows C[neuron(row), member] U[row][col]
 // come out of 16 v_mfma_f64_16x16x4_f64 (A operand: the gathered embedding weights cg, B operand: U); and, DC, the
 // rows' own dC partials  dcl[member][row] += sum_cols U[row][col] W[member][col]  on the VALU (W is wave-uniform).
-template <int NV, int HB, bool DC>
+// DC = 2: instead, the rows' cos / sin moments are STORED (Ub[tile][class][column][row]) for k_spike_dc -- the arrangement
+// of small shards, where this kernel runs before a = Kzz^-1 m (hence W) exists.
+template <int NV, int HB, int DC>
 __device__ __forceinline__ void cls_flush(const EngineView& ev, const double* __restrict__ C, const double (&acc)[NV * HB],
-                                          int neuron, int nrows, int memk, int nmem, int tile, int r, int h0, int H,
+                                          int neuron, int nrows, int memk, int nmem, int tile, int g, int r, int h0, int H,
                                           double* Ut, double* dcl) {
   const int lane = threadIdx.x, li = lane & 15, lg = lane >> 4, K = ev.K;
   const int ncol = NV * (H + 1);           // valid columns of the class's moment rows
@@ -164,7 +175,18 @@ __device__ __forceinline__ void cls_flush(const EngineView& ev, const double* __
       lds_wave_fence();                    // the tile is free for the next chunk
     }
   }
-  if (DC) {
+  if (DC == 2) {
+    double* ub = ev.Ub + ((long long)tile * K + g) * SV_WCOLS * 64 + lane;      // column-major over the tile's rows: coalesced
+#pragma unroll
+    for (int n = 0; n < HB; ++n) {
+      const int col = 2 * (h0 + n);
+      if (col < 2 * (H + 1)) {               // wave-uniform
+        ub[(long long)col * 64] = acc[NV * n + 0];
+        ub[(long long)(col + 1) * 64] = acc[NV * n + 1];
+      }
+    }
+  }
+  if (DC == 1) {
     // W of the members for this pass's harmonics, staged through the (now idle) transpose tile: [member][2 HB], entries
     // beyond the last harmonic are zeros (k_spike_pre).  Coalesced loads, all in flight, then broadcast reads.
     constexpr int WP = 2 * HB;                       // doubles per member and pass
@@ -196,7 +218,31 @@ __device__ __forceinline__ void cls_flush(const EngineView& ev, const double* __
   }
 }
 
-template <int NV, bool DC>
+// the rows' dC partials: every (trial, neuron, latent) entry of BOTH planes is written on every pass -- a whole segment
+// writes plane A and clears plane B, the halves of a cut segment write one plane each -- so the planes stay valid when an
+// item changes between this path and the pair loop; pieces of an oversize segment go to their slot
+__device__ __forceinline__ void cls_emit_rows(const EngineView& ev, const SpikeRow& row, int r, int memk, int nmem,
+                                              const double* dcl) {
+  const int lane = threadIdx.x, K = ev.K;
+  if (row.len <= 0) return;
+  for (int s = 0; s < nmem; ++s) {
+    const int k = __shfl(memk, s, 64);
+    const double v = dcl[s * 64 + lane];
+    const long long o = ((long long)r * ev.N + row.neuron) * K + k;
+    if (row.kind == 0) {
+      ev.gCspk[o] = v;
+      ev.gCspkB[o] = 0.0;
+    } else if (row.kind == 1) {
+      ev.gCspk[o] = v;
+    } else if (row.kind == 2) {
+      ev.gCspkB[o] = v;
+    } else {
+      ev.splitS[(long long)row.slot * K + k] = v;
+    }
+  }
+}
+
+template <int NV, int DC>
 __device__ __forceinline__ void cls_item(const EngineView& ev, const double* __restrict__ C, const SpikeClassTab* cls,
                                          int g, int ord, double* Ut, double* dcl) {
   constexpr int HBM = (NV == 2) ? 24 : 16;          // largest register pass: 48 / 64 accumulators
@@ -217,49 +263,31 @@ __device__ __forceinline__ void cls_item(const EngineView& ev, const double* __r
     if (left > 16 && NV == 2) {
       double acc[NV * 24];
       cls_pass<NV, 24>(tt, tl.maxlen, row.len, lane, t0, sc, h0, acc);
-      cls_flush<NV, 24, DC>(ev, C, acc, row.neuron, tl.nrows, memk, nmem, tile, r, h0, H, Ut, dcl);
+      cls_flush<NV, 24, DC>(ev, C, acc, row.neuron, tl.nrows, memk, nmem, tile, g, r, h0, H, Ut, dcl);
     } else if (left > 8) {
       double acc[NV * 16];
       cls_pass<NV, 16>(tt, tl.maxlen, row.len, lane, t0, sc, h0, acc);
-      cls_flush<NV, 16, DC>(ev, C, acc, row.neuron, tl.nrows, memk, nmem, tile, r, h0, H, Ut, dcl);
+      cls_flush<NV, 16, DC>(ev, C, acc, row.neuron, tl.nrows, memk, nmem, tile, g, r, h0, H, Ut, dcl);
     } else {
       double acc[NV * 8];
       cls_pass<NV, 8>(tt, tl.maxlen, row.len, lane, t0, sc, h0, acc);
-      cls_flush<NV, 8, DC>(ev, C, acc, row.neuron, tl.nrows, memk, nmem, tile, r, h0, H, Ut, dcl);
+      cls_flush<NV, 8, DC>(ev, C, acc, row.neuron, tl.nrows, memk, nmem, tile, g, r, h0, H, Ut, dcl);
     }
   }
-  if (DC && row.len > 0) {
-    // the row's dC partials: every (trial, neuron, latent) entry of BOTH planes is written on every pass -- a whole
-    // segment writes plane A and clears plane B, the halves of a cut segment write one plane each -- so the planes stay
-    // valid when an item changes between this path and the pair loop; pieces of an oversize segment go to their slot
-    for (int s = 0; s < nmem; ++s) {
-      const int k = __shfl(memk, s, 64);
-      const double v = dcl[s * 64 + lane];
-      const long long o = ((long long)r * ev.N + row.neuron) * K + k;
-      if (row.kind == 0) {
-        ev.gCspk[o] = v;
-        ev.gCspkB[o] = 0.0;
-      } else if (row.kind == 1) {
-        ev.gCspk[o] = v;
-      } else if (row.kind == 2) {
-        ev.gCspkB[o] = v;
-      } else {
-        ev.splitS[(long long)row.slot * K + k] = v;
-      }
-    }
-  }
+  if (DC == 1) cls_emit_rows(ev, row, r, memk, nmem, dcl);
 }
 
 // Work item = (tile, class); the number of classes is only known on the device, so the grid is a fixed number of
 // single-wave blocks that stride over the items (tiles in the host's cost order, longest first).
 // NV = 4: the classes that carry the time-weighted moments (periodic classes when Z / theta gradients are wanted: `full`);
-// NV = 2: all others.  Two kernels rather than one: the NV = 2 pass needs a third fewer registers.  DC: dC wanted.
-template <int NV, bool DC>
+// NV = 2: all others.  Two kernels rather than one: the NV = 2 pass needs a third fewer registers.
+// DC: 0 no dC, 1 dC rows here (needs W), 2 moments stored for k_spike_dc.
+template <int NV, int DC>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 8))) void k_spike_cls(EngineView ev,
                                                                                              const double* __restrict__ C,
                                                                                              int full) {
   __shared__ double Ut[64 * 16];
-  __shared__ double dcl[DC ? SV_CLS_MAXMEM * 64 : 1];
+  __shared__ double dcl[DC == 1 ? SV_CLS_MAXMEM * 64 : 1];
   const SpikeClassTab* cls = ev.cls;
   const int ncls = cls->ncls;
   int mine = 0;                                  // classes this kernel serves (scalar loop, ncls <= 32)
@@ -274,6 +302,71 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 8))) void
       }
     }
     cls_item<NV, DC>(ev, C, cls, g, w / mine, Ut, dcl);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ k_spike_dc
+// dC rows of the class path from STORED moments (k_spike_cls<.., 2>):  dcl[member][row] = sum_cols U[row][col] W[member][col],
+// in the passes and the order of cls_flush's fused form (bit-identical rows).  Work item = (tile, class), single-wave
+// blocks striding a fixed grid; `full` as in the moment kernels' launch (it sets the classes' pass length).
+__global__ __launch_bounds__(64) void k_spike_dc(EngineView ev, int full) {
+  __shared__ double Wl[SV_CLS_MAXMEM * 48];
+  __shared__ double dcl[SV_CLS_MAXMEM * 64];
+  const SpikeClassTab* cls = ev.cls;
+  const int ncls = cls->ncls, K = ev.K, R = ev.R, lane = threadIdx.x;
+  const int nitems = ev.ntiles * ncls;
+  for (int w = blockIdx.x; w < nitems; w += gridDim.x) {
+    const int g = w % ncls;
+    const SpikeTile tl = ev.tiles_ord[w / ncls];
+    const int r = tl.trial, tile = tl.id;
+    const int H = ev.cls_H[(long long)g * R + r];
+    if (H < 0) continue;                               // this (trial, class) takes the pair loop
+    const int nmem = cls->nmem[g];
+    const int memk = cls->mem[g][lane & (SV_CLS_MAXMEM - 1)];
+    SpikeRow row = ev.rows[tl.row0 + (lane < tl.nrows ? lane : 0)];
+    if (lane >= tl.nrows) row = SpikeRow{0, 0, 0, 0};
+    const int HBM = (full && cls->type[g] == SV_PERIODIC) ? 16 : 24;
+    const double* ub = ev.Ub + ((long long)tile * K + g) * SV_WCOLS * 64 + lane;
+    for (int h0 = 0; h0 <= H; h0 += HBM) {
+      const int left = H + 1 - h0;
+      const int HB = (left > 16 && HBM == 24) ? 24 : (left > 8) ? 16 : 8, WP = 2 * HB;
+      const int tot = nmem * WP;
+      for (int e = lane; e < tot; e += 64) {           // W of the members for this pass's harmonics (zeros beyond H)
+        const int sm = e / WP, c = e % WP, col = 2 * h0 + c;
+        const int mk = cls->mem[g][sm];
+        Wl[e] = (col < SV_WCOLS) ? ev.Wb[((long long)r * K + mk) * SV_WCOLS + col] : 0.0;
+      }
+      lds_wave_fence();
+      double v[SV_CLS_MAXMEM];
+#pragma unroll
+      for (int s = 0; s < SV_CLS_MAXMEM; ++s) v[s] = 0.0;
+      for (int n0 = 0; n0 < HB; n0 += 8) {             // eight harmonics' moments in flight
+        double u[16];
+#pragma unroll
+        for (int n = 0; n < 8; ++n) {
+          const int col = 2 * (h0 + n0 + n);
+          const bool ok = col < 2 * (H + 1);           // wave-uniform; beyond H the fused form multiplies by W = 0
+          u[2 * n] = ok ? ub[(long long)col * 64] : 0.0;
+          u[2 * n + 1] = ok ? ub[(long long)(col + 1) * 64] : 0.0;
+        }
+#pragma unroll
+        for (int s = 0; s < SV_CLS_MAXMEM; ++s)
+          if (s < nmem) {
+            const double* Wk = Wl + s * WP + 2 * n0;
+#pragma unroll
+            for (int n = 0; n < 8; ++n) {
+              v[s] = fma(u[2 * n], Wk[2 * n], v[s]);
+              v[s] = fma(u[2 * n + 1], Wk[2 * n + 1], v[s]);
+            }
+          }
+      }
+#pragma unroll
+      for (int s = 0; s < SV_CLS_MAXMEM; ++s)
+        if (s < nmem) dcl[s * 64 + lane] = (h0 == 0) ? v[s] : dcl[s * 64 + lane] + v[s];
+      lds_wave_fence();                                // W's tile is free for the next pass
+    }
+    cls_emit_rows(ev, row, r, memk, nmem, dcl);
+    lds_wave_fence();
   }
 }
 

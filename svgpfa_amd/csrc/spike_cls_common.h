@@ -129,6 +129,34 @@ __device__ inline void spike_class_trial(const EngineView& ev, const SpikeClassS
       pair = true;
     }
   const double PI = 3.14159265358979323846;
+  // Extent of every RBF member's inducing points in this trial: all latents' loads in flight at once (one latent after the
+  // other, each behind its own dependent load, made this function 15 us long), reduced per latent; lane k keeps latent k's.
+  double zlo_k = slo, zhi_k = slo;
+  {
+    double zv[SV_MAX_K];
+#pragma unroll
+    for (int k = 0; k < SV_MAX_K; ++k) {
+      zv[k] = slo;                                     // neutral: the window contains [slo, shi] anyway
+      if (k < K && tab.cls_of[k] >= 0 && tab.type[tab.cls_of[k]] == SV_RBF && lane < cs.Mk[k]) {
+        const double* zk = snap ? snap->Z[k] : ev.Zs + cs.offMk[k];
+        zv[k] = zk[(long long)r * cs.Mk[k] + lane];
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < SV_MAX_K; ++k)
+      if (k < K) {                                     // wave-uniform
+        double lo = zv[k], hi = zv[k];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+          lo = fmin(lo, __shfl_xor(lo, o, 64));
+          hi = fmax(hi, __shfl_xor(hi, o, 64));
+        }
+        if (lane == k) {
+          zlo_k = lo;
+          zhi_k = hi;
+        }
+      }
+  }
   for (int g = 0; g < tab.ncls; ++g) {
     double t0 = 0.0, sc = cs.lead[g];
     int H = cs.clsH[g];
@@ -137,17 +165,8 @@ __device__ inline void spike_class_trial(const EngineView& ev, const SpikeClassS
       double lo = slo, hi = shi;
       for (int s = 0; s < tab.nmem[g]; ++s) {
         const int k = tab.mem[g][s];
-        if (lane < cs.Mk[k]) {
-          const double* zk = snap ? snap->Z[k] : ev.Zs + cs.offMk[k];
-          const double zj = zk[(long long)r * cs.Mk[k] + lane];
-          lo = fmin(lo, zj);
-          hi = fmax(hi, zj);
-        }
-      }
-#pragma unroll
-      for (int o = 32; o > 0; o >>= 1) {
-        lo = fmin(lo, __shfl_xor(lo, o, 64));
-        hi = fmax(hi, __shfl_xor(hi, o, 64));
+        lo = fmin(lo, __shfl(zlo_k, k, 64));
+        hi = fmax(hi, __shfl(zhi_k, k, 64));
       }
       const double L = (hi - lo) + sqrt(41.5 / cs.lead[g]);     // wrapped copies below e^-41.5 = 1e-18 for every member
       H = 0;

@@ -60,8 +60,15 @@ struct svgpfa_engine {
   // roofline.  SVGPFA_OVERLAP=0 / 1 forces it off / on.  (Round 2 measured, ms per evaluation of cfg3, one stream -> two:
   // 1-way 1.219 -> 1.183, 2-way 0.664 -> 0.648, 4-way 0.384 -> 0.355, 8-way 0.236 -> 0.230.)
   int side_stream = -1;
-  hipStream_t s_side = nullptr, s_side2 = nullptr;   // quadrature chain / second class kernel on small shards
+  hipStream_t s_side = nullptr, s_side2 = nullptr, s_side3 = nullptr;   // quadrature chain / spike pass on small shards
   hipEvent_t ev_prep = nullptr, ev_quad = nullptr, ev_fork = nullptr, ev_join = nullptr;
+  hipEvent_t ev_b0 = nullptr, ev_cls = nullptr, ev_e0 = nullptr, ev_spk = nullptr;
+  // Small shards with the class path (SVGPFA_EARLY=0 turns it off): the spike MOMENTS need the spikes, C and the kernels'
+  // frequencies, nothing of Kzz -- so the class table (beside k_build_reg, from the caller's Z / theta) and the moment
+  // kernels (beside k_build_reg / k_prep / the quadrature chain) run on a stream of their own, store the rows' moments,
+  // and only the small tail that needs a = Kzz^-1 m (dC rows from the stored moments, pair loop) waits for k_prep.
+  bool early = false;
+  bool cls_wait = false;                        // the class table of the current build is (was) made on the spike stream
   bool fork_always = false;                     // SVGPFA_FORK=1: the two class kernels on two streams at every size (experiment)
   bool cls_on = true;                           // false: problem too small for the class path's extra launches (set_spikes)
   double series_min_pairs = 1e7;                // SVGPFA_SERIES_MIN_PAIRS: fewest (spike, inducing point) pairs for the class path
@@ -290,6 +297,7 @@ int svgpfa_create(const svgpfa_dims* d, int device, svgpfa_engine** out) {
   HIPCHK(e, hipHostMalloc((void**)&e->status_host, sizeof(int)));
   HIPCHK(e, hipStreamCreateWithFlags(&e->s_side, hipStreamNonBlocking));
   HIPCHK(e, hipStreamCreateWithFlags(&e->s_side2, hipStreamNonBlocking));
+  HIPCHK(e, hipStreamCreateWithFlags(&e->s_side3, hipStreamNonBlocking));
   HIPCHK(e, hipStreamCreateWithFlags(&e->s_cap, hipStreamNonBlocking));
   if (getenv("SVGPFA_GRAPH")) e->graph_mode = atoi(getenv("SVGPFA_GRAPH")) != 0 ? 1 : 0;
   {
@@ -315,7 +323,7 @@ int svgpfa_create(const svgpfa_dims* d, int device, svgpfa_engine** out) {
     e->grid_cls = std::max(8, prop.multiProcessorCount * std::max(1, bc));
     e->grid_pair = std::max(8, (prop.multiProcessorCount * std::max(1, bp)) & ~7);
   }
-  for (hipEvent_t* ev : {&e->ev_prep, &e->ev_quad, &e->ev_fork, &e->ev_join})
+  for (hipEvent_t* ev : {&e->ev_prep, &e->ev_quad, &e->ev_fork, &e->ev_join, &e->ev_b0, &e->ev_cls, &e->ev_e0, &e->ev_spk})
     HIPCHK(e, hipEventCreateWithFlags(ev, hipEventDisableTiming));
 
   int rc = 0;
@@ -342,9 +350,9 @@ void svgpfa_destroy(svgpfa_engine* e) {
   for (void* p : e->allocs) (void)hipFree(p);
   if (e->status_host) (void)hipHostFree(e->status_host);
   drop_graphs(e);
-  for (hipStream_t st : {e->s_side, e->s_side2, e->s_cap})
+  for (hipStream_t st : {e->s_side, e->s_side2, e->s_side3, e->s_cap})
     if (st) (void)hipStreamDestroy(st);
-  for (hipEvent_t ev : {e->ev_prep, e->ev_quad, e->ev_fork, e->ev_join})
+  for (hipEvent_t ev : {e->ev_prep, e->ev_quad, e->ev_fork, e->ev_join, e->ev_b0, e->ev_cls, e->ev_e0, e->ev_spk})
     if (ev) (void)hipEventDestroy(ev);
   for (auto& pr : e->ev_pool) {
     (void)hipEventDestroy(pr.first);
@@ -606,6 +614,12 @@ int svgpfa_set_spikes(svgpfa_engine* e, const int64_t* off, const double* times,
   // evaluation (class table, W, one or two class kernels), which only pays once the pair loop itself takes tens of
   // microseconds (cfg2, 4e6 pairs: 0.137 ms per evaluation with the class path against 0.11 without)
   e->cls_on = (double)S * (double)v.sumM >= e->series_min_pairs;
+  {
+    const bool side = v.nchunks > 0 && (e->side_stream == 1 || (e->side_stream < 0 && (long long)v.R * v.K <= 2048));
+    e->early = side && e->cls_on && v.ntiles > 0 && e->graph_mode != 1 &&      // (a captured evaluation forks from its own origin only)
+               !(getenv("SVGPFA_EARLY") && atoi(getenv("SVGPFA_EARLY")) == 0);
+    if (e->early) DALLOC(e, v.Ub, (size_t)v.ntiles * v.K * SV_WCOLS * 64);
+  }
   e->have_spikes = true;
   e->have_stats = false;
   e->p0_token = 0;
@@ -640,8 +654,11 @@ static void launch_build(svgpfa_engine* e, int write_aux, const SnapTable* snap,
 static bool graph_default(const svgpfa_engine* e) { return !e->timing && e->graph_mode == 1; }
 
 static void launch_classes(svgpfa_engine* e) {
-  hipLaunchKernelGGL(k_spike_classes, dim3((e->v.R + 3) / 4), dim3(256), 0, e->stream, e->v);
+  SnapTable none;
+  memset(&none, 0, sizeof none);
+  hipLaunchKernelGGL(k_spike_classes, dim3((e->v.R + 3) / 4), dim3(256), 0, e->stream, e->v, 0, none);
   e->cls_valid = true;
+  e->cls_wait = false;
 }
 
 int svgpfa_build_kernels(svgpfa_engine* e, const double* const* Z, const double* const* theta) {
@@ -656,7 +673,18 @@ int svgpfa_build_kernels(svgpfa_engine* e, const double* const* Z, const double*
     st.theta[k] = theta[k];
   }
   const bool cls = e->have_spikes && e->cls_on;
-  launch_build(e, 0, &st, cls);
+  if (cls && e->early) {
+    // the class table on the spike stream, from the caller's tensors, beside the build (behind everything enqueued so far:
+    // the previous evaluation's kernels read the table)
+    HIPCHK(e, hipEventRecord(e->ev_b0, e->stream));
+    HIPCHK(e, hipStreamWaitEvent(e->s_side2, e->ev_b0, 0));
+    hipLaunchKernelGGL(k_spike_classes, dim3((v.R + 3) / 4), dim3(256), 0, e->s_side2, v, 1, st);
+    HIPCHK(e, hipEventRecord(e->ev_cls, e->s_side2));
+    e->cls_wait = true;
+  } else {
+    e->cls_wait = false;
+  }
+  launch_build(e, 0, &st, cls && !e->early);
   e->aux_valid = false;
   e->p0_token = 0;
   e->cls_valid = cls || !e->cls_on;
@@ -752,7 +780,7 @@ static int launch_times_quad(svgpfa_engine* e, hipStream_t st) {
 #define SV_EV_POOL_MAX 4096
 static int fold_events(svgpfa_engine* e) {
   HIPCHK(e, hipStreamSynchronize(e->stream));
-  for (hipStream_t st : {e->s_side, e->s_side2})
+  for (hipStream_t st : {e->s_side, e->s_side2, e->s_side3})
     if (st) HIPCHK(e, hipStreamSynchronize(st));      // the event pairs live there when the pass is overlapped
   for (size_t i = 0; i < e->ev_used; ++i) {
     float ms = 0.f;
@@ -780,6 +808,31 @@ static int timing_begin(svgpfa_engine* e, int slot, hipStream_t st) {
 }
 static void timing_end(svgpfa_engine* e, int idx, hipStream_t st) {
   if (idx >= 0) (void)hipEventRecord(e->ev_pool[idx].second, st);
+}
+
+// Readers of the class table on the main stream wait (once) for the spike stream's k_spike_classes of the current build.
+static void await_classes(svgpfa_engine* e) {
+  if (!e->cls_wait) return;
+  (void)hipStreamWaitEvent(e->stream, e->ev_cls, 0);
+  e->cls_wait = false;
+}
+
+// pair-by-pair pass over the (chunk, latent) items the class path does not serve (early exit per trial when it serves all)
+static void launch_pair_pass(svgpfa_engine* e, hipStream_t sk, bool full, bool want_c, const double* C) {
+  EngineView& v = e->v;
+  const dim3 bs(64);
+  const long long npair = (long long)v.nchunks * v.K;
+  const dim3 gp((unsigned)std::min<long long>((npair + 7) & ~7LL, e->grid_pair));
+  if (npair <= 0) return;
+  if (e->precision == SVGPFA_PRECISION_MIXED) {
+    if (full && !want_c) hipLaunchKernelGGL((k_spike<true, float, false>), gp, bs, 0, sk, v, C);
+    else if (full) hipLaunchKernelGGL((k_spike<true, float>), gp, bs, 0, sk, v, C);
+    else hipLaunchKernelGGL((k_spike<false, float>), gp, bs, 0, sk, v, C);
+  } else {
+    if (full && !want_c) hipLaunchKernelGGL((k_spike<true, double, false>), gp, bs, 0, sk, v, C);
+    else if (full) hipLaunchKernelGGL((k_spike<true>), gp, bs, 0, sk, v, C);
+    else hipLaunchKernelGGL((k_spike<false>), gp, bs, 0, sk, v, C);
+  }
 }
 
 // The spike-time pass on stream sk.  full: Z / theta gradient sums wanted too; want_c: the spike means' per-neuron sums (dC)
@@ -812,11 +865,11 @@ static void launch_spike_pass(svgpfa_engine* e, hipStream_t sk, bool full, bool 
       (void)hipStreamWaitEvent(s4, ev_w, 0);
     }
     if (full && want_c) {
-      if (tw) hipLaunchKernelGGL((k_spike_cls<4, true>), gc, bs, 0, s4, v, C, 1);
-      hipLaunchKernelGGL((k_spike_cls<2, true>), gc, bs, 0, sk, v, C, 1);
+      if (tw) hipLaunchKernelGGL((k_spike_cls<4, 1>), gc, bs, 0, s4, v, C, 1);
+      hipLaunchKernelGGL((k_spike_cls<2, 1>), gc, bs, 0, sk, v, C, 1);
     } else {
-      if (tw) hipLaunchKernelGGL((k_spike_cls<4, false>), gc, bs, 0, s4, v, C, 1);
-      hipLaunchKernelGGL((k_spike_cls<2, false>), gc, bs, 0, sk, v, C, full ? 1 : 0);
+      if (tw) hipLaunchKernelGGL((k_spike_cls<4, 0>), gc, bs, 0, s4, v, C, 1);
+      hipLaunchKernelGGL((k_spike_cls<2, 0>), gc, bs, 0, sk, v, C, full ? 1 : 0);
     }
     if (fork) {
       (void)hipEventRecord(e->ev_join, s4);
@@ -829,21 +882,46 @@ static void launch_spike_pass(svgpfa_engine* e, hipStream_t sk, bool full, bool 
     if (full) hipLaunchKernelGGL(k_spike_comb<true>, gi, bs, 0, sk, v);
     else hipLaunchKernelGGL(k_spike_comb<false>, gi, bs, 0, sk, v);
   }
-  const long long npair = (long long)v.nchunks * v.K;
-  const dim3 gp((unsigned)std::min<long long>((npair + 7) & ~7LL, e->grid_pair));
-  if (npair > 0) {
-    if (e->precision == SVGPFA_PRECISION_MIXED) {
-      if (full && !want_c) hipLaunchKernelGGL((k_spike<true, float, false>), gp, bs, 0, sk, v, C);
-      else if (full) hipLaunchKernelGGL((k_spike<true, float>), gp, bs, 0, sk, v, C);
-      else hipLaunchKernelGGL((k_spike<false, float>), gp, bs, 0, sk, v, C);
-    } else {
-      if (full && !want_c) hipLaunchKernelGGL((k_spike<true, double, false>), gp, bs, 0, sk, v, C);
-      else if (full) hipLaunchKernelGGL((k_spike<true>), gp, bs, 0, sk, v, C);
-      else hipLaunchKernelGGL((k_spike<false>), gp, bs, 0, sk, v, C);
-    }
-  }
+  launch_pair_pass(e, sk, full, want_c, C);
   // (combine folded into k_item_bwd's gather: the forked kernel is joined behind the pair kernel, which does not need it)
   if (!joined) (void)hipStreamWaitEvent(sk, e->ev_join, 0);
+}
+
+// The spike pass of small shards (svgpfa_engine::early) on the spike stream ss: the moment kernels first -- they need the
+// class table (made on this stream with the kernel build), C and the spikes, and run beside k_build_reg / k_prep / the
+// quadrature chain -- then, behind k_prep's event, the tail that needs a = Kzz^-1 m and W: the combine (unless k_item_bwd's
+// gather does it), the dC rows from the stored moments, the pair loop.
+static void launch_spike_early(svgpfa_engine* e, hipStream_t ss, bool full, bool want_c, const double* C) {
+  EngineView& v = e->v;
+  const dim3 bs(64), gi(v.R * v.K);
+  const dim3 gc((unsigned)std::min<long long>((long long)v.ntiles * v.K, e->grid_cls));
+  const bool tw = full && v.ntype[SV_PERIODIC] > 0;
+  const bool dc = full && want_c;
+  // two class kernels (time-weighted moments wanted and periodic latents present): side by side, the second on s_side3
+  hipStream_t s2 = tw ? e->s_side3 : ss;
+  if (tw) {
+    (void)hipEventRecord(e->ev_fork, ss);
+    (void)hipStreamWaitEvent(s2, e->ev_fork, 0);
+  }
+  if (dc) {
+    if (tw) hipLaunchKernelGGL((k_spike_cls<4, 2>), gc, bs, 0, ss, v, C, 1);
+    hipLaunchKernelGGL((k_spike_cls<2, 2>), gc, bs, 0, s2, v, C, 1);
+  } else {
+    if (tw) hipLaunchKernelGGL((k_spike_cls<4, 0>), gc, bs, 0, ss, v, C, 1);
+    hipLaunchKernelGGL((k_spike_cls<2, 0>), gc, bs, 0, s2, v, C, full ? 1 : 0);
+  }
+  if (tw) {
+    (void)hipEventRecord(e->ev_join, s2);
+    (void)hipStreamWaitEvent(ss, e->ev_join, 0);
+  }
+  (void)hipStreamWaitEvent(ss, e->ev_prep, 0);
+  if (dc) hipLaunchKernelGGL(k_spike_pre, gi, bs, 0, ss, v);     // W here, not in k_prep: that would have to wait for the class table
+  if (!v.comb_fold) {
+    if (full) hipLaunchKernelGGL(k_spike_comb<true>, gi, bs, 0, ss, v);
+    else hipLaunchKernelGGL(k_spike_comb<false>, gi, bs, 0, ss, v);
+  }
+  if (dc) hipLaunchKernelGGL(k_spike_dc, gc, bs, 0, ss, v, 1);
+  launch_pair_pass(e, ss, full, want_c, C);
 }
 
 static int check_ready(svgpfa_engine* e) {
@@ -864,10 +942,16 @@ static int enqueue_elbo(svgpfa_engine* e, const PtrTable& pt, const ElboPlan& pl
   const unsigned mask = pl.mask;
   int rc;
   if (!e->cls_valid) launch_classes(e);   // spikes set after the last kernel build
-  // the class path's W rides in k_prep when this evaluation's spike pass wants dC
-  const bool have_w = pl.run_spike && pl.full && (mask & 2u) && e->cls_on && v.ntiles > 0;
-  launch_prep(e, pt, have_w);
   hipStream_t sm = e->stream;
+  const bool early = e->early && pl.side && pl.run_spike;
+  // The spike stream's kernels overwrite what earlier evaluations' kernels read: they start behind those.  Right after a
+  // kernel build the stream is already ordered so (its k_spike_classes waited for the main stream at the build).
+  const bool fresh = e->cls_wait;
+  if (early && !fresh) HIPCHK(e, hipEventRecord(e->ev_e0, sm));
+  if (!early) await_classes(e);           // (k_prep's W rider and the spike pass read the table)
+  // the class path's W rides in k_prep when this evaluation's spike pass wants dC
+  const bool have_w = !early && pl.run_spike && pl.full && (mask & 2u) && e->cls_on && v.ntiles > 0;
+  launch_prep(e, pt, have_w);
   // Small shards (pl.side): every kernel is one under-filled round, so the quadrature chain (f64 MFMA: posterior stats ->
   // ELL term) runs on a side stream beside the spike pass.  The SPIKE pass stays on the main stream, in front of
   // k_item_bwd: it is the longer chain on such shards, and a wait for an event that completed long ago costs a few
@@ -881,7 +965,15 @@ static int enqueue_elbo(svgpfa_engine* e, const PtrTable& pt, const ElboPlan& pl
     HIPCHK(e, hipEventRecord(e->ev_quad, sq));
   }
   // ---- spike pass (fp64 VALU bound): needs only a = Kzz^-1 m (and W) from k_prep
-  if (pl.run_spike) {
+  if (early) {
+    hipStream_t ss = e->s_side2;
+    if (!fresh) HIPCHK(e, hipStreamWaitEvent(ss, e->ev_e0, 0));
+    e->cls_wait = false;                  // k_item_bwd waits for this pass, which follows the class table on its stream
+    const int evp = timing_begin(e, 0, ss);
+    launch_spike_early(e, ss, pl.full, (mask & 2u) != 0, C);
+    timing_end(e, evp, ss);
+    HIPCHK(e, hipEventRecord(e->ev_spk, ss));
+  } else if (pl.run_spike) {
     const int evp = timing_begin(e, 0, sm);
     launch_spike_pass(e, sm, pl.full, (mask & 2u) != 0, C, have_w, pl.side, pl.side ? e->ev_prep : nullptr);
     timing_end(e, evp, sm);
@@ -891,6 +983,7 @@ static int enqueue_elbo(svgpfa_engine* e, const PtrTable& pt, const ElboPlan& pl
     if ((rc = launch_quad_ell(e, sm, C, d, (mask & 2u) ? 1 : 0, pl.want_lat ? 1 : 0))) return rc;
   } else {
     HIPCHK(e, hipStreamWaitEvent(sm, e->ev_quad, 0));     // join the quadrature chain
+    if (early) HIPCHK(e, hipStreamWaitEvent(sm, e->ev_spk, 0));
   }
   // ---- per-item adjoints + backward + the fixed-order cross-trial reductions in one kernel
   const int evb = timing_begin(e, 1, sm);
@@ -1050,6 +1143,7 @@ int svgpfa_freeze_stats(svgpfa_engine* e, const double* const* mean, const doubl
   PtrTable pt;
   if ((rc = fill_ptrs(e, pt, mean, cholvec, nullptr, nullptr, nullptr, 0))) return rc;
   if (!e->cls_valid) launch_classes(e);
+  await_classes(e);
   launch_prep(e, pt);
   if ((rc = launch_times_quad(e, e->stream))) return rc;
   // the per-neuron sums of the spike means are the spike part of dC, which the spike-time pass makes (cosine series:
@@ -1101,6 +1195,7 @@ int svgpfa_latent_stats_backward(svgpfa_engine* e, const double* const* mean, co
     }
   }
   const unsigned m2 = mask | SV_MASK_STATS;
+  await_classes(e);                       // the gather reads ser
   if (mask & (4u | 8u)) {
     DISPATCH_NT(e->NT, hipLaunchKernelGGL((k_item_bwd<NT_, true>), dim3(v.R * v.K), dim3(64 * e->tile_nw),
                                           lds_item_bwd(NT_, e->tile_nw, true), e->stream, v, pt, m2, (const double*)nullptr,

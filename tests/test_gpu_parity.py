@@ -684,3 +684,49 @@ def test_graph_replay_is_bit_identical_to_plain_launches(monkeypatch, kernels):
             for x, y in zip(a, b):
                 assert torch.equal(x, y)
     assert float(seqs["0"][0][0][0]) != float(seqs["0"][1][0][0])
+
+
+@pytest.mark.parametrize("case", [
+    dict(R=4, N=15, K=3, M=[12, 16, 9], kernels="mix", seed=21, n_quad=60, rate=60.0),      # whole rows and cut halves
+    dict(R=2, N=3, K=4, M=[10, 12, 9, 14], kernels="mix", seed=22, n_quad=40, rate=1300.0),   # oversize segments: split rows / chunks
+    dict(R=3, N=70, K=2, M=[20, 24], kernels="rbf", seed=23, n_quad=40, rate=9.0),            # two tiles per trial, short rows
+    dict(R=5, N=40, K=6, M=[9, 30, 17, 32, 12, 25], kernels="mix", seed=24, n_quad=50, rate=30.0),
+], ids=["halves", "oversize", "two-tiles", "six-latents"])
+def test_early_moments_equal_the_fused_pass(case, monkeypatch):
+    """Small shards (trials x latents <= 2048) run the class path's moment kernels on a stream of their own, beside the
+    kernel build and k_prep, store the rows' moments and make the dC rows from them once a = Kzz^-1 m exists (k_spike_dc);
+    SVGPFA_EARLY=0 keeps the fused pass of large problems.  Same bits for every gradient mask, with the parameters changing
+    between evaluations, with and without a kernel build in between, and with the spike sums reused under a token."""
+    prob = synthetic.make_problem(jitter=1.0, **case)
+    seqs = {}
+    for mode in ("0", "1"):
+        monkeypatch.setenv("SVGPFA_EARLY", mode)
+        eng, P = _engine(prob)
+        seq = []
+        for mask in (15, 3, 12, 1, 0):
+            shared = torch.empty(eng.shared_len, dtype=torch.float64, device=P["C"].device)
+            grads = eng.alloc_grads(mask)
+            for it in range(4):
+                P["mean"][0].mul_(1.0 + 0.01 * it)
+                P["C"].mul_(1.0 - 0.002 * it)
+                if it == 2:
+                    P["Z"][1].add_(0.003)
+                    P["theta"][0].mul_(1.01)
+                if it >= 2:
+                    eng.build_kernels(P["Z"], P["theta"])
+                eng.elbo(P["mean"], P["cholVecs"], P["C"], P["d"], mask, out=shared, grads=grads)
+                eng.sync()
+                seq.append([shared.clone()] + [t.clone() for g in grads if g is not None for t in g])
+        shared = torch.empty(eng.shared_len, dtype=torch.float64, device=P["C"].device)
+        eng.set_embedding_token(5)
+        for it in range(3):
+            P["mean"][1].mul_(0.99)
+            eng.elbo(P["mean"], P["cholVecs"], P["C"], P["d"], 0, out=shared, grads=(None, None, None))
+            eng.sync()
+            seq.append([shared.clone()])
+        seqs[mode] = seq
+        eng.close()
+    for a, b in zip(seqs["0"], seqs["1"]):
+        for x, y in zip(a, b):
+            assert torch.equal(x, y)
+    assert float(seqs["0"][0][0][0]) != float(seqs["0"][1][0][0])
