@@ -239,25 +239,48 @@ __global__ __launch_bounds__(256) void k_fin_items(EngineView ev, unsigned mask,
 #else
 #define SV_GATHER_ATTR __forceinline__
 #endif
+// The gather's first loads, requested at the top of the kernel IN FRONT of the factor staging's loads (every address is
+// valid whatever path the item takes): behind the staging, where they used to be issued, the item's path flag, then the
+// sums it points to, then the division were three memory latencies in a row (6 us of a 64-us block at the north-star size).
+struct GatherPre {
+  int ser, c0, c1;
+  double p0t, p1t, tt0, tt1, cd;
+};
+__device__ __forceinline__ GatherPre gather_issue(const EngineView& ev, const LatentMeta& m, const LatentPtrs& pt, int r,
+                                                  int k, unsigned mask, bool want_zt) {
+  const int tid = threadIdx.x, M = m.M;
+  GatherPre g;
+  g.ser = ev.ser[r * ev.K + k];
+  g.c0 = ev.chunk_first[r];
+  g.c1 = ev.chunk_first[r + 1];
+  const long long o = (long long)r * ev.sumM + m.colM + (tid < M ? tid : 0);
+  g.p0t = ev.P0t[o];
+  g.p1t = want_zt ? ev.P1t[o] : 0.0;
+  g.tt0 = ev.Tt[((long long)r * ev.K + k) * 2 + 0];
+  g.tt1 = ev.Tt[((long long)r * ev.K + k) * 2 + 1];
+  g.cd = ((mask & 1u) && tid < M) ? pt.cholvec[(long long)r * m.P + tid * (tid + 1) / 2 + tid] : 1.0;
+  return g;
+}
+
 template <int MP>
 __device__ SV_GATHER_ATTR void gather_item_inputs(const EngineView& ev, const LatentMeta& m, const LatentPtrs& pt, int r,
-                                                   int k, unsigned mask, bool want_zt, const KPar& kp, double* gs,
-                                                   double* p1l, double* cvd, double* gt, double* tpl, double* scr) {
+                                                   int k, unsigned mask, bool want_zt, const KPar& kp, const GatherPre& pre,
+                                                   double* gs, double* p1l, double* cvd, double* gt, double* tpl,
+                                                   double* scr) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, NTHB = blockDim.x, NWB = NTHB >> 6, M = m.M;
   const double s2 = kp.s2;
   const bool stats = (mask & SV_MASK_STATS) != 0;
-  const bool cls = !stats && ev.ser[r * ev.K + k] != 0;   // block-uniform
-  const int c0 = ev.chunk_first[r], c1 = (stats || cls) ? c0 : ev.chunk_first[r + 1];
+  const bool cls = !stats && pre.ser != 0;   // block-uniform
+  const int c0 = pre.c0, c1 = (stats || cls) ? c0 : pre.c1;
   double p0 = 0.0, p1sum = 0.0, t0acc = 0.0, t1acc = 0.0;
   if (cls && !ev.comb_fold) {                 // k_spike_comb left the item's sums per trial
     if (tid < M) {
-      const long long o = (long long)r * ev.sumM + m.colM + tid;
-      p0 = ev.P0t[o];
-      p1sum = want_zt ? ev.P1t[o] : 0.0;
+      p0 = pre.p0t;
+      p1sum = pre.p1t;
     }
     if (wave == 0 && lane == 0 && want_zt) {
-      t0acc = ev.Tt[((long long)r * ev.K + k) * 2 + 0];     // lane 0 carries the whole sum: the wave tree below adds zeros
-      t1acc = ev.Tt[((long long)r * ev.K + k) * 2 + 1];
+      t0acc = pre.tt0;                        // lane 0 carries the whole sum: the wave tree below adds zeros
+      t1acc = pre.tt1;
     }
   } else if (cls) {
     const SpikeItem it = ev.sitem[r * ev.K + k];
@@ -327,7 +350,7 @@ __device__ SV_GATHER_ATTR void gather_item_inputs(const EngineView& ev, const La
         p0 += ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
         p1sum += ((w[0] + w[1]) + (w[2] + w[3])) + ((w[4] + w[5]) + (w[6] + w[7]));
       }
-      if (mask & 1u) dinv = 1.0 / pt.cholvec[(long long)r * m.P + tid * (tid + 1) / 2 + tid];
+      if (mask & 1u) dinv = 1.0 / pre.cd;
     }
     gs[tid] = s2 * p0;
     p1l[tid] = p1sum;
@@ -401,6 +424,7 @@ __device__ __forceinline__ void item_bwd_body(const EngineView& ev, const int r,
   const bool want_zt = (mask & (4u | 8u)) != 0;
   long long ck[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   SV_CK(0);
+  const GatherPre gpre = gather_issue(ev, m, pt, r, k, mask, want_zt);
 
   if (want_lat) {
     load_factors<NT>(ev, m, r, Li, Vl, ul, zl, true);
@@ -414,7 +438,7 @@ __device__ __forceinline__ void item_bwd_body(const EngineView& ev, const int r,
   // kernel at the north-star size).  (Round 2 kept it between the phases above M = 32 after an intermediate version
   // returned wrong sums there: a compiler defect)
   SV_CK(1);
-  gather_item_inputs<MP>(ev, m, pt, r, k, mask, want_zt, p, gs, p1l, cvd, gt, tpl, S);
+  gather_item_inputs<MP>(ev, m, pt, r, k, mask, want_zt, p, gpre, gs, p1l, cvd, gt, tpl, S);
   SV_CK(2);
   if (SV_BWD_STOP == 9) return;      // after the staging of the factors and the gather
 
@@ -593,6 +617,17 @@ __device__ __forceinline__ void item_bwd_body(const EngineView& ev, const int r,
     }
     }   // node segments
     SV_CK(9);
+    // Vt for phase 2 where D took its buffer: requested HERE, ahead of the reductions (its memory latency was exposed behind
+    // them), stored once the last wave is done with D
+    constexpr int VPF = (FULL && !DSEP) ? (MP * MP + 127) / 128 : 1;      // values per thread at >= 128 threads
+    double vpf[VPF];
+    if (FULL && !DSEP) {
+#pragma unroll
+      for (int u = 0; u < VPF; ++u) {
+        const int e = tid + u * NTHB, i = e / MP, j = e % MP;
+        vpf[u] = (e < MP * MP && i < M && j <= i) ? ev.Vt[base + i * M + j] : 0.0;
+      }
+    }
 
     // ---- reductions: over the 16 time lanes, then over the wavefronts (fixed order)
 #pragma unroll
@@ -663,7 +698,13 @@ __device__ __forceinline__ void item_bwd_body(const EngineView& ev, const int r,
     }
     // Vt for phase 2: staged again only where D took its buffer.  Gt's padding rows / columns are exact zeros: they are
     // sums of products with zero-padded rows of Linv
-    if (FULL && !DSEP) stage_matrix<NT>(Vl, ev.Vt + base, M, tid, NTHB);
+    if (FULL && !DSEP) {
+#pragma unroll
+      for (int u = 0; u < VPF; ++u) {
+        const int e = tid + u * NTHB, i = e / MP, j = e % MP;
+        if (e < MP * MP) Vl[i * LD + j] = vpf[u];
+      }
+    }
   }
 
   SV_CK(10);

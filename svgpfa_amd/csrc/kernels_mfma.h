@@ -82,6 +82,40 @@ __device__ __forceinline__ void load_factors(const EngineView& ev, const LatentM
   const int M = m.M, tid = threadIdx.x;
   const long long base = m.offMM + (long long)r * M * M;
   const long long vbase = m.offM + (long long)r * M;
+  if (NT <= 2 && want_v) {
+    // both factors and the two vectors requested before anything is stored: ONE exposed memory latency instead of one
+    // per batch of four loads (M <= 32: 8 + 8 + 2 values per thread at 128 threads; at M = 64 the registers this takes
+    // cost more than the latency, see stage_matrix)
+    constexpr int LD = MP + 2;
+    const int nth = (int)blockDim.x;
+    const double* sl = ev.Linv + base;
+    const double* sv = ev.Vt + base;
+    const double uv = (tid < M) ? ev.ut[vbase + tid] : 0.0;
+    const double zv = (tid < M) ? ev.Zs[vbase + tid] : 0.0;
+    for (int e0 = tid; e0 < MP * MP; e0 += 8 * nth) {
+      double a[8], b[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int e = e0 + u * nth, i = e / MP, j = e % MP;
+        const bool ok = e < MP * MP && i < M && j <= i;
+        a[u] = ok ? sl[i * M + j] : 0.0;
+        b[u] = ok ? sv[i * M + j] : 0.0;
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int e = e0 + u * nth, i = e / MP, j = e % MP;
+        if (e < MP * MP) {
+          Li[i * LD + j] = a[u];
+          Vl[i * LD + j] = b[u];
+        }
+      }
+    }
+    if (tid < MP) {
+      ul[tid] = uv;
+      zl[tid] = zv;
+    }
+    return;
+  }
   stage_matrix<NT>(Li, ev.Linv + base, M, tid, (int)blockDim.x);
   if (want_v) stage_matrix<NT>(Vl, ev.Vt + base, M, tid, (int)blockDim.x);
   if (tid < MP) {
