@@ -12,6 +12,12 @@
 // MP = 16 NT >= max_k M_k; matrices are zero padded to MP, LDS rows padded to LD = MP + 2 doubles
 // (A-fragment reads are then bank-conflict free: lane -> (l & 15) * LD + (l >> 4)).
 #pragma once
+// Waves per block of k_times_fwd_mfma (SVGPFA_TIMES_NW up to SV_TIMES_MAXTH / 64; experiment builds raise the bound).
+// Measured at cfg3 (us): 2 waves 93.3, 3 95.9, 4 92.2; with a 1024-thread build 5 waves 125, 7 118, 13 (one tile each)
+// 149.  The kernel runs at ~85 % of its MFMA + VALU issue time: how the 13 tiles are dealt over the waves is not its limit.
+#ifndef SV_TIMES_MAXTH
+#define SV_TIMES_MAXTH 256
+#endif
 #include "engine_common.h"
 #include "spike_cls_common.h"
 
@@ -225,7 +231,7 @@ __device__ __forceinline__ void times_fwd_body(const EngineView& ev, const int r
 
 // One launch over all (trial, latent) items; the covariance type is resolved per block (wave-uniform branch).
 template <int NT>
-__global__ __launch_bounds__(256) void k_times_fwd_mfma(EngineView ev, const double* times,
+__global__ __launch_bounds__(SV_TIMES_MAXTH) void k_times_fwd_mfma(EngineView ev, const double* times,
                                                         const long long* toff, int nper, double* mu_out,
                                                         double* var_out, long long os_r, long long os_t,
                                                         long long os_k, int want_var) {

@@ -33,6 +33,7 @@ struct svgpfa_engine {
   int ell_parts = 0, KKT = 1;  // ell_parts > 0: MFMA GEMM form of the quadrature term
   int ell_lc[2] = {0, 0};      // looped tiles resident in LDS per role (fewer than all: streamed in chunks)
   int ell_nw = 4;              // waves per block of the ELL kernels
+  int times_nw = 4;            // waves per block of k_times_fwd (SVGPFA_TIMES_NW, up to SV_TIMES_MAXTH / 64)
   int tile_nw = 4;             // waves per block of k_item_bwd: 2 when R K >= 512 and M <= 32 (13 tiles of Q = 200 split
                                // 7 + 6 instead of 4 + 3 + 3 + 3, and four blocks instead of two per CU: cfg3 226 -> 203 us,
                                // its 8-way shard 0.200 -> 0.186 ms per step), else 4 (shorter per-block latency).
@@ -257,6 +258,7 @@ int svgpfa_create(const svgpfa_dims* d, int device, svgpfa_engine** out) {
   e->ell_nw = 4;
   if (getenv("SVGPFA_ELL_NW")) e->ell_nw = std::min(8, std::max(1, atoi(getenv("SVGPFA_ELL_NW"))));
   e->tile_nw = ((long long)v.R * v.K >= 512 && e->NT <= 2) ? 2 : 4;
+  if (getenv("SVGPFA_TIMES_NW")) e->times_nw = std::min(SV_TIMES_MAXTH / 64, std::max(1, atoi(getenv("SVGPFA_TIMES_NW"))));
   if (getenv("SVGPFA_TILE_NW")) {
     const int nw = atoi(getenv("SVGPFA_TILE_NW"));
     e->tile_nw = (nw >= 2 && nw <= 4 && nw >= e->NT) ? nw : 4;
@@ -753,7 +755,7 @@ static int launch_quad_ell(svgpfa_engine* e, hipStream_t st, const double* C, co
 static int launch_times(svgpfa_engine* e, hipStream_t st, const double* times, const long long* toff, int nper, double* mu,
                         double* var, long long os_r, long long os_t, long long os_k, int want_var) {
   EngineView& v = e->v;
-  DISPATCH_NT(e->NT, hipLaunchKernelGGL((k_times_fwd_mfma<NT_>), dim3(v.R * v.K), dim3(256),
+  DISPATCH_NT(e->NT, hipLaunchKernelGGL((k_times_fwd_mfma<NT_>), dim3(v.R * v.K), dim3(64 * e->times_nw),
                                         lds_times_mfma(NT_), st, v, times, toff, nper, mu, var, os_r, os_t, os_k,
                                         want_var));
   HIPCHK(e, hipGetLastError());

@@ -466,7 +466,11 @@ class ShardedLBFGS:
             return torch.as_tensor(orig_loss)
 
         d, t = st.get("d"), st.get("t")
-        Sb, Yb, m = st.get("Sb"), st.get("Yb"), st.get("m", 0)      # history rows 0..m-1 (oldest first), row m: candidate
+        # History: a window of m rows (oldest first) that SLIDES through buffers of up to 2 history_size + 1 rows, the
+        # candidate pair behind it.  Dropping the oldest pair moves the window's start by one row; only when the window
+        # reaches the end of the buffer is it copied back to the front -- once per history_size iterations instead of a
+        # shift of the whole history (2 m n doubles moved plus as many of temporary) every iteration.
+        Sb, Yb, m, w0 = st.get("Sb"), st.get("Yb"), st.get("m", 0), st.get("w0", 0)
         SY, YY = st.get("SY"), st.get("YY")
         H = st.get("H", 1.0)
         prev_g, prev_loss = st.get("prev_g"), st.get("prev_loss")
@@ -478,26 +482,31 @@ class ShardedLBFGS:
             n_iter += 1
             st["n_iter"] += 1
             if st["n_iter"] == 1:
-                m = 0
+                m = w0 = 0
                 SY = YY = np.zeros((0, 0))
                 H = 1.0
                 gtd = -gg
                 coef = np.array([H])
             else:
-                if Sb is None or m + 1 > Sb.shape[0]:                 # grow the history buffers geometrically
-                    cap = min(self.history_size, max(8, 2 * m)) + 1
-                    nS, nY = x.new_empty(cap, x.numel()), x.new_empty(cap, x.numel())
-                    if m:
-                        nS[:m], nY[:m] = Sb[:m], Yb[:m]
-                    Sb, Yb = nS, nY
-                part = vec.pair_dots(g, prev_g, d, t, Sb, Yb, m)      # writes the candidate pair into row m
+                if Sb is None or w0 + m + 1 > Sb.shape[0]:
+                    full = 2 * self.history_size + 1
+                    if Sb is None or Sb.shape[0] < full:              # grow the history buffers geometrically
+                        cap = min(full, max(8, 2 * (m + 1)))
+                        nS, nY = x.new_empty(cap, x.numel()), x.new_empty(cap, x.numel())
+                        if m:
+                            nS[:m], nY[:m] = Sb[w0:w0 + m], Yb[w0:w0 + m]
+                        Sb, Yb = nS, nY
+                    else:                                             # window at the end: back to the front (w0 >= m here)
+                        Sb[:m], Yb[:m] = Sb[w0:w0 + m], Yb[w0:w0 + m]
+                    w0 = 0
+                Sw, Yw = Sb[w0:], Yb[w0:]
+                part = vec.pair_dots(g, prev_g, d, t, Sw, Yw, m)      # writes the candidate pair into the window's row m
                 tot = self._read(part, part.numel())                  # the one host sync of the iteration
                 ys, yy, gg, sg, yg = (float(v) for v in tot[:5])
                 S_y, s_Y, Y_y, S_g, Y_g = (tot[5 + i * m:5 + (i + 1) * m] for i in range(5))
                 if ys > 1e-10:
-                    if m == self.history_size:       # drop the oldest pair (the candidate moves down with the rest)
-                        Sb[:m] = Sb[1:m + 1].clone()
-                        Yb[:m] = Yb[1:m + 1].clone()
+                    if m == self.history_size:       # drop the oldest pair: the window starts one row later
+                        w0 += 1
                         SY, YY = SY[1:, 1:], YY[1:, 1:]
                         S_y, s_Y, Y_y, S_g, Y_g = S_y[1:], s_Y[1:], Y_y[1:], S_g[1:], Y_g[1:]
                         m -= 1
@@ -511,7 +520,8 @@ class ShardedLBFGS:
                     m += 1
                 al, be, gtd = _two_loop(SY, YY, S_g, Y_g, H, gg, m)
                 coef = np.concatenate([-H * al, al - be, [H]])
-            dmax_t = vec.direction(g, Sb, Yb, m, coef, d, x, x0)          # d, x0 = x, max |d| (stays on the device)
+            dmax_t = vec.direction(g, Sb[w0:] if Sb is not None else None, Yb[w0:] if Yb is not None else None, m, coef, d,
+                                   x, x0)                                  # d, x0 = x, max |d| (stays on the device)
             prev_g = g
             prev_loss = loss
             t = min(1.0, 1.0 / gabs) * self.lr if st["n_iter"] == 1 else self.lr
@@ -555,7 +565,7 @@ class ShardedLBFGS:
             if abs(loss - prev_loss) < tc:
                 break
 
-        st.update(d=d, t=t, Sb=Sb, Yb=Yb, m=m, SY=SY, YY=YY, H=H, prev_g=prev_g, prev_loss=prev_loss, x0=x0)
+        st.update(d=d, t=t, Sb=Sb, Yb=Yb, m=m, w0=w0, SY=SY, YY=YY, H=H, prev_g=prev_g, prev_loss=prev_loss, x0=x0)
         return torch.as_tensor(orig_loss)
 
     # ------------------------------------------------------------------ flat mode, vectors on the host
