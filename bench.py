@@ -510,8 +510,8 @@ def main():
                          "traffic_source": ("profiles/%s @ csrc %s" % (traffic[1], traffic[3])) if traffic
                          else "none: no committed PMC digest was taken on this device code (csrc %s)" % kernel_source_sha(),
                          "algorithmic_bytes_per_launch": work.get("bytes_spike"),
-                         "kernel": "spike pass = k_spike_pre + k_spike_cls<4> + k_spike_cls<2> + k_spike_comb (class path, fp64) "
-                                   "+ k_spike (pair by pair%s)" % (", fp32" if mixed else ""),
+                         "kernel": "spike pass = k_spike_cls<4> + k_spike_cls<2> + k_spike_comb (class path, fp64; its weights W "
+                                   "ride in k_prep) + k_spike (pair by pair%s)" % (", fp32" if mixed else ""),
                          "kernel_avg_ms": spike_avg_ms, "kernel_launches": launches,
                          "executed_fp64_flops_per_launch": exec_flops,
                          "class_path_flops_per_launch": cls_flops, "pair_loop_flops_per_launch": pair_flops,
