@@ -35,26 +35,17 @@
 #include "spike_cls_common.h"
 
 // ------------------------------------------------------------------------------------------------ k_spike_classes
-// The class table and the per-trial entries in a launch of their own: for the engine's kernel SNAPSHOT when the spikes
-// arrived after the kernel build (snap = 0; else the class blocks of k_build_reg made them), or from the caller's Z / theta
-// on the spike stream of small shards, beside the kernel build (snap = 1).  grid = ceil(R / 4) blocks of 256 threads,
-// every block rebuilds the (tiny) table in LDS, one wavefront per trial then fills the per-trial entries.
-__global__ __launch_bounds__(256) void k_spike_classes(EngineView ev, int snap, SnapTable st) {
+// The class table and the per-trial entries for the engine's kernel SNAPSHOT, when the spikes arrived after the kernel
+// build (else the class blocks of k_build_reg made them): grid = ceil(R / 4) blocks of 256 threads, every block rebuilds
+// the (tiny) table in LDS, one wavefront per trial then fills the per-trial entries.
+__global__ __launch_bounds__(256) void k_spike_classes(EngineView ev) {
   __shared__ SpikeClassScratch cs;
-  __shared__ double fws[SV_MAX_K * (SV_FH + 3)];
   const int wave = threadIdx.x >> 6, R = ev.R;
   const int r = blockIdx.x * 4 + wave;
-  // (two call sites each: behind a select between &st and nullptr the compiler copies the table to scratch memory)
-  if (wave == 0) {
-    if (snap) spike_class_table(ev, cs, &st, fws);
-    else spike_class_table(ev, cs, nullptr, nullptr);
-  }
+  if (wave == 0) spike_class_table(ev, cs, nullptr, nullptr);
   __syncthreads();
   if (blockIdx.x == 0 && wave == 1) spike_class_store(ev, cs);
-  if (r < R) {
-    if (snap) spike_class_trial(ev, cs, &st, r);
-    else spike_class_trial(ev, cs, nullptr, r);
-  }
+  if (r < R) spike_class_trial(ev, cs, nullptr, r);
 }
 
 // ------------------------------------------------------------------------------------------------ k_spike_pre

@@ -63,13 +63,13 @@ struct svgpfa_engine {
   int side_stream = -1;
   hipStream_t s_side = nullptr, s_side2 = nullptr, s_side3 = nullptr;   // quadrature chain / spike pass on small shards
   hipEvent_t ev_prep = nullptr, ev_quad = nullptr, ev_fork = nullptr, ev_join = nullptr;
-  hipEvent_t ev_b0 = nullptr, ev_cls = nullptr, ev_e0 = nullptr, ev_spk = nullptr;
-  // Small shards with the class path (SVGPFA_EARLY=0 turns it off): the spike MOMENTS need the spikes, C and the kernels'
-  // frequencies, nothing of Kzz -- so the class table (beside k_build_reg, from the caller's Z / theta) and the moment
-  // kernels (beside k_build_reg / k_prep / the quadrature chain) run on a stream of their own, store the rows' moments,
-  // and only the small tail that needs a = Kzz^-1 m (dC rows from the stored moments, pair loop) waits for k_prep.
+  hipEvent_t ev_b0 = nullptr, ev_e0 = nullptr, ev_spk = nullptr;
+  // Small shards with the class path (SVGPFA_EARLY=0 turns it off): the spike MOMENTS need the spikes, C and the class table
+  // (a rider of k_build_reg), nothing of k_prep -- so the moment kernels run on a stream of their own from the end of the
+  // kernel build on, beside k_prep and the quadrature chain, store the rows' moments, and only the small tail that needs
+  // a = Kzz^-1 m (dC rows from the stored moments, pair loop) waits for k_prep.
   bool early = false;
-  bool cls_wait = false;                        // the class table of the current build is (was) made on the spike stream
+  bool fresh_build = false;                     // ev_b0 (end of the last kernel build) has not been waited for by the spike stream
   bool fork_always = false;                     // SVGPFA_FORK=1: the two class kernels on two streams at every size (experiment)
   bool cls_on = true;                           // false: problem too small for the class path's extra launches (set_spikes)
   double series_min_pairs = 1e7;                // SVGPFA_SERIES_MIN_PAIRS: fewest (spike, inducing point) pairs for the class path
@@ -325,7 +325,7 @@ int svgpfa_create(const svgpfa_dims* d, int device, svgpfa_engine** out) {
     e->grid_cls = std::max(8, prop.multiProcessorCount * std::max(1, bc));
     e->grid_pair = std::max(8, (prop.multiProcessorCount * std::max(1, bp)) & ~7);
   }
-  for (hipEvent_t* ev : {&e->ev_prep, &e->ev_quad, &e->ev_fork, &e->ev_join, &e->ev_b0, &e->ev_cls, &e->ev_e0, &e->ev_spk})
+  for (hipEvent_t* ev : {&e->ev_prep, &e->ev_quad, &e->ev_fork, &e->ev_join, &e->ev_b0, &e->ev_e0, &e->ev_spk})
     HIPCHK(e, hipEventCreateWithFlags(ev, hipEventDisableTiming));
 
   int rc = 0;
@@ -354,7 +354,7 @@ void svgpfa_destroy(svgpfa_engine* e) {
   drop_graphs(e);
   for (hipStream_t st : {e->s_side, e->s_side2, e->s_side3, e->s_cap})
     if (st) (void)hipStreamDestroy(st);
-  for (hipEvent_t ev : {e->ev_prep, e->ev_quad, e->ev_fork, e->ev_join, e->ev_b0, e->ev_cls, e->ev_e0, e->ev_spk})
+  for (hipEvent_t ev : {e->ev_prep, e->ev_quad, e->ev_fork, e->ev_join, e->ev_b0, e->ev_e0, e->ev_spk})
     if (ev) (void)hipEventDestroy(ev);
   for (auto& pr : e->ev_pool) {
     (void)hipEventDestroy(pr.first);
@@ -656,11 +656,8 @@ static void launch_build(svgpfa_engine* e, int write_aux, const SnapTable* snap,
 static bool graph_default(const svgpfa_engine* e) { return !e->timing && e->graph_mode == 1; }
 
 static void launch_classes(svgpfa_engine* e) {
-  SnapTable none;
-  memset(&none, 0, sizeof none);
-  hipLaunchKernelGGL(k_spike_classes, dim3((e->v.R + 3) / 4), dim3(256), 0, e->stream, e->v, 0, none);
+  hipLaunchKernelGGL(k_spike_classes, dim3((e->v.R + 3) / 4), dim3(256), 0, e->stream, e->v);
   e->cls_valid = true;
-  e->cls_wait = false;
 }
 
 int svgpfa_build_kernels(svgpfa_engine* e, const double* const* Z, const double* const* theta) {
@@ -675,18 +672,11 @@ int svgpfa_build_kernels(svgpfa_engine* e, const double* const* Z, const double*
     st.theta[k] = theta[k];
   }
   const bool cls = e->have_spikes && e->cls_on;
-  if (cls && e->early) {
-    // the class table on the spike stream, from the caller's tensors, beside the build (behind everything enqueued so far:
-    // the previous evaluation's kernels read the table)
+  launch_build(e, 0, &st, cls);
+  if (cls && e->early) {     // the spike stream's moment kernels of the next evaluation start here (class table ready)
     HIPCHK(e, hipEventRecord(e->ev_b0, e->stream));
-    HIPCHK(e, hipStreamWaitEvent(e->s_side2, e->ev_b0, 0));
-    hipLaunchKernelGGL(k_spike_classes, dim3((v.R + 3) / 4), dim3(256), 0, e->s_side2, v, 1, st);
-    HIPCHK(e, hipEventRecord(e->ev_cls, e->s_side2));
-    e->cls_wait = true;
-  } else {
-    e->cls_wait = false;
+    e->fresh_build = true;
   }
-  launch_build(e, 0, &st, cls && !e->early);
   e->aux_valid = false;
   e->p0_token = 0;
   e->cls_valid = cls || !e->cls_on;
@@ -812,13 +802,6 @@ static void timing_end(svgpfa_engine* e, int idx, hipStream_t st) {
   if (idx >= 0) (void)hipEventRecord(e->ev_pool[idx].second, st);
 }
 
-// Readers of the class table on the main stream wait (once) for the spike stream's k_spike_classes of the current build.
-static void await_classes(svgpfa_engine* e) {
-  if (!e->cls_wait) return;
-  (void)hipStreamWaitEvent(e->stream, e->ev_cls, 0);
-  e->cls_wait = false;
-}
-
 // pair-by-pair pass over the (chunk, latent) items the class path does not serve (early exit per trial when it serves all)
 static void launch_pair_pass(svgpfa_engine* e, hipStream_t sk, bool full, bool want_c, const double* C) {
   EngineView& v = e->v;
@@ -890,9 +873,9 @@ static void launch_spike_pass(svgpfa_engine* e, hipStream_t sk, bool full, bool 
 }
 
 // The spike pass of small shards (svgpfa_engine::early) on the spike stream ss: the moment kernels first -- they need the
-// class table (made on this stream with the kernel build), C and the spikes, and run beside k_build_reg / k_prep / the
-// quadrature chain -- then, behind k_prep's event, the tail that needs a = Kzz^-1 m and W: the combine (unless k_item_bwd's
-// gather does it), the dC rows from the stored moments, the pair loop.
+// class table (k_build_reg's riders), C and the spikes, and run beside k_prep and the quadrature chain -- then, behind
+// k_prep's event, the tail that needs a = Kzz^-1 m and W (k_prep's rider): the combine (unless k_item_bwd's gather does
+// it), the dC rows from the stored moments, the pair loop.
 static void launch_spike_early(svgpfa_engine* e, hipStream_t ss, bool full, bool want_c, const double* C) {
   EngineView& v = e->v;
   const dim3 bs(64), gi(v.R * v.K);
@@ -917,7 +900,6 @@ static void launch_spike_early(svgpfa_engine* e, hipStream_t ss, bool full, bool
     (void)hipStreamWaitEvent(ss, e->ev_join, 0);
   }
   (void)hipStreamWaitEvent(ss, e->ev_prep, 0);
-  if (dc) hipLaunchKernelGGL(k_spike_pre, gi, bs, 0, ss, v);     // W here, not in k_prep: that would have to wait for the class table
   if (!v.comb_fold) {
     if (full) hipLaunchKernelGGL(k_spike_comb<true>, gi, bs, 0, ss, v);
     else hipLaunchKernelGGL(k_spike_comb<false>, gi, bs, 0, ss, v);
@@ -946,13 +928,12 @@ static int enqueue_elbo(svgpfa_engine* e, const PtrTable& pt, const ElboPlan& pl
   if (!e->cls_valid) launch_classes(e);   // spikes set after the last kernel build
   hipStream_t sm = e->stream;
   const bool early = e->early && pl.side && pl.run_spike;
-  // The spike stream's kernels overwrite what earlier evaluations' kernels read: they start behind those.  Right after a
-  // kernel build the stream is already ordered so (its k_spike_classes waited for the main stream at the build).
-  const bool fresh = e->cls_wait;
+  // The spike stream's kernels overwrite what earlier evaluations' kernels read, and read the class table: they start
+  // behind the last kernel build's event, or (no build since the last evaluation) behind what the main stream holds now.
+  const bool fresh = e->fresh_build;
   if (early && !fresh) HIPCHK(e, hipEventRecord(e->ev_e0, sm));
-  if (!early) await_classes(e);           // (k_prep's W rider and the spike pass read the table)
   // the class path's W rides in k_prep when this evaluation's spike pass wants dC
-  const bool have_w = !early && pl.run_spike && pl.full && (mask & 2u) && e->cls_on && v.ntiles > 0;
+  const bool have_w = pl.run_spike && pl.full && (mask & 2u) && e->cls_on && v.ntiles > 0;
   launch_prep(e, pt, have_w);
   // Small shards (pl.side): every kernel is one under-filled round, so the quadrature chain (f64 MFMA: posterior stats ->
   // ELL term) runs on a side stream beside the spike pass.  The SPIKE pass stays on the main stream, in front of
@@ -969,8 +950,8 @@ static int enqueue_elbo(svgpfa_engine* e, const PtrTable& pt, const ElboPlan& pl
   // ---- spike pass (fp64 VALU bound): needs only a = Kzz^-1 m (and W) from k_prep
   if (early) {
     hipStream_t ss = e->s_side2;
-    if (!fresh) HIPCHK(e, hipStreamWaitEvent(ss, e->ev_e0, 0));
-    e->cls_wait = false;                  // k_item_bwd waits for this pass, which follows the class table on its stream
+    HIPCHK(e, hipStreamWaitEvent(ss, fresh ? e->ev_b0 : e->ev_e0, 0));
+    e->fresh_build = false;
     const int evp = timing_begin(e, 0, ss);
     launch_spike_early(e, ss, pl.full, (mask & 2u) != 0, C);
     timing_end(e, evp, ss);
@@ -1145,7 +1126,6 @@ int svgpfa_freeze_stats(svgpfa_engine* e, const double* const* mean, const doubl
   PtrTable pt;
   if ((rc = fill_ptrs(e, pt, mean, cholvec, nullptr, nullptr, nullptr, 0))) return rc;
   if (!e->cls_valid) launch_classes(e);
-  await_classes(e);
   launch_prep(e, pt);
   if ((rc = launch_times_quad(e, e->stream))) return rc;
   // the per-neuron sums of the spike means are the spike part of dC, which the spike-time pass makes (cosine series:
@@ -1197,7 +1177,6 @@ int svgpfa_latent_stats_backward(svgpfa_engine* e, const double* const* mean, co
     }
   }
   const unsigned m2 = mask | SV_MASK_STATS;
-  await_classes(e);                       // the gather reads ser
   if (mask & (4u | 8u)) {
     DISPATCH_NT(e->NT, hipLaunchKernelGGL((k_item_bwd<NT_, true>), dim3(v.R * v.K), dim3(64 * e->tile_nw),
                                           lds_item_bwd(NT_, e->tile_nw, true), e->stream, v, pt, m2, (const double*)nullptr,
