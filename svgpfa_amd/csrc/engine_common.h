@@ -5,7 +5,11 @@
 //   per-latent blocks   X[k]  : base offM[k]  = R * sum_{k'<k} M_k'      element (r, j)    at offM  + r*M   + j
 //                       XX[k] : base offMM[k] = R * sum_{k'<k} M_k'^2    element (r, i, j) at offMM + r*M*M + i*M + j
 //   Zs (snapshot of Z), a = Kzz^-1 m, ut = L^-1 m, adjoint of ut          : X layout
-//   Kzz, L = chol(Kzz), Linv = L^-1, Vt = L^-1 L_S, adjoint Gt of (Vt Vt^T) : XX layout
+//                       TT[k] : base offTT[k] = R * sum_{k'<k} P_k', P = M (M + 1) / 2: PACKED lower triangle,
+//                               element (r, i, j <= i) at offTT + r*P + i*(i+1)/2 + j
+//   Kzz, L = chol(Kzz) (written only when a getter asks) : XX layout
+//   Linv = L^-1, Vt = L^-1 L_S (both lower triangular)   : TT layout -- half the bytes of a full matrix both ways, and a
+//                               staging loop's consecutive elements are consecutive addresses across row ends
 // Everything downstream of the Cholesky works in WHITENED coordinates (kt = L^-1 kappa(t, Z),
 // ut = L^-1 m, Vt = L^-1 L_S): mu = kt.ut, var = s2 - |kt|^2 + |Vt^T kt|^2.  All whitened
 // quantities are O(1), which keeps fp64 error at ~sqrt(cond(Kzz)) u instead of cond(Kzz)^2 u
@@ -35,6 +39,7 @@
 struct LatentMeta {
   int M, P, ktype, nth;
   long long offM, offMM;
+  long long offTT;   // packed lower-triangular per-item matrices (Linv, Vt): R * sum_{k'<k} P_k', element (r, i, j <= i) at offTT + r P + i (i + 1) / 2 + j
   int colM;    // sum_{k'<k} M_k'
   int thoff;   // sum_{k'<k} nth_k'
   double scale2, inv_ls_scale, inv_p_scale;

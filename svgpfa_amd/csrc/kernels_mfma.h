@@ -71,7 +71,7 @@ __device__ __forceinline__ void stage_matrix(double* dst, const double* src, int
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       const int e = e0 + u * nth, i = e / MP, j = e % MP;
-      v[u] = (e < MP * MP && i < M && j <= i) ? src[i * M + j] : 0.0;
+      v[u] = (e < MP * MP && i < M && j <= i) ? src[i * (i + 1) / 2 + j] : 0.0;     // src: packed lower triangle
     }
 #pragma unroll
     for (int u = 0; u < U; ++u) {
@@ -86,7 +86,7 @@ __device__ __forceinline__ void load_factors(const EngineView& ev, const LatentM
                                              double* Vl, double* ul, double* zl, bool want_v) {
   constexpr int MP = 16 * NT;
   const int M = m.M, tid = threadIdx.x;
-  const long long base = m.offMM + (long long)r * M * M;
+  const long long base = m.offTT + (long long)r * m.P;       // Linv, Vt: packed lower triangles
   const long long vbase = m.offM + (long long)r * M;
   if (NT <= 2 && want_v) {
     // both factors and the two vectors requested before anything is stored: ONE exposed memory latency instead of one
@@ -104,8 +104,8 @@ __device__ __forceinline__ void load_factors(const EngineView& ev, const LatentM
       for (int u = 0; u < 8; ++u) {
         const int e = e0 + u * nth, i = e / MP, j = e % MP;
         const bool ok = e < MP * MP && i < M && j <= i;
-        a[u] = ok ? sl[i * M + j] : 0.0;
-        b[u] = ok ? sv[i * M + j] : 0.0;
+        a[u] = ok ? sl[i * (i + 1) / 2 + j] : 0.0;
+        b[u] = ok ? sv[i * (i + 1) / 2 + j] : 0.0;
       }
 #pragma unroll
       for (int u = 0; u < 8; ++u) {
@@ -263,7 +263,7 @@ __global__ __launch_bounds__(64 * NT) void k_prep_mfma(EngineView ev, LatentPtrT
   double* Ls = Li + MP * LD;     // MP*LD
   double* red = Ls + MP * LD;    // NT
   double* wsc = red + NT;        // 64 + SV_PRE_LDS (want_w)
-  const long long base = m.offMM + (long long)r * M * M;
+  const long long base = m.offTT + (long long)r * m.P;       // Linv, Vt: packed lower triangles
   const long long vbase = m.offM + (long long)r * M;
   const double* cv = pt.cholvec + (long long)r * m.P;
   stage_matrix<NT>(Li, ev.Linv + base, M, tid, NTH);
@@ -296,7 +296,7 @@ __global__ __launch_bounds__(64 * NT) void k_prep_mfma(EngineView ev, LatentPtrT
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         int i = 16 * a + 4 * q + lg, j = 16 * c + li;
-        if (i < M && j < M) ev.Vt[base + i * M + j] = V[a][q];
+        if (i < M && j <= i) ev.Vt[base + i * (i + 1) / 2 + j] = V[a][q];     // (Vt = Linv L_S is lower triangular)
         part = fma(V[a][q], V[a][q], part);
       }
   }

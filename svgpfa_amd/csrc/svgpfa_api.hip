@@ -38,7 +38,7 @@ struct svgpfa_engine {
                                // 7 + 6 instead of 4 + 3 + 3 + 3, and four blocks instead of two per CU: cfg3 226 -> 203 us,
                                // its 8-way shard 0.200 -> 0.186 ms per step), else 4 (shorter per-block latency).
                                // k_times_fwd stays at 4 (2 measured slower: 107 vs 101 us)
-  long long totM = 0, totMM = 0;  // R*sum M, R*sum M^2
+  long long totM = 0, totMM = 0, totTT = 0;  // R*sum M, R*sum M^2, R*sum M(M+1)/2
   bool have_quad = false, have_spikes = false, have_kernels = false, have_stats = false;
   bool aux_valid = false;   // Kzz / L buffers hold the matrices of the current kernel snapshot (getters only)
   bool timing = false;
@@ -206,7 +206,7 @@ int svgpfa_create(const svgpfa_dims* d, int device, svgpfa_engine** out) {
   v.R = d->n_trials; v.N = d->n_neurons; v.K = d->n_latents; v.Q = d->n_quad;
   v.reg = 0.0;
   e->meta.resize(v.K);
-  long long offM = 0, offMM = 0;
+  long long offM = 0, offMM = 0, offTT = 0;
   int colM = 0, thoff = 0;
   for (int k = 0; k < v.K; ++k) {
     LatentMeta& m = e->meta[k];
@@ -216,13 +216,14 @@ int svgpfa_create(const svgpfa_dims* d, int device, svgpfa_engine** out) {
     m.ktype = d->kernel_type[k];
     if (m.ktype != SV_RBF && m.ktype != SV_PERIODIC) FAIL(e, SVGPFA_ERR_INVALID, "unknown kernel type");
     m.nth = (m.ktype == SV_RBF) ? 1 : 2;
-    m.offM = offM; m.offMM = offMM; m.colM = colM; m.thoff = thoff;
+    m.offM = offM; m.offMM = offMM; m.offTT = offTT; m.colM = colM; m.thoff = thoff;
     double s = d->scale ? d->scale[k] : 1.0;
     m.scale2 = s * s;
     m.inv_ls_scale = 1.0 / (d->lengthscale_scale ? d->lengthscale_scale[k] : 1.0);
     m.inv_p_scale = 1.0 / (d->period_scale ? d->period_scale[k] : 1.0);
     offM += (long long)v.R * m.M;
     offMM += (long long)v.R * m.M * m.M;
+    offTT += (long long)v.R * m.P;
     colM += m.M;
     thoff += m.nth;
     e->Mmax = std::max(e->Mmax, m.M);
@@ -232,7 +233,7 @@ int svgpfa_create(const svgpfa_dims* d, int device, svgpfa_engine** out) {
     int t = e->meta[k].ktype;
     v.klist[t][v.ntype[t]++] = k;
   }
-  e->totM = offM; e->totMM = offMM;
+  e->totM = offM; e->totMM = offMM; e->totTT = offTT;
   v.sumM = colM; v.nth_total = thoff;
   e->NT = (e->Mmax + 15) / 16;
 
@@ -244,8 +245,8 @@ int svgpfa_create(const svgpfa_dims* d, int device, svgpfa_engine** out) {
   DALLOC(e, v.Zs, e->totM); DALLOC(e, v.theta, 2 * v.K);
   DALLOC(e, v.four, (size_t)v.K * SV_FROWS * (SV_FH + 2)); DALLOC(e, v.fourH, v.K);
   HIPCHK(e, hipMemset(v.fourH, 0xff, sizeof(int) * v.K));
-  DALLOC(e, v.Kzz, e->totMM); DALLOC(e, v.L, e->totMM); DALLOC(e, v.Linv, e->totMM);
-  DALLOC(e, v.a, e->totM); DALLOC(e, v.ut, e->totM); DALLOC(e, v.Vt, e->totMM); DALLOC(e, v.klpart, (size_t)v.R * v.K);
+  DALLOC(e, v.Kzz, e->totMM); DALLOC(e, v.L, e->totMM); DALLOC(e, v.Linv, e->totTT);
+  DALLOC(e, v.a, e->totM); DALLOC(e, v.ut, e->totM); DALLOC(e, v.Vt, e->totTT); DALLOC(e, v.klpart, (size_t)v.R * v.K);
   size_t rqk = (size_t)v.R * v.Q * v.K;
   DALLOC(e, v.muq, rqk); DALLOC(e, v.varq, rqk); DALLOC(e, v.gmuq, rqk); DALLOC(e, v.gvarq, rqk);
   e->KKT = (2 * v.K + 3) / 4;   // KS: k-steps of the h product
