@@ -160,7 +160,6 @@ struct EngineView {
   double* splitS;                                  // [nsplitS][K]
   double* Apart;                                   // [ntiles][K][SV_ACOLS] A-moment partials
   double* Wb;                                      // [R][K][SV_WCOLS] posterior-mean weights on the harmonics
-  double* Ub;                                      // [ntiles][K][SV_WCOLS][64] the rows' cos / sin moments (small shards only)
   double* P0t; double* P1t; double* Tt;            // [R][sumM] x 2, [R][K][2]: spike sums of class-path items (k_spike_comb)
   int comb_fold;                                   // 1: k_item_bwd's gather combines the moments itself (small shards)
   double* muspk;                                   // [K][S] (stats API only)

@@ -115,8 +115,6 @@ __device__ __forceinline__ void cls_pass(const double* __restrict__ tt, int maxl
 // Ut[row][16] so that the tile's partial A-moments  Apart[member][col] = sum_rows C[neuron(row), member] U[row][col]
 // come out of 16 v_mfma_f64_16x16x4_f64 (A operand: the gathered embedding weights cg, B operand: U); and, DC, the
 // rows' own dC partials  dcl[member][row] += sum_cols U[row][col] W[member][col]  on the VALU (W is wave-uniform).
-// DC = 2: instead, the rows' cos / sin moments are STORED (Ub[tile][class][column][row]) for k_spike_dc -- the arrangement
-// of small shards, where this kernel runs before a = Kzz^-1 m (hence W) exists.
 template <int NV, int HB, int DC>
 __device__ __forceinline__ void cls_flush(const EngineView& ev, const double* __restrict__ C, const double (&acc)[NV * HB],
                                           int neuron, int nrows, int memk, int nmem, int tile, int g, int r, int h0, int H,
@@ -164,17 +162,6 @@ __device__ __forceinline__ void cls_flush(const EngineView& ev, const double* __
         }
       }
       lds_wave_fence();                    // the tile is free for the next chunk
-    }
-  }
-  if (DC == 2) {
-    double* ub = ev.Ub + ((long long)tile * K + g) * SV_WCOLS * 64 + lane;      // column-major over the tile's rows: coalesced
-#pragma unroll
-    for (int n = 0; n < HB; ++n) {
-      const int col = 2 * (h0 + n);
-      if (col < 2 * (H + 1)) {               // wave-uniform
-        ub[(long long)col * 64] = acc[NV * n + 0];
-        ub[(long long)(col + 1) * 64] = acc[NV * n + 1];
-      }
     }
   }
   if (DC == 1) {
@@ -272,7 +259,7 @@ __device__ __forceinline__ void cls_item(const EngineView& ev, const double* __r
 // single-wave blocks that stride over the items (tiles in the host's cost order, longest first).
 // NV = 4: the classes that carry the time-weighted moments (periodic classes when Z / theta gradients are wanted: `full`);
 // NV = 2: all others.  Two kernels rather than one: the NV = 2 pass needs a third fewer registers.
-// DC: 0 no dC, 1 dC rows here (needs W), 2 moments stored for k_spike_dc.
+// DC: 1 = the rows' dC partials wanted (needs W).
 template <int NV, int DC>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 8))) void k_spike_cls(EngineView ev,
                                                                                              const double* __restrict__ C,
@@ -296,68 +283,21 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 8))) void
   }
 }
 
-// ------------------------------------------------------------------------------------------------ k_spike_dc
-// dC rows of the class path from STORED moments (k_spike_cls<.., 2>):  dcl[member][row] = sum_cols U[row][col] W[member][col],
-// in the passes and the order of cls_flush's fused form (bit-identical rows).  Work item = (tile, class), single-wave
-// blocks striding a fixed grid; `full` as in the moment kernels' launch (it sets the classes' pass length).
-__global__ __launch_bounds__(64) void k_spike_dc(EngineView ev, int full) {
-  __shared__ double Wl[SV_CLS_MAXMEM * 48];
-  __shared__ double dcl[SV_CLS_MAXMEM * 64];
+// Both kinds of class in ONE launch (the default up to R K = 4096 items, svgpfa_engine::cls_fused): work item = (tile, class)
+// over ALL classes, the item's class decides the pass it takes.  One launch boundary (a drained chip) less.
+template <int DC>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 8))) void k_spike_cls_all(EngineView ev,
+                                                                                                 const double* __restrict__ C,
+                                                                                                 int full) {
+  __shared__ double Ut[64 * 16];
+  __shared__ double dcl[DC == 1 ? SV_CLS_MAXMEM * 64 : 1];
   const SpikeClassTab* cls = ev.cls;
-  const int ncls = cls->ncls, K = ev.K, R = ev.R, lane = threadIdx.x;
+  const int ncls = cls->ncls;
   const int nitems = ev.ntiles * ncls;
   for (int w = blockIdx.x; w < nitems; w += gridDim.x) {
     const int g = w % ncls;
-    const SpikeTile tl = ev.tiles_ord[w / ncls];
-    const int r = tl.trial, tile = tl.id;
-    const int H = ev.cls_H[(long long)g * R + r];
-    if (H < 0) continue;                               // this (trial, class) takes the pair loop
-    const int nmem = cls->nmem[g];
-    const int memk = cls->mem[g][lane & (SV_CLS_MAXMEM - 1)];
-    SpikeRow row = ev.rows[tl.row0 + (lane < tl.nrows ? lane : 0)];
-    if (lane >= tl.nrows) row = SpikeRow{0, 0, 0, 0};
-    const int HBM = (full && cls->type[g] == SV_PERIODIC) ? 16 : 24;
-    const double* ub = ev.Ub + ((long long)tile * K + g) * SV_WCOLS * 64 + lane;
-    for (int h0 = 0; h0 <= H; h0 += HBM) {
-      const int left = H + 1 - h0;
-      const int HB = (left > 16 && HBM == 24) ? 24 : (left > 8) ? 16 : 8, WP = 2 * HB;
-      const int tot = nmem * WP;
-      for (int e = lane; e < tot; e += 64) {           // W of the members for this pass's harmonics (zeros beyond H)
-        const int sm = e / WP, c = e % WP, col = 2 * h0 + c;
-        const int mk = cls->mem[g][sm];
-        Wl[e] = (col < SV_WCOLS) ? ev.Wb[((long long)r * K + mk) * SV_WCOLS + col] : 0.0;
-      }
-      lds_wave_fence();
-      double v[SV_CLS_MAXMEM];
-#pragma unroll
-      for (int s = 0; s < SV_CLS_MAXMEM; ++s) v[s] = 0.0;
-      for (int n0 = 0; n0 < HB; n0 += 8) {             // eight harmonics' moments in flight
-        double u[16];
-#pragma unroll
-        for (int n = 0; n < 8; ++n) {
-          const int col = 2 * (h0 + n0 + n);
-          const bool ok = col < 2 * (H + 1);           // wave-uniform; beyond H the fused form multiplies by W = 0
-          u[2 * n] = ok ? ub[(long long)col * 64] : 0.0;
-          u[2 * n + 1] = ok ? ub[(long long)(col + 1) * 64] : 0.0;
-        }
-#pragma unroll
-        for (int s = 0; s < SV_CLS_MAXMEM; ++s)
-          if (s < nmem) {
-            const double* Wk = Wl + s * WP + 2 * n0;
-#pragma unroll
-            for (int n = 0; n < 8; ++n) {
-              v[s] = fma(u[2 * n], Wk[2 * n], v[s]);
-              v[s] = fma(u[2 * n + 1], Wk[2 * n + 1], v[s]);
-            }
-          }
-      }
-#pragma unroll
-      for (int s = 0; s < SV_CLS_MAXMEM; ++s)
-        if (s < nmem) dcl[s * 64 + lane] = (h0 == 0) ? v[s] : dcl[s * 64 + lane] + v[s];
-      lds_wave_fence();                                // W's tile is free for the next pass
-    }
-    cls_emit_rows(ev, row, r, memk, nmem, dcl);
-    lds_wave_fence();
+    if (full && cls->type[g] == SV_PERIODIC) cls_item<4, DC>(ev, C, cls, g, w / ncls, Ut, dcl);
+    else cls_item<2, DC>(ev, C, cls, g, w / ncls, Ut, dcl);
   }
 }
 

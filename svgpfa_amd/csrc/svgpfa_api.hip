@@ -54,23 +54,20 @@ struct svgpfa_engine {
   // (wave-uniform branch): measured faster than one launch per type for the per-item kernels (+3 % on cfg3: fewer
   // launches, shorter grid tails) and, since both types of the spike pass fit 3 waves / SIMD, for the spike pass too
   // (+1.5 %; its grid lists the longer periodic work items first).
-  // Two chains between k_prep and k_item_bwd: the spike pass and the quadrature chain (k_times_fwd -> k_quad_ell).  On small
-  // shards (default -1: R K <= 2048), where every launch under-fills the chip, the quadrature chain runs on a side stream
-  // (two cross-stream edges: prep -> times, quad_ell -> bwd) and the second class kernel of the spike pass on another; at
-  // full size one stream is kept, so that the spike pass runs alone and its hipEvent duration is comparable with the
-  // roofline.  SVGPFA_OVERLAP=0 / 1 forces it off / on.  (Round 2 measured, ms per evaluation of cfg3, one stream -> two:
-  // 1-way 1.219 -> 1.183, 2-way 0.664 -> 0.648, 4-way 0.384 -> 0.355, 8-way 0.236 -> 0.230.)
+  // Two chains between k_prep and k_item_bwd: the spike pass and the quadrature chain (k_times_fwd -> k_quad_ell).  ONE stream
+  // at every size.  SVGPFA_OVERLAP=1 puts the quadrature chain on a side stream (two cross-stream edges: prep -> times,
+  // quad_ell -> bwd) and, with two class kernels, the second on another.  Round 2 ran small shards that way (ms per evaluation
+  // of cfg3, one stream -> two: 4-way 0.384 -> 0.355, 8-way 0.236 -> 0.230); with this round's kernels one stream wins at
+  // every size (8-way 0.176 against 0.181): an edge that crosses streams costs 12-20 us at the end of a chain, the class
+  // kernels fill every wave slot of the chip, and kernels side by side slow each other down.
   int side_stream = -1;
-  hipStream_t s_side = nullptr, s_side2 = nullptr, s_side3 = nullptr;   // quadrature chain / spike pass on small shards
+  hipStream_t s_side = nullptr, s_side2 = nullptr;   // SVGPFA_OVERLAP=1: quadrature chain / second class kernel beside the main stream
   hipEvent_t ev_prep = nullptr, ev_quad = nullptr, ev_fork = nullptr, ev_join = nullptr;
-  hipEvent_t ev_b0 = nullptr, ev_e0 = nullptr, ev_spk = nullptr;
-  // Small shards with the class path (SVGPFA_EARLY=0 turns it off): the spike MOMENTS need the spikes, C and the class table
-  // (a rider of k_build_reg), nothing of k_prep -- so the moment kernels run on a stream of their own from the end of the
-  // kernel build on, beside k_prep and the quadrature chain, store the rows' moments, and only the small tail that needs
-  // a = Kzz^-1 m (dC rows from the stored moments, pair loop) waits for k_prep.
-  bool early = false;
-  bool fresh_build = false;                     // ev_b0 (end of the last kernel build) has not been waited for by the spike stream
   bool fork_always = false;                     // SVGPFA_FORK=1: the two class kernels on two streams at every size (experiment)
+  // Both kinds of class (with / without time-weighted moments) in ONE launch: default up to R K = 4096 items (one launch
+  // boundary -- a drained chip -- less: one rank's shard of cfg3, ms per evaluation, two kernels -> one: 2-way 0.405 -> 0.386,
+  // 4-way 0.266 -> 0.249, 8-way 0.198 -> 0.176; at the full 5 000 items 0.655 / 0.659).  SVGPFA_CLS_FUSED=0 / 1 forces it.
+  int cls_fused = -1;
   bool cls_on = true;                           // false: problem too small for the class path's extra launches (set_spikes)
   double series_min_pairs = 1e7;                // SVGPFA_SERIES_MIN_PAIRS: fewest (spike, inducing point) pairs for the class path
   bool cls_valid = false;                       // the class table of the spike pass belongs to the current kernel build
@@ -300,9 +297,9 @@ int svgpfa_create(const svgpfa_dims* d, int device, svgpfa_engine** out) {
   HIPCHK(e, hipHostMalloc((void**)&e->status_host, sizeof(int)));
   HIPCHK(e, hipStreamCreateWithFlags(&e->s_side, hipStreamNonBlocking));
   HIPCHK(e, hipStreamCreateWithFlags(&e->s_side2, hipStreamNonBlocking));
-  HIPCHK(e, hipStreamCreateWithFlags(&e->s_side3, hipStreamNonBlocking));
   HIPCHK(e, hipStreamCreateWithFlags(&e->s_cap, hipStreamNonBlocking));
   if (getenv("SVGPFA_GRAPH")) e->graph_mode = atoi(getenv("SVGPFA_GRAPH")) != 0 ? 1 : 0;
+  if (getenv("SVGPFA_CLS_FUSED")) e->cls_fused = atoi(getenv("SVGPFA_CLS_FUSED")) != 0 ? 1 : 0;
   {
     const char* ov = getenv("SVGPFA_OVERLAP");
     if (ov) e->side_stream = atoi(ov) != 0 ? 1 : 0;
@@ -326,7 +323,7 @@ int svgpfa_create(const svgpfa_dims* d, int device, svgpfa_engine** out) {
     e->grid_cls = std::max(8, prop.multiProcessorCount * std::max(1, bc));
     e->grid_pair = std::max(8, (prop.multiProcessorCount * std::max(1, bp)) & ~7);
   }
-  for (hipEvent_t* ev : {&e->ev_prep, &e->ev_quad, &e->ev_fork, &e->ev_join, &e->ev_b0, &e->ev_e0, &e->ev_spk})
+  for (hipEvent_t* ev : {&e->ev_prep, &e->ev_quad, &e->ev_fork, &e->ev_join})
     HIPCHK(e, hipEventCreateWithFlags(ev, hipEventDisableTiming));
 
   int rc = 0;
@@ -353,9 +350,9 @@ void svgpfa_destroy(svgpfa_engine* e) {
   for (void* p : e->allocs) (void)hipFree(p);
   if (e->status_host) (void)hipHostFree(e->status_host);
   drop_graphs(e);
-  for (hipStream_t st : {e->s_side, e->s_side2, e->s_side3, e->s_cap})
+  for (hipStream_t st : {e->s_side, e->s_side2, e->s_cap})
     if (st) (void)hipStreamDestroy(st);
-  for (hipEvent_t ev : {e->ev_prep, e->ev_quad, e->ev_fork, e->ev_join, e->ev_b0, e->ev_e0, e->ev_spk})
+  for (hipEvent_t ev : {e->ev_prep, e->ev_quad, e->ev_fork, e->ev_join})
     if (ev) (void)hipEventDestroy(ev);
   for (auto& pr : e->ev_pool) {
     (void)hipEventDestroy(pr.first);
@@ -617,12 +614,6 @@ int svgpfa_set_spikes(svgpfa_engine* e, const int64_t* off, const double* times,
   // evaluation (class table, W, one or two class kernels), which only pays once the pair loop itself takes tens of
   // microseconds (cfg2, 4e6 pairs: 0.137 ms per evaluation with the class path against 0.11 without)
   e->cls_on = (double)S * (double)v.sumM >= e->series_min_pairs;
-  {
-    const bool side = v.nchunks > 0 && (e->side_stream == 1 || (e->side_stream < 0 && (long long)v.R * v.K <= 2048));
-    e->early = side && e->cls_on && v.ntiles > 0 && e->graph_mode != 1 &&      // (a captured evaluation forks from its own origin only)
-               !(getenv("SVGPFA_EARLY") && atoi(getenv("SVGPFA_EARLY")) == 0);
-    if (e->early) DALLOC(e, v.Ub, (size_t)v.ntiles * v.K * SV_WCOLS * 64);
-  }
   e->have_spikes = true;
   e->have_stats = false;
   e->p0_token = 0;
@@ -674,10 +665,6 @@ int svgpfa_build_kernels(svgpfa_engine* e, const double* const* Z, const double*
   }
   const bool cls = e->have_spikes && e->cls_on;
   launch_build(e, 0, &st, cls);
-  if (cls && e->early) {     // the spike stream's moment kernels of the next evaluation start here (class table ready)
-    HIPCHK(e, hipEventRecord(e->ev_b0, e->stream));
-    e->fresh_build = true;
-  }
   e->aux_valid = false;
   e->p0_token = 0;
   e->cls_valid = cls || !e->cls_on;
@@ -773,7 +760,7 @@ static int launch_times_quad(svgpfa_engine* e, hipStream_t st) {
 #define SV_EV_POOL_MAX 4096
 static int fold_events(svgpfa_engine* e) {
   HIPCHK(e, hipStreamSynchronize(e->stream));
-  for (hipStream_t st : {e->s_side, e->s_side2, e->s_side3})
+  for (hipStream_t st : {e->s_side, e->s_side2})
     if (st) HIPCHK(e, hipStreamSynchronize(st));      // the event pairs live there when the pass is overlapped
   for (size_t i = 0; i < e->ev_used; ++i) {
     float ms = 0.f;
@@ -836,7 +823,8 @@ static void launch_spike_pass(svgpfa_engine* e, hipStream_t sk, bool full, bool 
   bool joined = true;
   if (v.ntiles > 0 && e->cls_on) {
     // the classes with time-weighted moments (periodic, when Z / theta gradients are wanted) have a kernel of their own
-    const bool tw = full && v.ntype[SV_PERIODIC] > 0;
+    const bool fused = e->cls_fused == 1 || (e->cls_fused < 0 && (long long)v.R * v.K <= 4096);
+    const bool tw = !fused && full && v.ntype[SV_PERIODIC] > 0;
     const bool fork = tw && (may_fork || e->fork_always);
     hipStream_t s4 = fork ? e->s_side2 : sk;
     if (full && want_c && !have_w) hipLaunchKernelGGL(k_spike_pre, gi, bs, 0, sk, v);
@@ -850,7 +838,10 @@ static void launch_spike_pass(svgpfa_engine* e, hipStream_t sk, bool full, bool 
       }
       (void)hipStreamWaitEvent(s4, ev_w, 0);
     }
-    if (full && want_c) {
+    if (fused) {
+      if (full && want_c) hipLaunchKernelGGL((k_spike_cls_all<1>), gc, bs, 0, sk, v, C, 1);
+      else hipLaunchKernelGGL((k_spike_cls_all<0>), gc, bs, 0, sk, v, C, full ? 1 : 0);
+    } else if (full && want_c) {
       if (tw) hipLaunchKernelGGL((k_spike_cls<4, 1>), gc, bs, 0, s4, v, C, 1);
       hipLaunchKernelGGL((k_spike_cls<2, 1>), gc, bs, 0, sk, v, C, 1);
     } else {
@@ -873,42 +864,6 @@ static void launch_spike_pass(svgpfa_engine* e, hipStream_t sk, bool full, bool 
   if (!joined) (void)hipStreamWaitEvent(sk, e->ev_join, 0);
 }
 
-// The spike pass of small shards (svgpfa_engine::early) on the spike stream ss: the moment kernels first -- they need the
-// class table (k_build_reg's riders), C and the spikes, and run beside k_prep and the quadrature chain -- then, behind
-// k_prep's event, the tail that needs a = Kzz^-1 m and W (k_prep's rider): the combine (unless k_item_bwd's gather does
-// it), the dC rows from the stored moments, the pair loop.
-static void launch_spike_early(svgpfa_engine* e, hipStream_t ss, bool full, bool want_c, const double* C) {
-  EngineView& v = e->v;
-  const dim3 bs(64), gi(v.R * v.K);
-  const dim3 gc((unsigned)std::min<long long>((long long)v.ntiles * v.K, e->grid_cls));
-  const bool tw = full && v.ntype[SV_PERIODIC] > 0;
-  const bool dc = full && want_c;
-  // two class kernels (time-weighted moments wanted and periodic latents present): side by side, the second on s_side3
-  hipStream_t s2 = tw ? e->s_side3 : ss;
-  if (tw) {
-    (void)hipEventRecord(e->ev_fork, ss);
-    (void)hipStreamWaitEvent(s2, e->ev_fork, 0);
-  }
-  if (dc) {
-    if (tw) hipLaunchKernelGGL((k_spike_cls<4, 2>), gc, bs, 0, ss, v, C, 1);
-    hipLaunchKernelGGL((k_spike_cls<2, 2>), gc, bs, 0, s2, v, C, 1);
-  } else {
-    if (tw) hipLaunchKernelGGL((k_spike_cls<4, 0>), gc, bs, 0, ss, v, C, 1);
-    hipLaunchKernelGGL((k_spike_cls<2, 0>), gc, bs, 0, s2, v, C, full ? 1 : 0);
-  }
-  if (tw) {
-    (void)hipEventRecord(e->ev_join, s2);
-    (void)hipStreamWaitEvent(ss, e->ev_join, 0);
-  }
-  (void)hipStreamWaitEvent(ss, e->ev_prep, 0);
-  if (!v.comb_fold) {
-    if (full) hipLaunchKernelGGL(k_spike_comb<true>, gi, bs, 0, ss, v);
-    else hipLaunchKernelGGL(k_spike_comb<false>, gi, bs, 0, ss, v);
-  }
-  if (dc) hipLaunchKernelGGL(k_spike_dc, gc, bs, 0, ss, v, 1);
-  launch_pair_pass(e, ss, full, want_c, C);
-}
-
 static int check_ready(svgpfa_engine* e) {
   if (!e->have_quad) FAIL(e, SVGPFA_ERR_STATE, "svgpfa_set_quad has not been called");
   if (!e->have_spikes) FAIL(e, SVGPFA_ERR_STATE, "svgpfa_set_spikes has not been called");
@@ -928,18 +883,12 @@ static int enqueue_elbo(svgpfa_engine* e, const PtrTable& pt, const ElboPlan& pl
   int rc;
   if (!e->cls_valid) launch_classes(e);   // spikes set after the last kernel build
   hipStream_t sm = e->stream;
-  const bool early = e->early && pl.side && pl.run_spike;
-  // The spike stream's kernels overwrite what earlier evaluations' kernels read, and read the class table: they start
-  // behind the last kernel build's event, or (no build since the last evaluation) behind what the main stream holds now.
-  const bool fresh = e->fresh_build;
-  if (early && !fresh) HIPCHK(e, hipEventRecord(e->ev_e0, sm));
   // the class path's W rides in k_prep when this evaluation's spike pass wants dC
   const bool have_w = pl.run_spike && pl.full && (mask & 2u) && e->cls_on && v.ntiles > 0;
   launch_prep(e, pt, have_w);
-  // Small shards (pl.side): every kernel is one under-filled round, so the quadrature chain (f64 MFMA: posterior stats ->
-  // ELL term) runs on a side stream beside the spike pass.  The SPIKE pass stays on the main stream, in front of
-  // k_item_bwd: it is the longer chain on such shards, and a wait for an event that completed long ago costs a few
-  // microseconds where a wait at the end of the critical chain costs 15-20 (kernel trace of an 8-way shard of cfg3).
+  // SVGPFA_OVERLAP=1 (pl.side): the quadrature chain (f64 MFMA: posterior stats -> ELL term) on a side stream beside the spike
+  // pass, which stays on the main stream in front of k_item_bwd.  Off by default at every size: a dependency that crosses
+  // streams costs 12-20 us at the end of a chain, and kernels side by side slow each other down.
   hipStream_t sq = pl.side ? e->s_side : sm;
   if (pl.side) {
     HIPCHK(e, hipEventRecord(e->ev_prep, sm));
@@ -949,15 +898,7 @@ static int enqueue_elbo(svgpfa_engine* e, const PtrTable& pt, const ElboPlan& pl
     HIPCHK(e, hipEventRecord(e->ev_quad, sq));
   }
   // ---- spike pass (fp64 VALU bound): needs only a = Kzz^-1 m (and W) from k_prep
-  if (early) {
-    hipStream_t ss = e->s_side2;
-    HIPCHK(e, hipStreamWaitEvent(ss, fresh ? e->ev_b0 : e->ev_e0, 0));
-    e->fresh_build = false;
-    const int evp = timing_begin(e, 0, ss);
-    launch_spike_early(e, ss, pl.full, (mask & 2u) != 0, C);
-    timing_end(e, evp, ss);
-    HIPCHK(e, hipEventRecord(e->ev_spk, ss));
-  } else if (pl.run_spike) {
+  if (pl.run_spike) {
     const int evp = timing_begin(e, 0, sm);
     launch_spike_pass(e, sm, pl.full, (mask & 2u) != 0, C, have_w, pl.side, pl.side ? e->ev_prep : nullptr);
     timing_end(e, evp, sm);
@@ -967,7 +908,6 @@ static int enqueue_elbo(svgpfa_engine* e, const PtrTable& pt, const ElboPlan& pl
     if ((rc = launch_quad_ell(e, sm, C, d, (mask & 2u) ? 1 : 0, pl.want_lat ? 1 : 0))) return rc;
   } else {
     HIPCHK(e, hipStreamWaitEvent(sm, e->ev_quad, 0));     // join the quadrature chain
-    if (early) HIPCHK(e, hipStreamWaitEvent(sm, e->ev_spk, 0));
   }
   // ---- per-item adjoints + backward + the fixed-order cross-trial reductions in one kernel
   const int evb = timing_begin(e, 1, sm);
@@ -1070,7 +1010,7 @@ int svgpfa_elbo(svgpfa_engine* e, const double* const* mean, const double* const
   pl.mask = mask;
   pl.want_lat = (mask & (1u | 4u | 8u)) != 0;
   pl.full = (mask & (2u | 4u | 8u)) != 0;
-  pl.side = v.nchunks > 0 && (e->side_stream == 1 || (e->side_stream < 0 && (long long)v.R * v.K <= 2048));
+  pl.side = v.nchunks > 0 && e->side_stream == 1;
   // A value-only evaluation reuses the spike pass's sums when the caller vouches (token) that C is unchanged since the pass
   // that produced them.  Only a value-only pass leaves reusable sums: the full pass accumulates them with different
   // roundings, and cached and un-cached evaluations are to stay bit-identical

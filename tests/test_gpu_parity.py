@@ -697,15 +697,16 @@ def test_graph_replay_is_bit_identical_to_plain_launches(monkeypatch, kernels):
     dict(R=3, N=70, K=2, M=[20, 24], kernels="rbf", seed=23, n_quad=40, rate=9.0),            # two tiles per trial, short rows
     dict(R=5, N=40, K=6, M=[9, 30, 17, 32, 12, 25], kernels="mix", seed=24, n_quad=50, rate=30.0),
 ], ids=["halves", "oversize", "two-tiles", "six-latents"])
-def test_early_moments_equal_the_fused_pass(case, monkeypatch):
-    """Small shards (trials x latents <= 2048) run the class path's moment kernels on a stream of their own, beside the
-    kernel build and k_prep, store the rows' moments and make the dC rows from them once a = Kzz^-1 m exists (k_spike_dc);
-    SVGPFA_EARLY=0 keeps the fused pass of large problems.  Same bits for every gradient mask, with the parameters changing
-    between evaluations, with and without a kernel build in between, and with the spike sums reused under a token."""
+def test_one_class_kernel_equals_two(case, monkeypatch):
+    """Up to 4096 (trial, latent) items the class path's two kinds of class (with / without time-weighted moments) share ONE
+    launch (k_spike_cls_all); SVGPFA_CLS_FUSED=0 keeps the two kernels of large problems.  Same bits for every gradient
+    mask, with the parameters changing between evaluations, with and without a kernel build in between, and with the
+    spike sums reused under a token; same again with the quadrature chain on a side stream (SVGPFA_OVERLAP=1)."""
     prob = synthetic.make_problem(jitter=1.0, **case)
     seqs = {}
-    for mode in ("0", "1"):
-        monkeypatch.setenv("SVGPFA_EARLY", mode)
+    for mode in ("0", "1", "1+overlap"):
+        monkeypatch.setenv("SVGPFA_CLS_FUSED", mode[0])
+        monkeypatch.setenv("SVGPFA_OVERLAP", "1" if "overlap" in mode else "0")
         eng, P = _engine(prob)
         seq = []
         for mask in (15, 3, 12, 1, 0):
@@ -731,7 +732,8 @@ def test_early_moments_equal_the_fused_pass(case, monkeypatch):
             seq.append([shared.clone()])
         seqs[mode] = seq
         eng.close()
-    for a, b in zip(seqs["0"], seqs["1"]):
-        for x, y in zip(a, b):
-            assert torch.equal(x, y)
+    for other in ("1", "1+overlap"):
+        for a, b in zip(seqs["0"], seqs[other]):
+            for x, y in zip(a, b):
+                assert torch.equal(x, y)
     assert float(seqs["0"][0][0][0]) != float(seqs["0"][1][0][0])
