@@ -266,8 +266,13 @@ __device__ __forceinline__ void kern_eval(double delta, const KPar& p, double& k
 // points).  One lane per latent, once per kernel build.
 // f: workspace of SV_FH + 3 doubles (LDS of the caller: a private array would put the whole kernel on scratch memory).
 __device__ inline int periodic_series(double beta, int M, double* tab, double* f) {
-  constexpr int NS = SV_FH + 48;        // start of the downward recurrence, far inside the decaying tail for beta <= 45
   if (!(beta > 0.0) || beta > 45.0) return -1;
+  // Start of the downward recurrence, far inside the decaying tail: I_n(beta) <= (beta / 2)^n / n!, so from n = 32 + 2 beta
+  // down the truncation error is below 1e-30 of I_0 for every beta <= 45 (SV_FH + 48 = 96 at the upper end; a fixed start
+  // at 96 made the class riders of k_build_reg, which repeat this per build for their harmonic counts, 8 us longer than
+  // the kernel's item blocks).  Entries above the start are zeros.
+  const int NS = min(SV_FH + 48, 32 + (int)(2.0 * beta));
+  for (int n = NS + 1; n <= SV_FH + 2; ++n) f[n] = 0.0;
   double fp = 0.0, fc = 1e-280, sum = 0.0;       // f_{n+1}, f_n
   const double tb = 2.0 / beta;
   for (int n = NS; n >= 1; --n) {
@@ -287,7 +292,7 @@ __device__ inline int periodic_series(double beta, int M, double* tab, double* f
   const double inv = 1.0 / sum;
   int H = 0;
   if (!tab) {                                    // H only (class riders / k_spike_classes): no table, no divisions
-    for (int n = 1; n <= SV_FH + 1; ++n)
+    for (int n = 1; n <= SV_FH + 1 && n <= NS; ++n)
       if (n * (2.0 * (f[n] * inv)) >= 1e-18) H = n;
     if (H > SV_FH) return -1;
     if (12 * (H + 2) > 23 * M) return -1;
