@@ -2,10 +2,13 @@
 exposes the host-side floor (Python marshalling + kernel launches) that limits strong scaling."""
 import os, sys, time
 sys.path.insert(0, os.path.join(os.path.dirname(__file__), "..", ".."))
+import gc
 import torch
 from svgpfa_amd.engine import engine_from_problem
 from svgpfa_amd.utils import synthetic
 full = synthetic.make_config("cfg3")
+gc.collect()
+gc.freeze()     # (a full pass of the cyclic collector over torch's heap is a 40-ms stall: tests/tools/step_jitter.py)
 for world, mode in [(w, m) for w in (1, 2, 4, 8) for m in ("0", "1", "auto")]:
     if mode == "auto":
         os.environ.pop("SVGPFA_OVERLAP", None)
@@ -18,12 +21,16 @@ for world, mode in [(w, m) for w in (1, 2, 4, 8) for m in ("0", "1", "auto")]:
     def step():
         eng.build_kernels(P["Z"], P["theta"])
         eng.elbo(P["mean"], P["cholVecs"], P["C"], P["d"], 15, out=shared, grads=grads)
-    for _ in range(5): step()
+    for _ in range(30): step()
     eng.sync()
-    t0 = time.perf_counter()
-    for _ in range(50): step()
-    t_enq = time.perf_counter() - t0
-    torch.cuda.synchronize()
-    t = time.perf_counter() - t0
-    print(f"world {world} overlap {mode}: trials {prob['R']:4d}  step {1e3*t/50:.3f} ms  (host enqueue only {1e3*t_enq/50:.3f} ms)  elbo {float(shared[0]):.6f}")
+    best, best_enq = 1e9, 1e9
+    for rep in range(3):                       # best of three runs of 100 steps (a busy host core shows up as an outlier)
+        t0 = time.perf_counter()
+        for _ in range(100): step()
+        t_enq = time.perf_counter() - t0
+        torch.cuda.synchronize()
+        t = time.perf_counter() - t0
+        if t < best:
+            best, best_enq = t, t_enq
+    print(f"world {world} overlap {mode}: trials {prob['R']:4d}  step {1e3*best/100:.3f} ms  (host enqueue only {1e3*best_enq/100:.3f} ms)  elbo {float(shared[0]):.6f}")
     eng.close()
