@@ -812,8 +812,8 @@ static void launch_pair_pass(svgpfa_engine* e, hipStream_t sk, bool full, bool w
 // wanted (only with full); have_w: k_prep made the class path's W (else k_spike_pre does, here).  Class path (cosine
 // series, kernels_spike_cls.h) for the (trial, latent) items it serves, the pair-by-pair pass (kernels_spike.h) for the
 // rest; both stride fixed grids over work lists that live on the device.
-// fork: the class kernel of the time-weighted moments on s_side2, beside the other one (small shards); ev_w is an event on
-// the stream that made W and the class table's inputs (recorded by the caller behind k_prep when have_w).
+// may_fork (SVGPFA_OVERLAP=1, two class kernels): the class kernel of the time-weighted moments on s_side2, beside the other
+// one; ev_w is an event on the stream that made W and the class table (recorded by the caller behind k_prep when have_w).
 static void launch_spike_pass(svgpfa_engine* e, hipStream_t sk, bool full, bool want_c, const double* C, bool have_w,
                               bool may_fork, hipEvent_t ev_w) {
   EngineView& v = e->v;
@@ -822,7 +822,8 @@ static void launch_spike_pass(svgpfa_engine* e, hipStream_t sk, bool full, bool 
   const dim3 gc((unsigned)std::min<long long>((long long)v.ntiles * v.K, e->grid_cls));
   bool joined = true;
   if (v.ntiles > 0 && e->cls_on) {
-    // the classes with time-weighted moments (periodic, when Z / theta gradients are wanted) have a kernel of their own
+    // one launch for all classes (shards), or the classes with time-weighted moments (periodic, when Z / theta gradients are
+    // wanted) in a kernel of their own
     const bool fused = e->cls_fused == 1 || (e->cls_fused < 0 && (long long)v.R * v.K <= 4096);
     const bool tw = !fused && full && v.ntype[SV_PERIODIC] > 0;
     const bool fork = tw && (may_fork || e->fork_always);
