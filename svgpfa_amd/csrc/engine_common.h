@@ -5,8 +5,8 @@
 //   per-latent blocks   X[k]  : base offM[k]  = R * sum_{k'<k} M_k'      element (r, j)    at offM  + r*M   + j
 //                       XX[k] : base offMM[k] = R * sum_{k'<k} M_k'^2    element (r, i, j) at offMM + r*M*M + i*M + j
 //   Zs (snapshot of Z), a = Kzz^-1 m, ut = L^-1 m, adjoint of ut          : X layout
-//                       TT[k] : base offTT[k] = R * sum_{k'<k} P_k', P = M (M + 1) / 2: PACKED lower triangle,
-//                               element (r, i, j <= i) at offTT + r*P + i*(i+1)/2 + j
+//                       TT[k] : base offTT[k] = R * sum_{k'<k} PT_k': PACKED lower triangle, rows padded to an even length
+//                               (PT = M (M + 1) / 2 + ceil(M / 2)), element (r, i, j <= i) at offTT + r*PT + sv_tri_off(i) + j
 //   Kzz, L = chol(Kzz) (written only when a getter asks) : XX layout
 //   Linv = L^-1, Vt = L^-1 L_S (both lower triangular)   : TT layout -- half the bytes of a full matrix both ways, and a
 //                               staging loop's consecutive elements are consecutive addresses across row ends
@@ -39,11 +39,17 @@
 struct LatentMeta {
   int M, P, ktype, nth;
   long long offM, offMM;
-  long long offTT;   // packed lower-triangular per-item matrices (Linv, Vt): R * sum_{k'<k} P_k', element (r, i, j <= i) at offTT + r P + i (i + 1) / 2 + j
+  long long offTT;   // packed lower-triangular per-item matrices (Linv, Vt): R * sum_{k'<k} PT_k', element (r, i, j <= i) at offTT + r PT + sv_tri_off(i) + j
+  int PT;            // doubles per packed item: rows padded to an even length (sv_tri_off(M))
   int colM;    // sum_{k'<k} M_k'
   int thoff;   // sum_{k'<k} nth_k'
   double scale2, inv_ls_scale, inv_p_scale;
 };
+
+// Row offset in a packed lower triangle whose rows are padded to an EVEN number of doubles (the pad element is a zero the
+// producer writes): every (i, 2p), (i, 2p + 1) pair is 16 aligned bytes, so a row can be copied in 16-byte pieces --
+// what the LDS-DMA staging of the large factors needs (kernels_mfma.h stage_matrix_dma).
+__host__ __device__ constexpr int sv_tri_off(int i) { return i * (i + 1) / 2 + ((i + 1) >> 1); }
 
 struct LatentPtrs {
   const double* mean;

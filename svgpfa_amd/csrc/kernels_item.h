@@ -76,7 +76,7 @@ __global__ __launch_bounds__(64) void k_build_reg(EngineView ev, int write_aux, 
   const int M = m.M;
   const KPar p = make_kpar(m, snap ? st.theta[k] : ev.theta + 2 * k);
   const long long base = m.offMM + (long long)r * M * M;
-  const long long tbase = m.offTT + (long long)r * m.P;
+  const long long tbase = m.offTT + (long long)r * m.PT;
   const double* z = (snap ? st.Z[k] : ev.Zs + m.offM) + (long long)r * M;
   const bool rowok = i < M;
   const double zi = rowok ? z[i] : 0.0;
@@ -147,7 +147,8 @@ __global__ __launch_bounds__(64) void k_build_reg(EngineView ev, int write_aux, 
 #pragma unroll
     for (int q = 0; q < MP; ++q)
       if (q < M) {
-        if (i <= q) ev.Linv[tbase + q * (q + 1) / 2 + i] = x[q];   // column i of the packed lower triangle: lanes write consecutive addresses
+        if (i <= q) ev.Linv[tbase + sv_tri_off(q) + i] = x[q];     // column i of the packed lower triangle: lanes write consecutive addresses
+        if (i == q && !(q & 1)) ev.Linv[tbase + sv_tri_off(q) + q + 1] = 0.0;   // the pad of an odd-length row
         if (write_aux) ev.L[base + i * M + q] = a[q];            // row i
       }
   }

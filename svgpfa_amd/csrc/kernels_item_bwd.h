@@ -418,7 +418,7 @@ __device__ __forceinline__ void item_bwd_body(const EngineView& ev, const int r,
   constexpr bool DSEP = NT >= 3 && FULL;   // D in its own buffer
   double* Dl = sm + lay.Dl;
   const KPar p = make_kpar(m, ev.theta + 2 * k);
-  const long long base = m.offTT + (long long)r * m.P;       // Vt: packed lower triangle
+  const long long base = m.offTT + (long long)r * m.PT;      // Vt: packed lower triangle
   const long long vbase = m.offM + (long long)r * M;
   const bool want_lat = (mask & (1u | 4u | 8u)) != 0;
   const bool want_zt = (mask & (4u | 8u)) != 0;
@@ -625,7 +625,7 @@ __device__ __forceinline__ void item_bwd_body(const EngineView& ev, const int r,
 #pragma unroll
       for (int u = 0; u < VPF; ++u) {
         const int e = tid + u * NTHB, i = e / MP, j = e % MP;
-        vpf[u] = (e < MP * MP && i < M && j <= i) ? ev.Vt[base + i * (i + 1) / 2 + j] : 0.0;
+        vpf[u] = (e < MP * MP && i < M && j <= i) ? ev.Vt[base + sv_tri_off(i) + j] : 0.0;
       }
     }
 

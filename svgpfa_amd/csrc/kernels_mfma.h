@@ -71,7 +71,7 @@ __device__ __forceinline__ void stage_matrix(double* dst, const double* src, int
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       const int e = e0 + u * nth, i = e / MP, j = e % MP;
-      v[u] = (e < MP * MP && i < M && j <= i) ? src[i * (i + 1) / 2 + j] : 0.0;     // src: packed lower triangle
+      v[u] = (e < MP * MP && i < M && j <= i) ? src[sv_tri_off(i) + j] : 0.0;     // src: packed lower triangle
     }
 #pragma unroll
     for (int u = 0; u < U; ++u) {
@@ -81,12 +81,33 @@ __device__ __forceinline__ void stage_matrix(double* dst, const double* src, int
   }
 }
 
+// The same image by LDS-DMA (global_load_lds, 16 bytes per lane: every wave instruction fills 128 consecutive doubles of
+// the padded image; the source address is per lane, so pairs above the diagonal and the row padding come from zeros in
+// global memory, and the pair that holds a diagonal element of an odd-length row ends in the pad zero its producer wrote):
+// no registers, every load of a matrix in flight at once.  For M > 32, where a block is alone on its CU and the
+// register-staged form -- batches of four loads, each waited for -- left the staging of the two 32-KB factors as 10 of the
+// block's 73 us at cfg5 (cycle stamps, -DSV_BWD_CLK; with 4-byte pieces the DMA took 11: 132 instructions per matrix).
+// The caller waits (vmcnt) and synchronises before reading.
+__device__ __attribute__((aligned(16))) const double sv_zero_pad[2] = {0.0, 0.0};
+template <int NT>
+__device__ __forceinline__ void stage_matrix_dma(double* dst, const double* src, int M, int tid, int nth) {
+  constexpr int MP = 16 * NT, LD = MP + 2, TOT2 = MP * LD / 2;       // pairs of doubles in the image (LD is even)
+  const int lane = tid & 63, wave = tid >> 6, nw = nth >> 6;
+  for (int c = wave; c * 64 < TOT2; c += nw) {
+    const int e2 = c * 64 + lane, i = (2 * e2) / LD, j = (2 * e2) % LD;
+    if (e2 < TOT2) {
+      const double* g = (i < M && j <= i) ? src + sv_tri_off(i) + j : sv_zero_pad;
+      __builtin_amdgcn_global_load_lds((const void*)g, (__attribute__((address_space(3))) void*)(dst + c * 128), 16, 0, 0);
+    }
+  }
+}
+
 template <int NT>
 __device__ __forceinline__ void load_factors(const EngineView& ev, const LatentMeta& m, int r, double* Li,
                                              double* Vl, double* ul, double* zl, bool want_v) {
   constexpr int MP = 16 * NT;
   const int M = m.M, tid = threadIdx.x;
-  const long long base = m.offTT + (long long)r * m.P;       // Linv, Vt: packed lower triangles
+  const long long base = m.offTT + (long long)r * m.PT;      // Linv, Vt: packed lower triangles
   const long long vbase = m.offM + (long long)r * M;
   if (NT <= 2 && want_v) {
     // both factors and the two vectors requested before anything is stored: ONE exposed memory latency instead of one
@@ -104,8 +125,8 @@ __device__ __forceinline__ void load_factors(const EngineView& ev, const LatentM
       for (int u = 0; u < 8; ++u) {
         const int e = e0 + u * nth, i = e / MP, j = e % MP;
         const bool ok = e < MP * MP && i < M && j <= i;
-        a[u] = ok ? sl[i * (i + 1) / 2 + j] : 0.0;
-        b[u] = ok ? sv[i * (i + 1) / 2 + j] : 0.0;
+        a[u] = ok ? sl[sv_tri_off(i) + j] : 0.0;
+        b[u] = ok ? sv[sv_tri_off(i) + j] : 0.0;
       }
 #pragma unroll
       for (int u = 0; u < 8; ++u) {
@@ -120,6 +141,18 @@ __device__ __forceinline__ void load_factors(const EngineView& ev, const LatentM
       ul[tid] = uv;
       zl[tid] = zv;
     }
+    return;
+  }
+  if (NT >= 3) {
+    const double uv = (tid < M) ? ev.ut[vbase + tid] : 0.0;
+    const double zv = (tid < M) ? ev.Zs[vbase + tid] : 0.0;
+    stage_matrix_dma<NT>(Li, ev.Linv + base, M, tid, (int)blockDim.x);
+    if (want_v) stage_matrix_dma<NT>(Vl, ev.Vt + base, M, tid, (int)blockDim.x);
+    if (tid < MP) {
+      ul[tid] = uv;
+      zl[tid] = zv;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the DMA pieces have landed (a barrier follows in every caller)
     return;
   }
   stage_matrix<NT>(Li, ev.Linv + base, M, tid, (int)blockDim.x);
@@ -263,7 +296,7 @@ __global__ __launch_bounds__(64 * NT) void k_prep_mfma(EngineView ev, LatentPtrT
   double* Ls = Li + MP * LD;     // MP*LD
   double* red = Ls + MP * LD;    // NT
   double* wsc = red + NT;        // 64 + SV_PRE_LDS (want_w)
-  const long long base = m.offTT + (long long)r * m.P;       // Linv, Vt: packed lower triangles
+  const long long base = m.offTT + (long long)r * m.PT;      // Linv, Vt: packed lower triangles
   const long long vbase = m.offM + (long long)r * M;
   const double* cv = pt.cholvec + (long long)r * m.P;
   stage_matrix<NT>(Li, ev.Linv + base, M, tid, NTH);
@@ -296,7 +329,8 @@ __global__ __launch_bounds__(64 * NT) void k_prep_mfma(EngineView ev, LatentPtrT
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         int i = 16 * a + 4 * q + lg, j = 16 * c + li;
-        if (i < M && j <= i) ev.Vt[base + i * (i + 1) / 2 + j] = V[a][q];     // (Vt = Linv L_S is lower triangular)
+        if (i < M && j <= i) ev.Vt[base + sv_tri_off(i) + j] = V[a][q];       // (Vt = Linv L_S is lower triangular)
+        if (i < M && j == i && !(i & 1)) ev.Vt[base + sv_tri_off(i) + i + 1] = 0.0;   // the pad of an odd-length row
         part = fma(V[a][q], V[a][q], part);
       }
   }

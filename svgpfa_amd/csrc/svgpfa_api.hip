@@ -210,6 +210,7 @@ int svgpfa_create(const svgpfa_dims* d, int device, svgpfa_engine** out) {
     m.M = d->n_ind[k];
     if (m.M <= 0 || m.M > SV_MAX_M) FAIL(e, SVGPFA_ERR_UNSUPPORTED, "inducing points per latent must be in 1..64");
     m.P = m.M * (m.M + 1) / 2;
+    m.PT = sv_tri_off(m.M);
     m.ktype = d->kernel_type[k];
     if (m.ktype != SV_RBF && m.ktype != SV_PERIODIC) FAIL(e, SVGPFA_ERR_INVALID, "unknown kernel type");
     m.nth = (m.ktype == SV_RBF) ? 1 : 2;
@@ -220,7 +221,7 @@ int svgpfa_create(const svgpfa_dims* d, int device, svgpfa_engine** out) {
     m.inv_p_scale = 1.0 / (d->period_scale ? d->period_scale[k] : 1.0);
     offM += (long long)v.R * m.M;
     offMM += (long long)v.R * m.M * m.M;
-    offTT += (long long)v.R * m.P;
+    offTT += (long long)v.R * m.PT;
     colM += m.M;
     thoff += m.nth;
     e->Mmax = std::max(e->Mmax, m.M);
