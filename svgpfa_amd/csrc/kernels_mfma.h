@@ -299,7 +299,8 @@ __global__ __launch_bounds__(64 * NT) void k_prep_mfma(EngineView ev, LatentPtrT
   const long long base = m.offTT + (long long)r * m.PT;      // Linv, Vt: packed lower triangles
   const long long vbase = m.offM + (long long)r * M;
   const double* cv = pt.cholvec + (long long)r * m.P;
-  stage_matrix<NT>(Li, ev.Linv + base, M, tid, NTH);
+  if (NT >= 3) stage_matrix_dma<NT>(Li, ev.Linv + base, M, tid, NTH);     // (lands behind the loads below; the barrier waits)
+  else stage_matrix<NT>(Li, ev.Linv + base, M, tid, NTH);
   for (int e0 = tid; e0 < MP * MP; e0 += 4 * NTH) {      // L_S from the row-major tril vector, four loads in flight
     double v[4];
 #pragma unroll
@@ -313,6 +314,7 @@ __global__ __launch_bounds__(64 * NT) void k_prep_mfma(EngineView ev, LatentPtrT
       if (e < MP * MP) Ls[i * LD + j] = v[u];
     }
   }
+  if (NT >= 3) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the DMA pieces of Linv have landed
   __syncthreads();
 
   // panel c of L_S -> Vt ; |Vt|_F^2
