@@ -13,18 +13,20 @@
 // A spike then costs 6 fp64 instructions per harmonic and CLASS (8 with the time-weighted moments) instead of 8..10 per
 // harmonic and LATENT (round 2's spike_body_series), and there is no per-spike embedding gather at all.
 //
-// Kernels (launched in this order, all on the spike stream):
-//   k_spike_classes (with the kernel build)  class table; per (trial, class) window / period / harmonics; ser[r][k]
-//   k_spike_pre     (r, k)        W = s2 c_n (Abar_n, Bbar_n): the posterior-mean weights a projected on the harmonics
-//                                 (only when dC is wanted; needs a = Kzz^-1 m from k_prep)
-//   k_spike_cls     (tile, class) U for the tile's <= 64 rows (lane = row = one (trial, neuron) segment or half of one,
-//                                 harmonics in registers), A-moment partials by f64 MFMA through an LDS transpose, dC rows
-//   k_spike_comb    (r, k)        sums the tiles' partials (fixed order) and combines them per inducing point: P0, P1, T of
-//                                 the item -- what k_item_bwd's gather reads.  On small shards, where every launch is one
-//                                 under-filled round and the spike path is the critical chain, the gather does this
-//                                 combine itself instead (ev.comb_fold; kernels_item_bwd.h gather_item_inputs): one launch
-//                                 and one dependency less, at the price of ~2.5 us per k_item_bwd block (which is why the
-//                                 full-size problem keeps the separate kernel: 262 -> 288 us against 11.5 us measured)
+// Steps (in this order, on the evaluation's one stream):
+//   class table   class table; per (trial, class) window / period / harmonics; ser[r][k] -- rider blocks of k_build_reg
+//                 (spike_cls_common.h; k_spike_classes when the spikes arrive after the kernel build)
+//   W             (r, k): W = s2 c_n (Abar_n, Bbar_n): the posterior-mean weights a projected on the harmonics (only when
+//                 dC is wanted; needs a = Kzz^-1 m) -- a rider of k_prep's wave 0 (k_spike_pre in the statistics calls)
+//   k_spike_cls   (tile, class): U for the tile's <= 64 rows (lane = row = one (trial, neuron) segment or half of one,
+//                 harmonics in registers), A-moment partials by f64 MFMA through an LDS transpose, dC rows; one kernel per
+//                 kind of class (with / without time-weighted moments) on large problems, both in one launch on shards
+//                 (k_spike_cls_all)
+//   k_spike_comb  (r, k): sums the tiles' partials (fixed order) and combines them per inducing point: P0, P1, T of the
+//                 item -- what k_item_bwd's gather reads.  On small shards, where every launch is one under-filled round,
+//                 the gather does this combine itself instead (ev.comb_fold; kernels_item_bwd.h gather_item_inputs): one
+//                 launch less, at the price of ~2.5 us per k_item_bwd block (which is why the full-size problem keeps the
+//                 separate kernel: 262 -> 288 us against 11.5 us measured)
 // (trial, latent) items the series does not serve (short lengthscales, very few inducing points) keep the pair-by-pair
 // pass of kernels_spike.h; ser[r][k] says which.
 // Replaces the reference's K*R Python loop of kernelsMatricesStore.py:208-221, svPosteriorOnLatents.py:265-300 and
