@@ -368,7 +368,7 @@ def main():
 
     import torch
     import torch.distributed as dist
-    from svgpfa_amd.distributed import allreduce_shared
+    from svgpfa_amd.distributed import allreduce_shared_async
     from svgpfa_amd.engine import engine_from_problem
     from svgpfa_amd.utils import synthetic
 
@@ -400,12 +400,30 @@ def main():
     if args.estep_cache and args.variant == "estep":
         eng.set_embedding_token(1)
 
+    # N > 1: consecutive evaluations write alternating `shared` buffers and their all-reduce is enqueued without blocking
+    # the compute stream, so the exchange of evaluation i (17.7 KB, latency-bound, two cross-stream edges) runs beside the
+    # kernels of evaluation i + 1; a buffer is waited for before it is written again, and all of them before the clock stops.
+    bufs = [shared, torch.empty_like(shared)] if use_dist else [shared]
+    works = [None] * len(bufs)
+    nstep = [0]
+
     def step():
+        b = nstep[0] % len(bufs)
+        nstep[0] += 1
+        if works[b] is not None:
+            works[b].wait()
+            works[b] = None
         if args.variant == "all":
             eng.build_kernels(P["Z"], P["theta"])
-        eng.elbo(P["mean"], P["cholVecs"], P["C"], P["d"], mask, out=shared, grads=grads)
+        eng.elbo(P["mean"], P["cholVecs"], P["C"], P["d"], mask, out=bufs[b], grads=grads)
         if use_dist:
-            allreduce_shared(shared)   # RCCL sum of [ELBO, ELL, KL, dC, dd, dtheta]
+            works[b] = allreduce_shared_async(bufs[b])   # RCCL sum of [ELBO, ELL, KL, dC, dd, dtheta]
+
+    def drain():
+        for b in range(len(bufs)):
+            if works[b] is not None:
+                works[b].wait()
+                works[b] = None
 
     # Python's cyclic collector, left alone, runs a full (generation 2) pass over everything torch's import left on the heap
     # some tens of evaluations into the loop -- 40 ms, 400 steps' worth at cfg2 (tests/tools/step_jitter.py).  The heap as
@@ -419,9 +437,11 @@ def main():
     # W warm-up steps then run at steady state even when W is small
     for _ in range(30):
         step()
+    drain()
     eng.sync()
     for _ in range(args.warmup):
         step()
+    drain()
     eng.sync()
     eng.enable_timing(True)
     if use_dist:
@@ -430,6 +450,7 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
+    drain()
     torch.cuda.synchronize()
     if use_dist:
         dist.barrier()
@@ -438,7 +459,7 @@ def main():
     item_ms, item_launches = eng.kernel_ms(1)
     eng.enable_timing(False)
     eng.sync()
-    elbo = float(shared[0])
+    elbo = float(bufs[(nstep[0] - 1) % len(bufs)][0])
 
     if use_dist:
         t = torch.tensor([elapsed, spike_ms / max(launches, 1), item_ms / max(item_launches, 1)], dtype=torch.float64,
@@ -499,7 +520,8 @@ def main():
                        "variant": "ALL (rebuild kernels + ELBO + 4 gradient groups)" if args.variant == "all"
                        else ("E-step (ELBO + variational gradients)"
                                          + (", spike sums reused across evaluations" if args.estep_cache else "")),
-                       "parallelism": f"trials sharded {world}-way by spike count, 1 RCCL all-reduce/step" if world > 1 else "single GPU"},
+                       "parallelism": f"trials sharded {world}-way by spike count, 1 RCCL all-reduce/step (enqueued beside the next evaluation)"
+                       if world > 1 else "single GPU"},
             "elbo": elbo,
             "roofline": None,
             "roofline_spike": {"bound": spike_bound, "achieved": achieved, "peak": peak,

@@ -22,6 +22,19 @@ def allreduce_shared(shared, group=None):
     return shared
 
 
+def allreduce_shared_async(shared, group=None):
+    """The same sum, enqueued without blocking the caller's stream: returns a work handle whose wait() makes the current
+    stream wait for the result (None when there is nothing to wait for: one rank, or the gloo rehearsal, which is
+    synchronous).  For callers that can use the result later than the next launch -- a loop of independent evaluations into
+    alternating output buffers -- the exchange then overlaps with the following evaluation's kernels."""
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+        if shared.is_cuda and dist.get_backend(group) == "gloo":
+            allreduce_shared(shared, group)
+            return None
+        return dist.all_reduce(shared, op=dist.ReduceOp.SUM, group=group, async_op=True)
+    return None
+
+
 def agree_max(flag, group=None):
     """Maximum of a small non-negative int over ranks (every rank gets it): used to agree on a rank-local failure
     (a non positive-definite Kzz of ONE rank's trials) so that all ranks raise together instead of one rank leaving
