@@ -121,3 +121,46 @@ def test_two_rank_gloo_sharded_sum_equals_full_problem():
         p.join(timeout=180)
         assert p.exitcode == 0
     assert q.get(timeout=5) < 1e-12
+
+
+def _rank_async(rank, world, port, q):
+    import torch
+    import torch.distributed as dist
+    sys.path.insert(0, REPO)
+    from svgpfa_amd import distributed
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    # bench.py's N > 1 loop: alternating output buffers, the exchange of evaluation i waited for only before buffer
+    # i % 2 is written again (and at the end)
+    bufs, works, got = [torch.zeros(6, dtype=torch.float64) for _ in range(2)], [None, None], []
+    for i in range(7):
+        b = i % 2
+        if works[b] is not None:
+            works[b].wait()
+            got.append(bufs[b].clone())
+        bufs[b].copy_(torch.arange(6, dtype=torch.float64) * (i + 1) + rank)      # this rank's "evaluation" i
+        works[b] = distributed.allreduce_shared_async(bufs[b])
+    for b in ((7 % 2), (8 % 2)):                                                   # drain in the order they were enqueued
+        if works[b] is not None:
+            works[b].wait()
+            got.append(bufs[b].clone())
+    if rank == 0:
+        want = [torch.arange(6, dtype=torch.float64) * (i + 1) * world + sum(range(world)) for i in range(7)]
+        q.put(max(float((g - w).abs().max()) for g, w in zip(got, want)) if len(got) == 7 else -1.0)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_gloo_async_exchange_with_alternating_buffers():
+    import torch.multiprocessing as mp
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_rank_async, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(timeout=180)
+        assert p.exitcode == 0
+    assert q.get(timeout=5) == 0.0
