@@ -11,7 +11,14 @@ the named synthetic workload (seeded), inputs already resident i
                     the closure of the reference's svEM.py:218-223
 With N > 1 (launched by torch.distributed.run, one rank per GPU) the 500 trials are sharded by
 spike count across ranks (total work fixed: "strong" scaling) and every step ends with ONE RCCL
-all-reduce of the shared vector [ELBO, ELL, KL, dC, dd, dtheta].
+all-reduce of the shared vector [ELBO, ELL, KL, dC, dd, dtheta].  `value` is the BLOCKING form
+(svgpfa_amd.distributed.allreduce_shared: the compute stream waits for the reduced vector before the
+next evaluation starts -- what an optimiser's closure needs, reference stats/svEM.py:274-294); two
+more loops of K steps each run behind the headline's timed region and are reported beside it:
+`value_host_synced` (the host also waits for the reduced vector every step, as a closure that reads
+the bound does) and `value_pipelined` (alternating output buffers, the exchange of evaluation i
+enqueued beside the kernels of evaluation i + 1: throughput of INDEPENDENT evaluations, an upper
+bound no dependent loop reaches).
 
 Rank 0 prints one JSON line.  Extra objects:
   roofline     : the kernel with the largest device time in this run -- k_item_bwd (f64 MFMA + VALU) since
@@ -359,6 +366,10 @@ def main():
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="collective backend; gloo + --single-device rehearses the N > 1 path on a one-GPU box")
     ap.add_argument("--single-device", action="store_true", help="every rank uses cuda:0 (rehearsal only)")
+    ap.add_argument("--theta-spread", action="store_true",
+                    help="kernel parameters as a kernel M-step leaves them (synthetic.spread_theta: every periodic latent "
+                         "its own period, RBF lengthscales 0.2 .. 0.9) instead of SURVEY 8(d)'s one value per type: the "
+                         "worst case of the spike pass's class path (not the headline)")
     ap.add_argument("--estep-cache", action="store_true",
                     help="E-step variant only: let value-only evaluations reuse the spike sums while C, Z, theta are "
                          "unchanged (svgpfa_set_embedding_token), as the closure of a real E-step does")
@@ -368,7 +379,7 @@ def main():
 
     import torch
     import torch.distributed as dist
-    from svgpfa_amd.distributed import allreduce_shared_async
+    from svgpfa_amd.distributed import allreduce_shared, allreduce_shared_async
     from svgpfa_amd.engine import engine_from_problem
     from svgpfa_amd.utils import synthetic
 
@@ -390,7 +401,7 @@ def main():
         else:
             dist.init_process_group("gloo")
 
-    full = synthetic.make_config(args.config)
+    full = synthetic.make_config(args.config, theta_spread=args.theta_spread)
     prob = synthetic.shard_trials(full, rank, world) if world > 1 else full
     eng, P = engine_from_problem(prob, device=local_rank, precision="mixed" if args.dtype == "mixed" else "fp64")
     mask = 15 if args.variant == "all" else 1
@@ -400,30 +411,66 @@ def main():
     if args.estep_cache and args.variant == "estep":
         eng.set_embedding_token(1)
 
-    # N > 1: consecutive evaluations write alternating `shared` buffers and their all-reduce is enqueued without blocking
-    # the compute stream, so the exchange of evaluation i (17.7 KB, latency-bound, two cross-stream edges) runs beside the
-    # kernels of evaluation i + 1; a buffer is waited for before it is written again, and all of them before the clock stops.
-    bufs = [shared, torch.empty_like(shared)] if use_dist else [shared]
-    works = [None] * len(bufs)
+    def evaluate(out):
+        if args.variant == "all":
+            eng.build_kernels(P["Z"], P["theta"])
+        eng.elbo(P["mean"], P["cholVecs"], P["C"], P["d"], mask, out=out, grads=grads)
+
+    # Headline step.  N > 1: the evaluation, then the BLOCKING all-reduce of its shared vector -- the compute stream waits
+    # for the reduced values, so evaluation i + 1 starts behind the exchange of evaluation i, as in an optimiser loop whose
+    # next closure depends on the reduced bound and gradient (svgpfa_amd/stats: the EM closures call the same function).
+    def step():
+        evaluate(shared)
+        if use_dist:
+            allreduce_shared(shared)
+
+    def drain():
+        pass
+
+    # Supplementary N > 1 loops (not the headline).  host-synced: the host waits for the reduced vector as well.
+    def step_host_synced():
+        evaluate(shared)
+        allreduce_shared(shared)
+        torch.cuda.current_stream(dev).synchronize()
+
+    # pipelined: consecutive evaluations write alternating buffers and their all-reduce is enqueued without blocking the
+    # compute stream, so the exchange of evaluation i (17.7 KB, latency-bound) runs beside the kernels of evaluation i + 1;
+    # a buffer is waited for before it is written again, and all of them before the clock stops.
+    bufs = [shared, torch.empty_like(shared)]
+    works = [None, None]
     nstep = [0]
 
-    def step():
-        b = nstep[0] % len(bufs)
+    def step_pipelined():
+        b = nstep[0] % 2
         nstep[0] += 1
         if works[b] is not None:
             works[b].wait()
             works[b] = None
-        if args.variant == "all":
-            eng.build_kernels(P["Z"], P["theta"])
-        eng.elbo(P["mean"], P["cholVecs"], P["C"], P["d"], mask, out=bufs[b], grads=grads)
-        if use_dist:
-            works[b] = allreduce_shared_async(bufs[b])   # RCCL sum of [ELBO, ELL, KL, dC, dd, dtheta]
+        evaluate(bufs[b])
+        works[b] = allreduce_shared_async(bufs[b])
 
-    def drain():
-        for b in range(len(bufs)):
+    def drain_pipelined():
+        for b in range(2):
             if works[b] is not None:
                 works[b].wait()
                 works[b] = None
+
+    def timed_loop(fn, fin):
+        for _ in range(max(args.warmup, 3)):
+            fn()
+        fin()
+        dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            fn()
+        fin()
+        torch.cuda.synchronize()
+        dist.barrier()
+        el = time.perf_counter() - t0
+        t = torch.tensor([el], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t[0])
 
     # Python's cyclic collector, left alone, runs a full (generation 2) pass over everything torch's import left on the heap
     # some tens of evaluations into the loop -- 40 ms, 400 steps' worth at cfg2 (tests/tools/step_jitter.py).  The heap as
@@ -459,7 +506,11 @@ def main():
     item_ms, item_launches = eng.kernel_ms(1)
     eng.enable_timing(False)
     eng.sync()
-    elbo = float(bufs[(nstep[0] - 1) % len(bufs)][0])
+    elbo = float(shared[0])
+    extra = {}
+    if world > 1:
+        extra["value_host_synced"] = args.steps / timed_loop(step_host_synced, drain)
+        extra["value_pipelined"] = args.steps / timed_loop(step_pipelined, drain_pipelined)
 
     if use_dist:
         t = torch.tensor([elapsed, spike_ms / max(launches, 1), item_ms / max(item_launches, 1)], dtype=torch.float64,
@@ -520,9 +571,14 @@ def main():
                        "variant": "ALL (rebuild kernels + ELBO + 4 gradient groups)" if args.variant == "all"
                        else ("E-step (ELBO + variational gradients)"
                                          + (", spike sums reused across evaluations" if args.estep_cache else "")),
-                       "parallelism": f"trials sharded {world}-way by spike count, 1 RCCL all-reduce/step (enqueued beside the next evaluation)"
+                       "kernel_parameters": "spread (every periodic latent its own period, RBF lengthscales 0.2 .. 0.9)"
+                       if args.theta_spread else "SURVEY 8(d): one lengthscale / period per kernel type",
+                       "parallelism": f"trials sharded {world}-way by spike count, 1 BLOCKING all-reduce ({args.backend}) per "
+                                      f"evaluation: the next evaluation starts behind the exchange (value); value_host_synced: the "
+                                      f"host waits for it too; value_pipelined: exchange beside the next evaluation's kernels"
                        if world > 1 else "single GPU"},
             "elbo": elbo,
+            **extra,
             "roofline": None,
             "roofline_spike": {"bound": spike_bound, "achieved": achieved, "peak": peak,
                          "unit": "TFLOP/s", "frac": spike_frac,

@@ -206,13 +206,6 @@ int svgpfa_enable_timing(svgpfa_engine* e, int on);
 int svgpfa_kernel_ms(svgpfa_engine* e, int32_t which, double* total_ms, int32_t* launches);
 int svgpfa_spike_kernel_ms(svgpfa_engine* e, double* total_ms, int32_t* launches);
 
-/* With SVGPFA_GRAPH=1 in the environment at engine creation (off by default) svgpfa_elbo records its launch sequence
- * (kernels, side streams, events) as a HIP graph the second time it sees the same pointer arguments and gradient mask,
- * and replays it with one hipGraphLaunch into the caller's stream from then on; results are bit-identical to the plain
- * launches.  The caller keeps those buffers alive and at the same addresses, as for any enqueued evaluation.  Returns
- * the number of evaluations replayed from a graph so far (no reference counterpart: the reference runs eagerly). */
-int64_t svgpfa_graph_replays(const svgpfa_engine* e);
-
 /* ---- Vector kernels of the EM loop's optimiser -------------------------------------------------------------------
  * The reference optimises every conditional-maximisation step with torch.optim.LBFGS (stats/svEM.py:266-294); its
  * iteration is ~60 small tensor operations.  These stateless entry points (no engine: device pointers, a HIP stream,

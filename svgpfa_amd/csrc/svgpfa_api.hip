@@ -54,16 +54,10 @@ struct svgpfa_engine {
   // (wave-uniform branch): measured faster than one launch per type for the per-item kernels (+3 % on cfg3: fewer
   // launches, shorter grid tails) and, since both types of the spike pass fit 3 waves / SIMD, for the spike pass too
   // (+1.5 %; its grid lists the longer periodic work items first).
-  // Two chains between k_prep and k_item_bwd: the spike pass and the quadrature chain (k_times_fwd -> k_quad_ell).  ONE stream
-  // at every size.  SVGPFA_OVERLAP=1 puts the quadrature chain on a side stream (two cross-stream edges: prep -> times,
-  // quad_ell -> bwd) and, with two class kernels, the second on another.  Round 2 ran small shards that way (ms per evaluation
-  // of cfg3, one stream -> two: 4-way 0.384 -> 0.355, 8-way 0.236 -> 0.230); with this round's kernels one stream wins at
-  // every size (8-way 0.176 against 0.181): an edge that crosses streams costs 12-20 us at the end of a chain, the class
-  // kernels fill every wave slot of the chip, and kernels side by side slow each other down.
-  int side_stream = -1;
-  hipStream_t s_side = nullptr, s_side2 = nullptr;   // SVGPFA_OVERLAP=1: quadrature chain / second class kernel beside the main stream
-  hipEvent_t ev_prep = nullptr, ev_quad = nullptr, ev_fork = nullptr, ev_join = nullptr;
-  bool fork_always = false;                     // SVGPFA_FORK=1: the two class kernels on two streams at every size (experiment)
+  // ONE stream at every size.  (Rounds 2-3 measured the quadrature chain or the second class kernel on side streams and
+  // the whole evaluation replayed as a HIP graph: an edge that crosses streams costs 12-20 us at the end of a chain, the
+  // class kernels fill every wave slot of the chip, kernels side by side slow each other down, and a graph's branches run
+  // through the same queues and barrier packets -- all removed in round 4)
   // Both kinds of class (with / without time-weighted moments) in ONE launch: default up to R K = 4096 items (one launch
   // boundary -- a drained chip -- less: one rank's shard of cfg3, ms per evaluation, two kernels -> one: 2-way 0.405 -> 0.386,
   // 4-way 0.266 -> 0.249, 8-way 0.198 -> 0.176; at the full 5 000 items 0.655 / 0.659).  SVGPFA_CLS_FUSED=0 / 1 forces it.
@@ -72,32 +66,7 @@ struct svgpfa_engine {
   double series_min_pairs = 1e7;                // SVGPFA_SERIES_MIN_PAIRS: fewest (spike, inducing point) pairs for the class path
   bool cls_valid = false;                       // the class table of the spike pass belongs to the current kernel build
   int grid_cls = 2048, grid_pair = 2048;        // blocks of the two persistent-style spike kernels (resident waves of the chip)
-  // Graph launch of one ELBO evaluation (small shards: the evaluation's ten-odd launches, three streams and six events cost the
-  // host ~0.1 ms, more than the kernels take).  The launch sequence is captured once per (gradient mask, pointer set,
-  // with / without the class table's kernel, with / without the spike pass) on a private stream and replayed with one
-  // hipGraphLaunch into the caller's stream.  SVGPFA_GRAPH=1 turns it on; off by default: on this runtime a replay's
-  // dependency edges cost what the events of the plain launches cost (8-way shard of cfg3 0.186 plain / 0.190 replayed,
-  // 4-way 0.264 / 0.247, cfg2 0.080 / 0.075 ms per evaluation), it only halves the host's time per evaluation.
-  int graph_mode = -1;
-  hipStream_t s_cap = nullptr;
-  struct GraphSlot {
-    std::vector<uint64_t> key;
-    hipGraphExec_t exec = nullptr;
-    uint64_t used = 0;
-  };
-  std::vector<GraphSlot> graphs;
-  std::vector<std::vector<uint64_t>> graph_seen;   // keys evaluated once with plain launches: a graph is recorded at a key's second sight
-  uint64_t graph_clock = 0;
-  int64_t graph_replays = 0;
 };
-#define SV_GRAPH_SLOTS 8
-
-static void drop_graphs(svgpfa_engine* e) {
-  for (auto& g : e->graphs)
-    if (g.exec) (void)hipGraphExecDestroy(g.exec);
-  e->graphs.clear();
-  e->graph_seen.clear();
-}
 
 #define HIPCHK(e, call)                                                                  \
   do {                                                                                   \
@@ -296,21 +265,13 @@ int svgpfa_create(const svgpfa_dims* d, int device, svgpfa_engine** out) {
   HIPCHK(e, hipMemset(v.fin_ticket, 0, sizeof(unsigned)));
   DALLOC(e, v.fin_part, 2 + SV_FIN_NS);
   HIPCHK(e, hipHostMalloc((void**)&e->status_host, sizeof(int)));
-  HIPCHK(e, hipStreamCreateWithFlags(&e->s_side, hipStreamNonBlocking));
-  HIPCHK(e, hipStreamCreateWithFlags(&e->s_side2, hipStreamNonBlocking));
-  HIPCHK(e, hipStreamCreateWithFlags(&e->s_cap, hipStreamNonBlocking));
-  if (getenv("SVGPFA_GRAPH")) e->graph_mode = atoi(getenv("SVGPFA_GRAPH")) != 0 ? 1 : 0;
   if (getenv("SVGPFA_CLS_FUSED")) e->cls_fused = atoi(getenv("SVGPFA_CLS_FUSED")) != 0 ? 1 : 0;
   {
-    const char* ov = getenv("SVGPFA_OVERLAP");
-    if (ov) e->side_stream = atoi(ov) != 0 ? 1 : 0;
     // diagnosis / test switches: kernels of a type pair by pair in the spike pass instead of through their cosine series
     const char* rs = getenv("SVGPFA_RBF_SERIES");
     v.rbf_series = (rs && atoi(rs) == 0) ? 0 : 1;
     const char* mp = getenv("SVGPFA_SERIES_MIN_PAIRS");
     if (mp) e->series_min_pairs = atof(mp);
-    const char* fk = getenv("SVGPFA_FORK");
-    e->fork_always = fk && atoi(fk) != 0;
     const char* ps = getenv("SVGPFA_PERIODIC_SERIES");
     v.per_series = (ps && atoi(ps) == 0) ? 0 : 1;
   }
@@ -324,8 +285,6 @@ int svgpfa_create(const svgpfa_dims* d, int device, svgpfa_engine** out) {
     e->grid_cls = std::max(8, prop.multiProcessorCount * std::max(1, bc));
     e->grid_pair = std::max(8, (prop.multiProcessorCount * std::max(1, bp)) & ~7);
   }
-  for (hipEvent_t* ev : {&e->ev_prep, &e->ev_quad, &e->ev_fork, &e->ev_join})
-    HIPCHK(e, hipEventCreateWithFlags(ev, hipEventDisableTiming));
 
   int rc = 0;
   DISPATCH_NT(e->NT, rc = allow_lds(e, (k_prep_mfma<NT_>), lds_prep_mfma(NT_));
@@ -350,11 +309,6 @@ void svgpfa_destroy(svgpfa_engine* e) {
   (void)hipDeviceSynchronize();
   for (void* p : e->allocs) (void)hipFree(p);
   if (e->status_host) (void)hipHostFree(e->status_host);
-  drop_graphs(e);
-  for (hipStream_t st : {e->s_side, e->s_side2, e->s_cap})
-    if (st) (void)hipStreamDestroy(st);
-  for (hipEvent_t ev : {e->ev_prep, e->ev_quad, e->ev_fork, e->ev_join})
-    if (ev) (void)hipEventDestroy(ev);
   for (auto& pr : e->ev_pool) {
     (void)hipEventDestroy(pr.first);
     (void)hipEventDestroy(pr.second);
@@ -392,7 +346,6 @@ int svgpfa_sync(svgpfa_engine* e) {
 int svgpfa_set_reg(svgpfa_engine* e, double eps) {
   if (!e) return SVGPFA_ERR_INVALID;
   e->v.reg = eps;
-  drop_graphs(e);     // captured launches carry the view by value
   return SVGPFA_OK;
 }
 
@@ -544,7 +497,10 @@ int svgpfa_set_spikes(svgpfa_engine* e, const int64_t* off, const double* times,
   v.nrows = (int)rows.size();
   v.ntiles = (int)tiles.size();
   v.nsplitS = (int)sS_neuron.size();
-  std::vector<double> tt((size_t)(tt_len + 4 * 64), 0.0);   // one prefetch group of padding (k_spike_cls reads ahead)
+  // k_spike_cls's pass loads rows 0 .. 3 unconditionally and, in every iteration i0 < maxlen, rows i0 + 4 .. i0 + 7: the
+  // highest row read of a tile is 4 ceil(maxlen / 4) + 3 <= maxlen + 6, i.e. up to 7 rows past the tile (maxlen = 1), so
+  // two prefetch groups of padding behind the last tile (sv_cls_tt_pad; checked by tests/test_cpu_host.py)
+  std::vector<double> tt((size_t)(tt_len + SV_CLS_TT_PAD), 0.0);
   for (const SpikeTile& tl : tiles)
     for (int l = 0; l < tl.nrows; ++l) {
       const SpikeRow& rw = rows[tl.row0 + l];
@@ -646,8 +602,6 @@ static void launch_build(svgpfa_engine* e, int write_aux, const SnapTable* snap,
 
 // Classes of the spike pass's class path for the current kernel snapshot (needs the spikes' windows): they ride in the
 // kernel build's launch (launch_build); this separate kernel serves a build that ran before the spikes were set.
-static bool graph_default(const svgpfa_engine* e) { return !e->timing && e->graph_mode == 1; }
-
 static void launch_classes(svgpfa_engine* e) {
   hipLaunchKernelGGL(k_spike_classes, dim3((e->v.R + 3) / 4), dim3(256), 0, e->stream, e->v);
   e->cls_valid = true;
@@ -761,8 +715,6 @@ static int launch_times_quad(svgpfa_engine* e, hipStream_t st) {
 #define SV_EV_POOL_MAX 4096
 static int fold_events(svgpfa_engine* e) {
   HIPCHK(e, hipStreamSynchronize(e->stream));
-  for (hipStream_t st : {e->s_side, e->s_side2})
-    if (st) HIPCHK(e, hipStreamSynchronize(st));      // the event pairs live there when the pass is overlapped
   for (size_t i = 0; i < e->ev_used; ++i) {
     float ms = 0.f;
     HIPCHK(e, hipEventElapsedTime(&ms, e->ev_pool[i].first, e->ev_pool[i].second));
@@ -813,57 +765,33 @@ static void launch_pair_pass(svgpfa_engine* e, hipStream_t sk, bool full, bool w
 // wanted (only with full); have_w: k_prep made the class path's W (else k_spike_pre does, here).  Class path (cosine
 // series, kernels_spike_cls.h) for the (trial, latent) items it serves, the pair-by-pair pass (kernels_spike.h) for the
 // rest; both stride fixed grids over work lists that live on the device.
-// may_fork (SVGPFA_OVERLAP=1, two class kernels): the class kernel of the time-weighted moments on s_side2, beside the other
-// one; ev_w is an event on the stream that made W and the class table (recorded by the caller behind k_prep when have_w).
-static void launch_spike_pass(svgpfa_engine* e, hipStream_t sk, bool full, bool want_c, const double* C, bool have_w,
-                              bool may_fork, hipEvent_t ev_w) {
+static void launch_spike_pass(svgpfa_engine* e, hipStream_t sk, bool full, bool want_c, const double* C, bool have_w) {
   EngineView& v = e->v;
   const dim3 bs(64);
   const dim3 gi(v.R * v.K);
   const dim3 gc((unsigned)std::min<long long>((long long)v.ntiles * v.K, e->grid_cls));
-  bool joined = true;
   if (v.ntiles > 0 && e->cls_on) {
     // one launch for all classes (shards), or the classes with time-weighted moments (periodic, when Z / theta gradients are
     // wanted) in a kernel of their own
     const bool fused = e->cls_fused == 1 || (e->cls_fused < 0 && (long long)v.R * v.K <= 4096);
     const bool tw = !fused && full && v.ntype[SV_PERIODIC] > 0;
-    const bool fork = tw && (may_fork || e->fork_always);
-    hipStream_t s4 = fork ? e->s_side2 : sk;
     if (full && want_c && !have_w) hipLaunchKernelGGL(k_spike_pre, gi, bs, 0, sk, v);
-    if (fork) {
-      // (both forks of a capture start at its origin stream and join it again: a stream forked from a forked stream and
-      // joined back to THAT sends hipStreamEndCapture of the HIP runtime bundled with PyTorch 2.10 (ROCm 7.0) into endless
-      // recursion -- tests/tools/hipgraph_probe, pattern D)
-      if (!(have_w && ev_w)) {
-        (void)hipEventRecord(e->ev_fork, sk);
-        ev_w = e->ev_fork;
-      }
-      (void)hipStreamWaitEvent(s4, ev_w, 0);
-    }
     if (fused) {
       if (full && want_c) hipLaunchKernelGGL((k_spike_cls_all<1>), gc, bs, 0, sk, v, C, 1);
       else hipLaunchKernelGGL((k_spike_cls_all<0>), gc, bs, 0, sk, v, C, full ? 1 : 0);
     } else if (full && want_c) {
-      if (tw) hipLaunchKernelGGL((k_spike_cls<4, 1>), gc, bs, 0, s4, v, C, 1);
+      if (tw) hipLaunchKernelGGL((k_spike_cls<4, 1>), gc, bs, 0, sk, v, C, 1);
       hipLaunchKernelGGL((k_spike_cls<2, 1>), gc, bs, 0, sk, v, C, 1);
     } else {
-      if (tw) hipLaunchKernelGGL((k_spike_cls<4, 0>), gc, bs, 0, s4, v, C, 1);
+      if (tw) hipLaunchKernelGGL((k_spike_cls<4, 0>), gc, bs, 0, sk, v, C, 1);
       hipLaunchKernelGGL((k_spike_cls<2, 0>), gc, bs, 0, sk, v, C, full ? 1 : 0);
-    }
-    if (fork) {
-      (void)hipEventRecord(e->ev_join, s4);
-      joined = false;
     }
   }
   if (!v.comb_fold && e->cls_on) {
-    if (!joined) (void)hipStreamWaitEvent(sk, e->ev_join, 0);
-    joined = true;
     if (full) hipLaunchKernelGGL(k_spike_comb<true>, gi, bs, 0, sk, v);
     else hipLaunchKernelGGL(k_spike_comb<false>, gi, bs, 0, sk, v);
   }
   launch_pair_pass(e, sk, full, want_c, C);
-  // (combine folded into k_item_bwd's gather: the forked kernel is joined behind the pair kernel, which does not need it)
-  if (!joined) (void)hipStreamWaitEvent(sk, e->ev_join, 0);
 }
 
 static int check_ready(svgpfa_engine* e) {
@@ -873,10 +801,10 @@ static int check_ready(svgpfa_engine* e) {
   return SVGPFA_OK;
 }
 
-// The launches of one ELBO evaluation, main chain on e->stream (the capture stream when a graph is being recorded).
+// The launches of one ELBO evaluation, all on e->stream.
 struct ElboPlan {
   unsigned mask;
-  bool want_lat, full, side, run_spike;
+  bool want_lat, full, run_spike;
 };
 static int enqueue_elbo(svgpfa_engine* e, const PtrTable& pt, const ElboPlan& pl, const double* C, const double* d,
                         double* shared) {
@@ -888,29 +816,15 @@ static int enqueue_elbo(svgpfa_engine* e, const PtrTable& pt, const ElboPlan& pl
   // the class path's W rides in k_prep when this evaluation's spike pass wants dC
   const bool have_w = pl.run_spike && pl.full && (mask & 2u) && e->cls_on && v.ntiles > 0;
   launch_prep(e, pt, have_w);
-  // SVGPFA_OVERLAP=1 (pl.side): the quadrature chain (f64 MFMA: posterior stats -> ELL term) on a side stream beside the spike
-  // pass, which stays on the main stream in front of k_item_bwd.  Off by default at every size: a dependency that crosses
-  // streams costs 12-20 us at the end of a chain, and kernels side by side slow each other down.
-  hipStream_t sq = pl.side ? e->s_side : sm;
-  if (pl.side) {
-    HIPCHK(e, hipEventRecord(e->ev_prep, sm));
-    HIPCHK(e, hipStreamWaitEvent(sq, e->ev_prep, 0));
-    if ((rc = launch_times_quad(e, sq))) return rc;
-    if ((rc = launch_quad_ell(e, sq, C, d, (mask & 2u) ? 1 : 0, pl.want_lat ? 1 : 0))) return rc;
-    HIPCHK(e, hipEventRecord(e->ev_quad, sq));
-  }
   // ---- spike pass (fp64 VALU bound): needs only a = Kzz^-1 m (and W) from k_prep
   if (pl.run_spike) {
     const int evp = timing_begin(e, 0, sm);
-    launch_spike_pass(e, sm, pl.full, (mask & 2u) != 0, C, have_w, pl.side, pl.side ? e->ev_prep : nullptr);
+    launch_spike_pass(e, sm, pl.full, (mask & 2u) != 0, C, have_w);
     timing_end(e, evp, sm);
   }
-  if (!pl.side) {
-    if ((rc = launch_times_quad(e, sm))) return rc;
-    if ((rc = launch_quad_ell(e, sm, C, d, (mask & 2u) ? 1 : 0, pl.want_lat ? 1 : 0))) return rc;
-  } else {
-    HIPCHK(e, hipStreamWaitEvent(sm, e->ev_quad, 0));     // join the quadrature chain
-  }
+  // ---- quadrature chain (f64 MFMA): posterior statistics at the nodes -> ELL term and its adjoints
+  if ((rc = launch_times_quad(e, sm))) return rc;
+  if ((rc = launch_quad_ell(e, sm, C, d, (mask & 2u) ? 1 : 0, pl.want_lat ? 1 : 0))) return rc;
   // ---- per-item adjoints + backward + the fixed-order cross-trial reductions in one kernel
   const int evb = timing_begin(e, 1, sm);
   if (mask & (4u | 8u)) {
@@ -923,78 +837,6 @@ static int enqueue_elbo(svgpfa_engine* e, const PtrTable& pt, const ElboPlan& pl
   timing_end(e, evb, sm);
   hipLaunchKernelGGL(k_fin_items, dim3(v.nth_total + SV_FIN_NS), dim3(256), 0, sm, v, mask, shared);
   HIPCHK(e, hipGetLastError());
-  return SVGPFA_OK;
-}
-
-// One evaluation as one hipGraphLaunch (see svgpfa_engine::graphs).  Captured on a private stream -- the caller's may be
-// the null stream, which cannot be captured -- and replayed into the caller's.
-static int graph_elbo(svgpfa_engine* e, const PtrTable& pt, const ElboPlan& pl, const double* C, const double* d,
-                      double* shared) {
-  hipStream_t user = e->stream;
-  const bool need_cls = !e->cls_valid;
-  std::vector<uint64_t> key;
-  key.reserve(8 + 5 * (size_t)e->v.K);
-  key.push_back(pl.mask);
-  key.push_back((need_cls ? 1u : 0u) | (pl.run_spike ? 2u : 0u));
-  key.push_back((uint64_t)(uintptr_t)C);
-  key.push_back((uint64_t)(uintptr_t)d);
-  key.push_back((uint64_t)(uintptr_t)shared);
-  for (int k = 0; k < e->v.K; ++k)
-    for (const void* q : {(const void*)pt.p[k].mean, (const void*)pt.p[k].cholvec, (const void*)pt.p[k].g_mean,
-                          (const void*)pt.p[k].g_cholvec, (const void*)pt.p[k].g_Z})
-      key.push_back((uint64_t)(uintptr_t)q);
-  svgpfa_engine::GraphSlot* slot = nullptr;
-  for (auto& g : e->graphs)
-    if (g.key == key) slot = &g;
-  if (!slot && std::find(e->graph_seen.begin(), e->graph_seen.end(), key) == e->graph_seen.end()) {
-    // first sight of this pointer set (a caller that allocates its outputs per call never repeats one): plain launches
-    if (e->graph_seen.size() >= SV_GRAPH_SLOTS) e->graph_seen.erase(e->graph_seen.begin());
-    e->graph_seen.push_back(std::move(key));
-    return enqueue_elbo(e, pt, pl, C, d, shared);
-  }
-  if (!slot) {
-    e->stream = e->s_cap;
-    hipError_t st = hipStreamBeginCapture(e->s_cap, hipStreamCaptureModeRelaxed);
-    if (st != hipSuccess) {
-      e->stream = user;
-      e->err = std::string("hipStreamBeginCapture: ") + hipGetErrorString(st);
-      return SVGPFA_ERR_HIP;
-    }
-    const int rc = enqueue_elbo(e, pt, pl, C, d, shared);
-    hipGraph_t g = nullptr;
-    st = hipStreamEndCapture(e->s_cap, &g);
-    e->stream = user;
-    if (rc) {
-      if (g) (void)hipGraphDestroy(g);
-      return rc;
-    }
-    if (st != hipSuccess) {
-      e->err = std::string("hipStreamEndCapture: ") + hipGetErrorString(st);
-      return SVGPFA_ERR_HIP;
-    }
-    hipGraphExec_t ex = nullptr;
-    st = hipGraphInstantiate(&ex, g, nullptr, nullptr, 0);
-    (void)hipGraphDestroy(g);
-    if (st != hipSuccess) {
-      e->err = std::string("hipGraphInstantiate: ") + hipGetErrorString(st);
-      return SVGPFA_ERR_HIP;
-    }
-    if (e->graphs.size() >= SV_GRAPH_SLOTS) {     // least recently used out
-      size_t lru = 0;
-      for (size_t i = 1; i < e->graphs.size(); ++i)
-        if (e->graphs[i].used < e->graphs[lru].used) lru = i;
-      (void)hipGraphExecDestroy(e->graphs[lru].exec);
-      e->graphs.erase(e->graphs.begin() + lru);
-    }
-    e->graphs.emplace_back();
-    slot = &e->graphs.back();
-    slot->key = std::move(key);
-    slot->exec = ex;
-  }
-  slot->used = ++e->graph_clock;
-  e->cls_valid = true;
-  HIPCHK(e, hipGraphLaunch(slot->exec, user));
-  e->graph_replays += 1;
   return SVGPFA_OK;
 }
 
@@ -1012,14 +854,12 @@ int svgpfa_elbo(svgpfa_engine* e, const double* const* mean, const double* const
   pl.mask = mask;
   pl.want_lat = (mask & (1u | 4u | 8u)) != 0;
   pl.full = (mask & (2u | 4u | 8u)) != 0;
-  pl.side = v.nchunks > 0 && e->side_stream == 1;
   // A value-only evaluation reuses the spike pass's sums when the caller vouches (token) that C is unchanged since the pass
   // that produced them.  Only a value-only pass leaves reusable sums: the full pass accumulates them with different
   // roundings, and cached and un-cached evaluations are to stay bit-identical
   const bool reuse_p0 = !pl.full && e->emb_token != 0 && e->p0_token == e->emb_token;
   pl.run_spike = v.nchunks > 0 && !reuse_p0;
   if (pl.run_spike) e->p0_token = pl.full ? 0 : e->emb_token;
-  if (graph_default(e)) return graph_elbo(e, pt, pl, C, d, shared);
   return enqueue_elbo(e, pt, pl, C, d, shared);
 }
 
@@ -1073,7 +913,7 @@ int svgpfa_freeze_stats(svgpfa_engine* e, const double* const* mean, const doubl
   if ((rc = launch_times_quad(e, e->stream))) return rc;
   // the per-neuron sums of the spike means are the spike part of dC, which the spike-time pass makes (cosine series:
   // ~0.3 ms at the north-star size against 2 ms for the posterior mean and variance at every spike)
-  if (v.nchunks > 0) launch_spike_pass(e, e->stream, true, true, C, false, false, nullptr);
+  if (v.nchunks > 0) launch_spike_pass(e, e->stream, true, true, C, false);
   e->p0_token = 0;                     // that pass overwrote the reusable spike sums
   hipLaunchKernelGGL(k_mseg_from_dc, dim3((v.N * v.K + SV_FS_OUT - 1) / SV_FS_OUT), dim3(256), 0, e->stream, v);
   HIPCHK(e, hipGetLastError());
@@ -1223,8 +1063,6 @@ int svgpfa_set_embedding_token(svgpfa_engine* e, uint64_t token) {
   e->emb_token = token;
   return SVGPFA_OK;
 }
-
-int64_t svgpfa_graph_replays(const svgpfa_engine* e) { return e ? e->graph_replays : 0; }
 
 int svgpfa_enable_timing(svgpfa_engine* e, int on) {
   if (!e) return SVGPFA_ERR_INVALID;

@@ -312,10 +312,6 @@ class Engine:
         self._check(self.lib.svgpfa_kernel_ms(self._h, int(which), ctypes.byref(tot), ctypes.byref(n)))
         return tot.value, n.value
 
-    def graph_replays(self):
-        """Evaluations replayed from a recorded HIP graph so far (small shards; include/svgpfa.h)."""
-        return int(self.lib.svgpfa_graph_replays(self._h))
-
     def spike_kernel_ms(self):
         return self.kernel_ms(0)
 

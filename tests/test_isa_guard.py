@@ -46,6 +46,23 @@ def test_guard_flags_the_copy_in_front_of_the_exec_restore(tmp_path):
     assert len(found) == 1 and found[0][1] == ".LBB17_405" and "v224, v154" in found[0][3]
 
 
+def test_guard_flags_any_exec_dependent_instruction_in_front_of_the_restore(tmp_path):
+    """A spill store, an LDS write or an accumulator move in another operand form in that place would be the same defect."""
+    for ins in ("scratch_store_dword off, v154, s32 offset:16", "ds_write_b32 v3, v154", "v_accvgpr_write_b32 a12, v154",
+                "v_add_u32_e32 v224, v154, v1", "global_store_dword v[2:3], v154, off"):
+        found = _scan_text(tmp_path, BAD.replace("v_mov_b32_e32 v224, v154", ins))
+        assert len(found) == 1 and found[0][1] == ".LBB17_405", (ins, found)
+    assert _scan_text(tmp_path, BAD.replace("v_mov_b32_e32 v224, v154", "v_mov_b32_e32 v224, 0x3ff00000")) == []
+    assert _scan_text(tmp_path, BAD.replace("v_mov_b32_e32 v224, v154", "v_readfirstlane_b32 s12, v154")) == []
+
+
+def test_build_refuses_to_pass_with_nothing_scanned(tmp_path):
+    import __graft_entry__ as ge
+    import pytest
+    with pytest.raises(RuntimeError, match="no device assembly"):
+        ge.check_isa(paths=[], require=True)
+
+
 def test_guard_accepts_the_copy_behind_the_exec_restore(tmp_path):
     assert _scan_text(tmp_path, GOOD) == []
     assert _scan_text(tmp_path, UNIFORM) == []
@@ -56,12 +73,12 @@ def test_last_build_is_clean():
     this repeats the scan so that the round's CPU suite records it."""
     import __graft_entry__ as ge
     ge.build()
-    files = sorted(glob.glob(os.path.join(ge.BUILD_DIR, "*gfx950*.s")))
+    files = sorted(glob.glob(os.path.join(ge.BUILD_DIR, "*amdgcn*.s")))
     if not files:          # library built elsewhere (e.g. on the GPU box from a stale tree): rebuild to get the assembly
         ge.build(force=True)
-        files = sorted(glob.glob(os.path.join(ge.BUILD_DIR, "*gfx950*.s")))
+        files = sorted(glob.glob(os.path.join(ge.BUILD_DIR, "*amdgcn*.s")))
     assert files, "build() kept no device assembly"
-    assert ge.check_isa(files) == []
+    assert ge.check_isa(files, require=True) == []
 
 
 def test_no_scratch_outside_the_class_kernels():

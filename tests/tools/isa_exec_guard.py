@@ -5,8 +5,11 @@ branch only -- for a wave whose lanes all took the other branch, under exec = 0 
 found: threadIdx.x inside k_item_bwd<3, true>) is garbage afterwards.
 
 A block is suspect when it is the target of an `s_cbranch_execz` (a join) and, between its label and its
-`s_or_b64 exec, exec, ...`, among nothing but scalar instructions and SGPR spills (v_writelane / v_readlane ignore EXEC and
-are legitimate there), it holds a vector-register copy (v_mov / v_accvgpr_read / v_accvgpr_write from a vector register).
+`s_or_b64 exec, exec, ...`, it holds ANY instruction whose effect depends on EXEC -- a vector-register copy (the case
+found), or any other VALU / LDS / memory instruction (round 4, after review: a spill store or an accumulator move in
+another operand form in that place would be the same defect) -- except the ones that are legitimate there: scalar
+instructions, SGPR spills (v_writelane / v_readlane ignore EXEC) and splats of an SGPR or a constant into a VGPR (every
+lane gets the same value whatever the mask... for the lanes that are on; such a register is rematerialised, not saved).
 
     python tests/tools/isa_exec_guard.py file.s [...]      exit status 1 if any suspect block is found
 """
@@ -16,9 +19,13 @@ import sys
 LABEL = re.compile(r"^(\.LBB\d+_\d+|[A-Za-z_][\w$.]*):")
 EXEC_RESTORE = re.compile(r"^\s*s_or_b64\s+exec,\s*exec,")
 EXECZ_TARGET = re.compile(r"^\s*s_cbranch_execz\s+(\.LBB\d+_\d+)")
-# what the register allocator puts at the top of a block: copies and spills
-COPY = re.compile(r"^\s*(v_mov_b32_e32|v_mov_b64_e32|v_accvgpr_write_b32|v_accvgpr_read_b32|v_accvgpr_mov_b32)\s+([av]\[?[\d:]+\]?),\s*([avs]\[?[\d:]+\]?)\s*$")
-PROLOGUE_OK = re.compile(r"^\s*(v_writelane_b32|v_readlane_b32|s_nop|s_mov_b32|s_mov_b64|s_waitcnt|s_load_\w+)\b")
+# copies: `v_mov dst, src` and the accumulator moves; harmless when the source is an SGPR or a literal (rematerialisation)
+COPY = re.compile(r"^\s*(v_mov_b32_e32|v_mov_b64_e32|v_accvgpr_write_b32|v_accvgpr_read_b32|v_accvgpr_mov_b32)\s+([av]\[?[\d:]+\]?),\s*(\S+)\s*$")
+VECTOR_SRC = re.compile(r"^[av]\[?[\d:]+\]?$")
+# instructions whose effect does not depend on EXEC (or that have none): allowed in front of the restore
+PROLOGUE_OK = re.compile(r"^\s*(v_writelane_b32|v_readlane_b32|v_readfirstlane_b32|s_\w+)\b")
+# everything else that executes per lane
+EXEC_DEPENDENT = re.compile(r"^\s*(v_|ds_|global_|buffer_|scratch_|flat_|tbuffer_|image_)\w+")
 
 
 def scan(path):
@@ -54,12 +61,14 @@ def scan(path):
             block = None
             continue
         c = COPY.match(s)
-        if c and not c.group(3).startswith("s"):          # a copy FROM an SGPR is a uniform rematerialisation: harmless
+        if c and not VECTOR_SRC.match(c.group(3)):        # a splat of an SGPR / constant: uniform rematerialisation, harmless
+            continue
+        if PROLOGUE_OK.match(s):
+            continue
+        if c or EXEC_DEPENDENT.match(s):
             pending.append((ln, s.strip()))
             continue
-        if c or PROLOGUE_OK.match(s):
-            continue
-        block = None                                       # real code before any exec restore: not a join prologue
+        block = None                                       # anything else (unknown mnemonic): stop, do not guess
     return findings
 
 
