@@ -317,9 +317,28 @@ __device__ inline int periodic_series(double beta, int M, double* tab, double* f
   return H;
 }
 
-__device__ __forceinline__ double wave_sum(double x) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) x += __shfl_xor(x, o, 64);
+// Lane exchanges inside a row of 16 lanes by DPP (v_mov_b32_dpp on the two halves of a double: register-to-register, a few
+// cycles) instead of ds_bpermute_b32 (through the LDS pipeline, ~100 cycles per step and a waitcnt): the cross-lane sums of
+// this engine sit in the serial sections of its per-item kernels, where nothing overlaps with them.
+template <int CTRL>
+__device__ __forceinline__ double dpp_mov_f64(double x) {
+  int lo = __double2loint(x), hi = __double2hiint(x);
+  lo = __builtin_amdgcn_update_dpp(lo, lo, CTRL, 0xf, 0xf, false);
+  hi = __builtin_amdgcn_update_dpp(hi, hi, CTRL, 0xf, 0xf, false);
+  return __hiloint2double(hi, lo);
+}
+// sum over the 16 lanes of a row (lanes sharing lane >> 4), every lane gets it: rotations by 8, 4, 2, 1 (row_ror)
+__device__ __forceinline__ double row16_sum(double x) {
+  x += dpp_mov_f64<0x128>(x);
+  x += dpp_mov_f64<0x124>(x);
+  x += dpp_mov_f64<0x122>(x);
+  x += dpp_mov_f64<0x121>(x);
+  return x;
+}
+__device__ __forceinline__ double wave_sum(double x) {     // every lane gets the sum over the wavefront (fixed order)
+  x = row16_sum(x);
+  x += __shfl_xor(x, 16, 64);
+  x += __shfl_xor(x, 32, 64);
   return x;
 }
 

@@ -28,28 +28,29 @@
 #define SV_MASK_STATS 16u   // internal mask bit: svgpfa_latent_stats_backward (adjoints at quadrature nodes AND spikes given)
 #define SV_FIN_OUT 8   // outputs per reduction group of phase 3 (8 consecutive doubles = one 64-B segment per trial)
 
-// stride (doubles) of the per-wave transpose scratch of phase 1: rows are written with lane -> row (stride LDS2) and
-// read with lane -> column; LDS2 = 17 mod 32 makes the 16-lane row writes and the 32-lane transposed reads conflict free
-// up to one bank (the old stride MP + 2 cost a 2-way conflict on every transposed ds_read_b64)
-__host__ __device__ constexpr int sv_tr_stride(int MP) { return ((MP + 14) / 32) * 32 + 17; }
+// doubles of scratch the gather of phase 2's inputs needs when it combines the spike moments itself (gather_item_inputs:
+// the class's moments + three coefficient rows); it borrows the Gt region, which nothing else uses before the reductions
+#define SV_GATHER_SCR (SV_ACOLS + 3 * (SV_FH + 1))
 
 // LDS layout of one block (offsets in doubles) -- ONE constexpr function shared by the kernel (which places its buffers with
-// it) and the host (which sizes the launch with it), so the two cannot disagree.  The transpose scratch of phase 1 and the
-// Gt / At matrix of phase 2 share one region: at the north-star shape (NT = 2, 2 waves) a block needs 34 KB, so four
-// blocks (8 waves) stay resident per CU.  Above M = 32 the FULL variant keeps D in a buffer of its own (Vt stays staged: a
-// block is alone on its CU there, and a second staging phase is an exposed memory latency).
+// it) and the host (which sizes the launch with it), so the two cannot disagree.  The per-wave partial sums of phase 1, the
+// gather's scratch and the Gt / At matrix of phase 2 share one region: at the north-star shape (NT = 2, 2 waves) a block
+// needs 38 KB, so four blocks (8 waves, what the registers allow) stay resident per CU.  The FULL variant keeps E in a
+// buffer of its own at every M: Vt stays staged for phase 2 (until round 4 E took Vt's place at M <= 32 and Vt was fetched
+// again behind the node tiles -- a second exposed memory latency per block for 9 KB of LDS that four blocks per CU leave
+// unused anyway).
 struct ItemBwdLayout {
-  size_t Li, Vl, S, ul, al, zl, gt, gs, gq, gzq, szl, czl, gvs, tred, redz, redt, thq, p1l, cvd, tpl, Dl, total;
+  size_t Li, Vl, S, ul, al, zl, gt, gs, gq, gzq, szl, czl, wpart, tred, redz, redt, thq, p1l, cvd, tpl, Dl, total;
 };
 __host__ __device__ constexpr ItemBwdLayout sv_item_bwd_layout(int NT, int NWB, bool full) {
-  const size_t MP = 16 * NT, LD = MP + 2, L2 = sv_tr_stride(16 * NT);
-  const size_t SZ = ((size_t)NWB * 16 * L2 > MP * LD) ? (size_t)NWB * 16 * L2 : MP * LD;
-  const bool dsep = NT >= 3 && full;
+  const size_t MP = 16 * NT, LD = MP + 2;
+  const size_t SZ = (MP * LD > SV_GATHER_SCR) ? MP * LD : SV_GATHER_SCR;
+  const bool dsep = full;
   ItemBwdLayout o{};
   size_t p = 0;
   o.Li = p; p += MP * LD;          // Linv
-  o.Vl = p; p += MP * LD;          // Vt (M <= 32, FULL: D = Linv^T (Vt Vt^T - I) during phase 1); later C
-  o.S = p; p += SZ;                // phase 1: per-wave transpose scratch; then Gt summed over the waves (rows padded to LD), later At
+  o.Vl = p; p += MP * LD;          // Vt; later C
+  o.S = p; p += SZ;                // gather scratch; then Gt summed over the waves (rows padded to LD), later At
   o.ul = p; p += MP;               // ut
   o.al = p; p += MP;               // a = Linv^T ut
   o.zl = p; p += MP;               // Z
@@ -59,7 +60,7 @@ __host__ __device__ constexpr ItemBwdLayout sv_item_bwd_layout(int NT, int NWB, 
   o.gzq = p; p += MP;              // quadrature part of dZ (direct)
   o.szl = p; p += MP;              // sin of the inducing-point phases (periodic)
   o.czl = p; p += MP;              // cos
-  o.gvs = p; p += (size_t)NWB * 16;
+  o.wpart = p; p += (size_t)NWB * 2 * MP;   // per-wave partial sums of gu / dz behind the node tiles
   o.tred = p; p += (size_t)NWB * 2;
   o.redz = p; p += (size_t)NT * MP;   // per-panel row sums of the dZ contraction
   o.redt = p; p += 2 * (size_t)NT;    // per-panel dtheta partials
@@ -67,7 +68,7 @@ __host__ __device__ constexpr ItemBwdLayout sv_item_bwd_layout(int NT, int NWB, 
   o.p1l = p; p += MP;              // spike partial sums P1 of the trial
   o.cvd = p; p += MP;              // 1 / diag(L_S)
   o.tpl = p; p += 8;               // spike-direct theta partials of the trial, 2 used
-  o.Dl = dsep ? p : o.Vl;          // D: its own MP x LD buffer above M = 32 (FULL), else in Vt's place
+  o.Dl = dsep ? p : o.Vl;          // E = Linv^T (Vt Vt^T - I) Linv (FULL): its own MP x LD buffer
   if (dsep) p += MP * LD;
   o.total = p;
   return o;
@@ -386,7 +387,7 @@ __device__ SV_GATHER_ATTR void gather_item_inputs(const EngineView& ev, const La
 template <int NT, int KT, bool FULL>
 __device__ __forceinline__ void item_bwd_body(const EngineView& ev, const int r, const int k, const LatentPtrs pt, unsigned mask,
                               double* sm) {
-  constexpr int MP = 16 * NT, LD = MP + 2, NTRI = NT * (NT + 1) / 2, L2S = sv_tr_stride(MP);
+  constexpr int MP = 16 * NT, LD = MP + 2, NTRI = NT * (NT + 1) / 2;
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6, li = lane & 15, lg = lane >> 4;
   const int NTHB = blockDim.x, NWB = NTHB >> 6;   // 2 or 4 waves per block (host: 2 when the grid is large and M <= 32)
@@ -407,7 +408,7 @@ __device__ __forceinline__ void item_bwd_body(const EngineView& ev, const int r,
   double* gzq = sm + lay.gzq;
   double* szl = sm + lay.szl;
   double* czl = sm + lay.czl;
-  double* gvs = sm + lay.gvs;
+  double* wpart = sm + lay.wpart;
   double* tred = sm + lay.tred;
   double* redz = sm + lay.redz;
   double* redt = sm + lay.redt;
@@ -415,7 +416,6 @@ __device__ __forceinline__ void item_bwd_body(const EngineView& ev, const int r,
   double* p1l = sm + lay.p1l;
   double* cvd = sm + lay.cvd;
   double* tpl = sm + lay.tpl;
-  constexpr bool DSEP = NT >= 3 && FULL;   // D in its own buffer
   double* Dl = sm + lay.Dl;
   const KPar p = make_kpar(m, ev.theta + 2 * k);
   const long long base = m.offTT + (long long)r * m.PT;      // Vt: packed lower triangle
@@ -447,49 +447,52 @@ __device__ __forceinline__ void item_bwd_body(const EngineView& ev, const int r,
     __syncthreads();
     if (KT == SV_PERIODIC && tid < MP) sv_sincos_quarter(zl[tid] * p.q4, szl[tid], czl[tid]);
     if (FULL) {
-      // The adjoint of kappa(t, Z) at a node is gk = Linv^T [gm ut + 2 gv (Vt Vt^T - I) kt] = gm a + 2 gv D kt with the
-      // per-item matrix D = Linv^T (Vt Vt^T - I): one dense M x M x 16 product per tile instead of three triangular ones
-      // (T = Vt^T kt, Vt T, Linv^T .).  D is built once per item, one 16-column panel per wavefront, and replaces Vt in LDS.
+      // The adjoint of kappa(t, Z) at a node is gk = Linv^T [gm ut + 2 gv (Vt Vt^T - I) kt], kt = Linv kappa(t, Z), i.e.
+      //     gk = gm a + 2 gv E kappa(t, Z)      with the per-item SYMMETRIC matrix  E = Linv^T (Vt Vt^T - I) Linv
+      // one dense M x M x 16 product per tile on the RAW kernel values -- independent of the whitening chain of the same
+      // tile (round 3 multiplied D = Linv^T (Vt Vt^T - I) with kt: the same 16 MFMAs, but behind the 12 of kt).  Rounding:
+      // E kappa and D kt both carry an absolute error of order u cond(Kzz) (kt itself is computed with u sqrt(cond) and then
+      // multiplied by D ~ sqrt(cond)); the MATLAB-fixture parity test (eps = 1e-5, cond 1e6) bounds it either way.
+      // E is built once per item, one 16-column panel per wavefront.
       // Every wave builds a panel (NWB >= NT in every launch configuration; waves >= NT repeat panel wave % NT and store
       // the same values again): no wave-uniform branch around this register-heavy section.  ROCm 7.2's compiler was caught
       // placing a spill of threadIdx.x at the JOIN of such a branch in front of the exec restore (DESIGN.md section 9,
       // tests/tools/isa_exec_guard.py), where a wave that skipped the branch loses it.
-      d4 Dp[NT];
+      d4 Ep[NT];
       const int c = wave % NT;
       {
-        d4 P[NT], VV[NT];
+        d4 P[NT], T1[NT], T2[NT];
 #pragma unroll
         for (int b = 0; b < NT; ++b)
 #pragma unroll
-          for (int q = 0; q < 4; ++q) P[b][q] = Vl[(16 * c + li) * LD + 16 * b + 4 * q + lg];   // Vt^T panel
-        tri_chain<NT, 0>(VV, Vl, LD, P, li, lg);
+          for (int q = 0; q < 4; ++q) P[b][q] = Li[(16 * b + 4 * q + lg) * LD + 16 * c + li];   // Linv[:, panel c]
+        tri_chain<NT, 1>(T1, Vl, LD, P, li, lg);       // Vt^T Linv[:, c]
+        tri_chain<NT, 0>(T2, Vl, LD, T1, li, lg);      // Vt Vt^T Linv[:, c]
 #pragma unroll
         for (int a = 0; a < NT; ++a)
 #pragma unroll
-          for (int q = 0; q < 4; ++q)
-            if (16 * a + 4 * q + lg == 16 * c + li) VV[a][q] -= 1.0;
-        tri_chain<NT, 1>(Dp, Li, LD, VV, li, lg);
+          for (int q = 0; q < 4; ++q) T2[a][q] -= P[a][q];
+        tri_chain<NT, 1>(Ep, Li, LD, T2, li, lg);      // Linv^T (Vt Vt^T - I) Linv[:, c]
       }
-      if (!DSEP) __syncthreads();                                        // every wave is done reading Vt
 #pragma unroll
       for (int a = 0; a < NT; ++a)
 #pragma unroll
-        for (int q = 0; q < 4; ++q) Dl[(16 * a + 4 * q + lg) * LD + 16 * c + li] = Dp[a][q];
+        for (int q = 0; q < 4; ++q) Dl[(16 * a + 4 * q + lg) * LD + 16 * c + li] = Ep[a][q];
     }
     __syncthreads();
     SV_CK(3);
     if (SV_BWD_STOP == 10) return;   // after the D panels
-    d4 gu[NT], dz[NT], GW[NTRI];
+    d4 dz[NT], GW[NTRI];
+    double gu[NT];                      // lane (li, lg): partial of gu_{16 a + li} over the nodes lg + 4 q of every tile
 #pragma unroll
     for (int a = 0; a < NT; ++a) {
-      gu[a] = (d4){0.0, 0.0, 0.0, 0.0};
+      gu[a] = 0.0;
       dz[a] = (d4){0.0, 0.0, 0.0, 0.0};
     }
 #pragma unroll
     for (int t = 0; t < NTRI; ++t) GW[t] = (d4){0.0, 0.0, 0.0, 0.0};
     double th0 = 0.0, th1 = 0.0;
-    double* Sw = S + wave * 16 * L2S;
-    double* gvw = gvs + wave * 16;
+    double* Sw = wpart + wave * 2 * MP;    // this wave's partial sums of gu / dz (written behind its last tile)
     // periodic: kappa and its derivative bases follow from the node's own sin / cos and the inducing
     // points' (szl, czl) by angle addition (no per-pair sincos, no second exp).  Per-j constants are read
     // from LDS at their use sites (jo is an opaque 0: it keeps them out of long-lived registers).
@@ -542,16 +545,36 @@ __device__ __forceinline__ void item_bwd_body(const EngineView& ev, const int r,
             X0[a][q] = p.s2 * sv_exp2_neg(fma(cs, p.h2, -p.h2));
           }
         }
+      // adjoints of the four nodes lg + 4 q of this tile: what this lane's registers of the TRANSPOSED whitened tile
+      // below belong to (L1 / L2 hits: the tile's 16 values are one 128-byte line, fetched by the prefetch above)
+      double gm4[4], gv4[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int n4 = 16 * tile + lg + 4 * q;
+        gm4[q] = (n4 < Qs) ? gmq[n4] : 0.0;
+        gv4[q] = (n4 < Qs) ? gvq[n4] : 0.0;
+      }
       if (tile == wave) SV_CK(5);
-      d4 Kw[NT];
-      tri_chain<NT, 0>(Kw, Li, LD, X0, li, lg);
+      // Whitened tile TRANSPOSED: KwT[t][i] = sum_j kappa(t, z_j) Linv[i][j] -- the raw kernel tile is the A operand as it
+      // stands (lane = node, registers = inducing points), Linv's fragments the B operand; the accumulator then holds
+      // node lg + 4 q of inducing point 16 a + li, which is BOTH operand layouts of the contraction over the nodes
+      //     Gt += KwT^T diag(gv) KwT,
+      // so that product needs no transpose through LDS (round 3: 8 ds_write + 12 ds_read + two fences per tile, and the
+      // kernel's LDS bank conflicts).
+      d4 KwT[NT];
+#pragma unroll
+      for (int a = 0; a < NT; ++a) {
+        d4 acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int b = 0; b <= a; ++b)
+#pragma unroll
+          for (int q = 0; q < 4; ++q)
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(X0[b][q], Li[(16 * a + li) * LD + 16 * b + 4 * q + lg], acc, 0, 0, 0);
+        KwT[a] = acc;
+      }
       if (tile == wave) SV_CK(6);
-#pragma unroll
-      for (int a = 0; a < NT; ++a)
-#pragma unroll
-        for (int q = 0; q < 4; ++q) gu[a][q] = fma(gm, Kw[a][q], gu[a][q]);
+      d4 Gk[NT];
       if (FULL) {
-        d4 Gk[NT];
 #pragma unroll
         for (int a = 0; a < NT; ++a) {
           d4 acc = {0.0, 0.0, 0.0, 0.0};
@@ -559,9 +582,31 @@ __device__ __forceinline__ void item_bwd_body(const EngineView& ev, const int r,
           for (int b = 0; b < NT; ++b)
 #pragma unroll
             for (int q = 0; q < 4; ++q)
-              acc = __builtin_amdgcn_mfma_f64_16x16x4f64(Dl[(16 * a + li) * LD + 16 * b + 4 * q + lg], Kw[b][q], acc, 0, 0, 0);
-          Gk[a] = acc;                                            // D kt
+              acc = __builtin_amdgcn_mfma_f64_16x16x4f64(Dl[(16 * a + li) * LD + 16 * b + 4 * q + lg], X0[b][q], acc, 0, 0, 0);
+          Gk[a] = acc;                                            // E kappa(t, Z): independent of KwT
         }
+      }
+      {
+        d4 gK[NT];
+#pragma unroll
+        for (int a = 0; a < NT; ++a)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            gu[a] = fma(gm4[q], KwT[a][q], gu[a]);
+            gK[a][q] = gv4[q] * KwT[a][q];
+          }
+        int t = 0;
+#pragma unroll
+        for (int a = 0; a < NT; ++a)
+#pragma unroll
+          for (int b = 0; b <= a; ++b) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) GW[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(KwT[a][q], gK[b][q], GW[t], 0, 0, 0);
+            ++t;
+          }
+      }
+      if (tile == wave) SV_CK(7);
+      if (FULL) {
 #pragma unroll
         for (int a = 0; a < NT; ++a)
 #pragma unroll
@@ -588,74 +633,56 @@ __device__ __forceinline__ void item_bwd_body(const EngineView& ev, const int r,
             }
           }
       }
-      if (tile == wave) SV_CK(7);
-      // Gt += Kw^T diag(gvar) Kw : contraction over the time index -> transpose through LDS
-#pragma unroll
-      for (int a = 0; a < NT; ++a)
-#pragma unroll
-        for (int q = 0; q < 4; ++q) Sw[li * L2S + 16 * a + 4 * q + lg] = Kw[a][q];
-      if (lg == 0) gvw[li] = gvv;
-      lds_wave_fence();
-#pragma unroll
-      for (int c = 0; c < 4; ++c) {
-        const int nc = 4 * c + lg;
-        const double g = gvw[nc];
-        double aop[NT];
-#pragma unroll
-        for (int a = 0; a < NT; ++a) aop[a] = Sw[nc * L2S + 16 * a + li];
-        int t = 0;
-#pragma unroll
-        for (int a = 0; a < NT; ++a)
-#pragma unroll
-          for (int b = 0; b <= a; ++b) {
-            GW[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(aop[a], g * aop[b], GW[t], 0, 0, 0);
-            ++t;
-          }
-      }
-      lds_wave_fence();
       if (tile == wave) SV_CK(8);
     }
     }   // node segments
     SV_CK(9);
-    // Vt for phase 2 where D took its buffer: requested HERE, ahead of the reductions (its memory latency was exposed behind
-    // them), stored once the last wave is done with D
-    constexpr int VPF = (FULL && !DSEP) ? (MP * MP + 127) / 128 : 1;      // values per thread at >= 128 threads
-    double vpf[VPF];
-    if (FULL && !DSEP) {
+    // ---- reductions: gu over the four node groups (lg), dz over the 16 node lanes; then over the wavefronts (fixed order)
 #pragma unroll
-      for (int u = 0; u < VPF; ++u) {
-        const int e = tid + u * NTHB, i = e / MP, j = e % MP;
-        vpf[u] = (e < MP * MP && i < M && j <= i) ? ev.Vt[base + sv_tri_off(i) + j] : 0.0;
-      }
-    }
-
-    // ---- reductions: over the 16 time lanes, then over the wavefronts (fixed order)
-#pragma unroll
-    for (int a = 0; a < NT; ++a)
+    for (int a = 0; a < NT; ++a) {
+      const double g = grp4_sum(gu[a]);
+      if (lg == 0) Sw[16 * a + li] = g;
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
-        double g = row16_sum(gu[a][q]);
-        double z = FULL ? row16_sum(dz[a][q]) : 0.0;
-        if (li == 0) {               // per-wave partials of gu / dz: in the wave's own transpose scratch, now idle
-          Sw[16 * a + 4 * q + lg] = g;
-          Sw[MP + 16 * a + 4 * q + lg] = z;
-        }
+        const double z = FULL ? row16_sum(dz[a][q]) : 0.0;
+        if (li == 0) Sw[MP + 16 * a + 4 * q + lg] = z;
       }
+    }
     th0 = wave_sum(th0);
     th1 = wave_sum(th1);
     if (lane == 0) {
       tred[wave * 2 + 0] = th0;
       tred[wave * 2 + 1] = th1;
     }
-    __syncthreads();   // all waves done with their tiles (and with D)
-    if (tid < MP) {    // gu / dz: the waves' partials, in order (read before Gt takes the scratch region over)
+    // Gt: the waves' accumulator tiles added in wave order into the (idle) scratch region, both triangles (tile (a, b),
+    // a > b, is mirrored into (b, a)), rows padded to LD; wave 0 writes ahead of the barrier.  Gt's padding rows / columns
+    // are exact zeros: sums of products with zero-padded rows of Linv
+    auto gt_tiles = [&](const bool first) {
+      int t = 0;
+#pragma unroll
+      for (int a = 0; a < NT; ++a)
+#pragma unroll
+        for (int b = 0; b <= a; ++b) {
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const int row = 16 * a + lg + 4 * q, col = 16 * b + li;
+            const double v = first ? GW[t][q] : Gl[row * LD + col] + GW[t][q];
+            Gl[row * LD + col] = v;
+            if (a != b) Gl[col * LD + row] = v;
+          }
+          ++t;
+        }
+    };
+    if (wave == 0) gt_tiles(true);
+    __syncthreads();   // all waves done with their tiles; wave 0's Gt tiles and every wave's partials are in LDS
+    if (tid < MP) {    // gu / dz: the waves' partials, in order
       double g = 0.0, z = 0.0;
       if (tid < M) {
-        g = S[tid];
-        for (int w = 1; w < NWB; ++w) g += S[w * 16 * L2S + tid];
+        g = wpart[tid];
+        for (int w = 1; w < NWB; ++w) g += wpart[w * 2 * MP + tid];
         if (FULL) {
-          z = S[MP + tid];
-          for (int w = 1; w < NWB; ++w) z += S[w * 16 * L2S + MP + tid];
+          z = wpart[MP + tid];
+          for (int w = 1; w < NWB; ++w) z += wpart[w * 2 * MP + MP + tid];
           z *= p.cz;
         }
       }
@@ -675,35 +702,9 @@ __device__ __forceinline__ void item_bwd_body(const EngineView& ev, const int r,
       thq[0] = p.c0 * t0s;
       thq[1] = p.c1 * t1s;
     }
-    __syncthreads();   // the scratch region becomes Gt, summed over the waves in order, both triangles (tile (a, b), a > b,
-                       // is mirrored into (b, a)), rows padded to LD
-    for (int w = 0; w < NWB; ++w) {
-      if (wave == w) {
-        int t = 0;
-#pragma unroll
-        for (int a = 0; a < NT; ++a)
-#pragma unroll
-          for (int b = 0; b <= a; ++b) {
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-              const int row = 16 * a + lg + 4 * q, col = 16 * b + li;
-              const double v = (w == 0) ? GW[t][q] : Gl[row * LD + col] + GW[t][q];
-              Gl[row * LD + col] = v;
-              if (a != b) Gl[col * LD + row] = v;
-            }
-            ++t;
-          }
-      }
+    for (int w = 1; w < NWB; ++w) {
+      if (wave == w) gt_tiles(false);
       __syncthreads();
-    }
-    // Vt for phase 2: staged again only where D took its buffer.  Gt's padding rows / columns are exact zeros: they are
-    // sums of products with zero-padded rows of Linv
-    if (FULL && !DSEP) {
-#pragma unroll
-      for (int u = 0; u < VPF; ++u) {
-        const int e = tid + u * NTHB, i = e / MP, j = e % MP;
-        if (e < MP * MP) Vl[i * LD + j] = vpf[u];
-      }
     }
   }
 
@@ -927,8 +928,11 @@ __device__ __forceinline__ void item_bwd_body(const EngineView& ev, const int r,
 // M > 32 (cfg5): one block per CU (115 / 151 KB of LDS), one wave per SIMD.  Eight waves per block were measured for the
 // value-only variant (it fits 256 registers): no gain -- 13 node tiles give the busiest SIMD four tiles either way, and the
 // item's serial sections (staging, cross-wave sums) overlap with nothing while a block is alone on its CU.
+#ifndef SV_BWD_WPE
+#define SV_BWD_WPE 2    // waves per SIMD the compiler must leave room for at M <= 32 (experiment builds: 3)
+#endif
 template <int NT, bool FULL>
-__global__ __launch_bounds__(256, (NT <= 2 ? 2 : 1)) void k_item_bwd(EngineView ev, LatentPtrTable ptab, unsigned mask,
+__global__ __launch_bounds__(256, (NT <= 2 ? SV_BWD_WPE : 1)) void k_item_bwd(EngineView ev, LatentPtrTable ptab, unsigned mask,
                                                                      const double* C, const double* d, double* shared) {
   extern __shared__ double sm[];
   const int r = blockIdx.x / ev.K, k = blockIdx.x % ev.K;

@@ -47,11 +47,6 @@ __device__ __forceinline__ void tri_chain(d4 (&D)[NT], const double* Mat, int LD
   }
 }
 
-__device__ __forceinline__ double row16_sum(double x) {   // sum over the 16 lanes sharing lane >> 4
-#pragma unroll
-  for (int o = 8; o > 0; o >>= 1) x += __shfl_xor(x, o, 64);
-  return x;
-}
 __device__ __forceinline__ double grp4_sum(double x) {    // sum over the 4 lanes sharing lane & 15
   x += __shfl_xor(x, 16, 64);
   x += __shfl_xor(x, 32, 64);

@@ -7,7 +7,7 @@ out=$root/gpurun_out/${1:-phases}
 shift || true
 mkdir -p "$out"
 cd /tmp && export TMPDIR=/tmp
-for st in 1 2 6 7 8 3 0; do
+for st in 9 10 1 2 6 7 8 3 0; do
   lib=$root/svgpfa_amd/csrc/libdiag_stop$st.so
   [ $st = 0 ] && lib=$root/svgpfa_amd/csrc/libsvgpfa_hip.so
   [ -f "$lib" ] || continue
