@@ -36,6 +36,19 @@
 #define SV_ACOLS (4 * (SV_FH + 1))    // columns of one A-moment row: [harmonic][cos | sin | t cos | t sin]
 #define SV_WCOLS (2 * (SV_FH + 1))    // columns of one W row: [harmonic][cos | sin]
 
+// Rows of a tile's transposed times that cls_pass (kernels_spike_cls.h) reads (it fetches a group of SV_CLS_PF spikes' times ahead of the loop
+// and a further group in every iteration, unconditionally): rows 0 .. sv_cls_rows_read(maxlen) - 1.  The host pads the
+// array behind the last tile by SV_CLS_TT_PAD doubles so that the read-ahead of the LAST tile stays inside the allocation
+// (inside the array it lands in the next tile).
+#define SV_CLS_PF 4
+#define SV_CLS_TT_PAD (2 * SV_CLS_PF * 64)
+__host__ __device__ constexpr int sv_cls_rows_read(int maxlen) {
+  return (maxlen <= 0) ? SV_CLS_PF : ((maxlen + SV_CLS_PF - 1) / SV_CLS_PF) * SV_CLS_PF + SV_CLS_PF;
+}
+static_assert(64 * sv_cls_rows_read(1) <= 64 * 1 + SV_CLS_TT_PAD && 64 * sv_cls_rows_read(2) <= 64 * 2 + SV_CLS_TT_PAD &&
+              64 * sv_cls_rows_read(3) <= 64 * 3 + SV_CLS_TT_PAD && 64 * sv_cls_rows_read(4) <= 64 * 4 + SV_CLS_TT_PAD &&
+              64 * sv_cls_rows_read(5) <= 64 * 5 + SV_CLS_TT_PAD, "tt padding shorter than the class kernel's read-ahead");
+
 struct LatentMeta {
   int M, P, ktype, nth;
   long long offM, offMM;

@@ -16,7 +16,7 @@
 #pragma once
 #include "engine_common.h"
 #include "kernels_mfma.h"
-#include "kernels_spike_cls.h"
+#include "spike_cls_common.h"
 
 #ifndef SV_BWD_CLK
 #define SV_BWD_CLK 0    // diagnosis builds only: 1 = one thread of one block prints cycle stamps of the phases (device printf)

@@ -165,30 +165,19 @@ __device__ __forceinline__ void load_factors(const EngineView& ev, const LatentM
 // base_r + i*os_t + k*os_k with base_r = toff[r]*os_t (CSR times) or r*os_r (nper times per trial).  The engine's own
 // quadrature statistics use [r][k][q] (os_r = K Q, os_t = 1, os_k = Q): the 16 nodes of a tile are 128 contiguous bytes
 // for this kernel's stores, for the adjoint loads of k_item_bwd and for the ELL kernel's rows.
-template <int NT, int KT>
-__device__ __forceinline__ void times_fwd_body(const EngineView& ev, const int r, const int k, const double* times,
-                               const long long* toff, int nper, double* mu_out, double* var_out, long long os_r,
-                               long long os_t, long long os_k, int want_var, double* sm) {
+//
+// The tile loop of one wavefront.  Li, Vl (padded M x M images), ul = ut, zl = Z and (periodic) szl / czl = sin / cos of
+// the inducing points' phases are in LDS and synchronised by the caller.  DYN = false: wave w takes tiles w, w + NWB, ...;
+// DYN = true: the block's waves draw tiles from the LDS counter `next` (zeroed by the caller in front of its barrier) --
+// for blocks whose waves do not start the loop together (k_front: one wave carries a rider).
+template <int NT, int KT, bool DYN>
+__device__ __forceinline__ void times_tiles(const KPar& p, const double* Li, const double* Vl, const double* ul,
+                                            const double* zl, const double* szl, const double* czl, const double* times,
+                                            long long t0, int nt, double* mu_out, double* var_out, long long obase,
+                                            long long os_t, int want_var, int* next, const int tid) {
   constexpr int MP = 16 * NT, LD = MP + 2;
-  const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6, li = lane & 15, lg = lane >> 4;
-  const LatentMeta m = ev.meta[k];
-  double* Li = sm;
-  double* Vl = Li + MP * LD;
-  double* ul = Vl + MP * LD;
-  double* zl = ul + MP;
-  const KPar p = make_kpar(m, ev.theta + 2 * k);
-  const long long t0 = toff ? toff[r] : (long long)r * nper;
-  const int nt = toff ? (int)(toff[r + 1] - toff[r]) : nper;
-  load_factors<NT>(ev, m, r, Li, Vl, ul, zl, want_var != 0);
-  __syncthreads();
-
-  // periodic: sin / cos of the inducing points' phases in LDS, so that a (node, inducing point) pair costs two FMAs by
-  // angle addition instead of a sincos; read at the use site (jo is an opaque lg: keeps them out of long-lived VGPRs)
-  double* szl = zl + MP;
-  double* czl = szl + MP;
-  if (KT == SV_PERIODIC && tid < MP) sv_sincos_quarter(zl[tid] * p.q4, szl[tid], czl[tid]);
-  if (KT == SV_PERIODIC) __syncthreads();
+  // per-lane constants: ut and (RBF) Z of this lane's inducing points
   double uj[NT][4], zj[NT][4];
 #pragma unroll
   for (int a = 0; a < NT; ++a)
@@ -197,19 +186,25 @@ __device__ __forceinline__ void times_fwd_body(const EngineView& ev, const int r
       uj[a][q] = ul[16 * a + 4 * q + lg];
       zj[a][q] = zl[16 * a + 4 * q + lg];
     }
-
   const int ntiles = (nt + 15) >> 4;
-  const int NWB = blockDim.x >> 6;     // waves per block (launch parameter; 4)
-  const long long obase = (toff ? t0 * os_t : (long long)r * os_r) + (long long)k * os_k;
-  // the time of the NEXT tile is fetched one iteration ahead (global latency hidden behind the MFMA chain)
-  double tq_next = (wave < ntiles) ? times[t0 + ((16 * wave + li < nt) ? 16 * wave + li : 0)] : 0.0;
-  for (int tile = wave; tile < ntiles; tile += NWB) {
+  const int NWB = blockDim.x >> 6;     // waves per block (launch parameter)
+  auto draw = [&](int prev) -> int {
+    if (!DYN) return prev < 0 ? wave : prev + NWB;
+    int v = 0;
+    if (lane == 0) v = atomicAdd(next, 1);
+    return __builtin_amdgcn_readfirstlane(v);
+  };
+  // the tile after this one is drawn, and its times fetched, one iteration ahead (global latency hidden behind the MFMA chain)
+  int tile = draw(-1);
+  double tq_next = (tile < ntiles) ? times[t0 + ((16 * tile + li < nt) ? 16 * tile + li : 0)] : 0.0;
+  while (tile < ntiles) {
     const int node = 16 * tile + li;
     const bool ok = node < nt;
     const double tq = tq_next;
-    {
-      const int nn = node + 16 * NWB;
-      if (tile + NWB < ntiles) tq_next = times[t0 + ((nn < nt) ? nn : 0)];
+    const int tile_n = draw(tile);
+    if (tile_n < ntiles) {
+      const int nn = 16 * tile_n + li;
+      tq_next = times[t0 + ((nn < nt) ? nn : 0)];
     }
     d4 X0[NT];
     double stq = 0.0, ctq = 0.0;
@@ -254,7 +249,35 @@ __device__ __forceinline__ void times_fwd_body(const EngineView& ev, const int r
       mu_out[o] = pm;
       if (want_var) var_out[o] = (p.s2 - n2) + tt;
     }
+    tile = tile_n;
   }
+}
+
+template <int NT, int KT>
+__device__ __forceinline__ void times_fwd_body(const EngineView& ev, const int r, const int k, const double* times,
+                               const long long* toff, int nper, double* mu_out, double* var_out, long long os_r,
+                               long long os_t, long long os_k, int want_var, double* sm) {
+  constexpr int MP = 16 * NT, LD = MP + 2;
+  const int tid = threadIdx.x;
+  const LatentMeta m = ev.meta[k];
+  double* Li = sm;
+  double* Vl = Li + MP * LD;
+  double* ul = Vl + MP * LD;
+  double* zl = ul + MP;
+  const KPar p = make_kpar(m, ev.theta + 2 * k);
+  const long long t0 = toff ? toff[r] : (long long)r * nper;
+  const int nt = toff ? (int)(toff[r + 1] - toff[r]) : nper;
+  load_factors<NT>(ev, m, r, Li, Vl, ul, zl, want_var != 0);
+  __syncthreads();
+
+  // periodic: sin / cos of the inducing points' phases in LDS, so that a (node, inducing point) pair costs two FMAs by
+  // angle addition instead of a sincos; read at the use site (jo is an opaque lg: keeps them out of long-lived VGPRs)
+  double* szl = zl + MP;
+  double* czl = szl + MP;
+  if (KT == SV_PERIODIC && tid < MP) sv_sincos_quarter(zl[tid] * p.q4, szl[tid], czl[tid]);
+  if (KT == SV_PERIODIC) __syncthreads();
+  const long long obase = (toff ? t0 * os_t : (long long)r * os_r) + (long long)k * os_k;
+  times_tiles<NT, KT, false>(p, Li, Vl, ul, zl, szl, czl, times, t0, nt, mu_out, var_out, obase, os_t, want_var, nullptr, tid);
 }
 
 // One launch over all (trial, latent) items; the covariance type is resolved per block (wave-uniform branch).
@@ -367,6 +390,193 @@ __global__ __launch_bounds__(64 * NT) void k_prep_mfma(EngineView ev, LatentPtrT
     ev.klpart[item] = 0.5 * (tot - (double)M);
   }
   if (want_w && c == 0) spike_pre_item(ev, item, r, k, m, (lane < M) ? wsc[lane] : 0.0, wsc + 64);
+}
+
+// ------------------------------------------------------------------------------ k_front
+// k_prep_mfma and the quadrature pass of k_times_fwd_mfma in ONE block per (trial, latent) item (svgpfa_elbo; round 4): the
+// block stages Linv and L_S once, its first NT waves produce the panels of Vt = Linv L_S (-> HBM for k_item_bwd, and into
+// L_S's place in LDS), one more wave the mean chain (ut, a) and the KL sum; then all four waves walk the trial's
+// quadrature tiles (times_tiles, tiles drawn from an LDS counter) with both factors already in LDS.  Against the two
+// launches: one staging of Linv and none of Vt (44 MB of reads at the north-star size), one launch boundary less -- on a
+// small shard one whole round of the chip -- and the class path's W (spike_pre_item, when dC is wanted) rides on the
+// block's last wave while the others have already started on the tiles.
+// One item per block: a version with persistent blocks that requested the NEXT item's inputs into registers ahead of the
+// tile loop was built and measured (round 4): 146-171 us against 128 at the north-star size.  The 8-15 us that cycle
+// stamps show between a block's start and its first tile are not exposed memory latency but this block's own instructions
+// (index arithmetic of the staging, the panel and mean chains, the logs of the KL term) queueing behind three other waves
+// per SIMD that are in their tile loops: the kernel is issue-bound, and the item loop only added registers (the compiler
+// hoists every fp64 polynomial constant of the body out of such a loop: 94 -> 177 VGPRs).
+// grid = R K blocks of 256 threads; dynamic LDS sv_front_lds(NT).
+__host__ __device__ constexpr size_t sv_front_lds(int NT) {
+  const size_t MP = 16 * (size_t)NT, LD = MP + 2;
+  return (2 * MP * LD + 5 * MP + 6 + 64 + SV_PRE_LDS) * 8;
+}
+#ifndef SV_FRONT_CLK
+#define SV_FRONT_CLK 0    // diagnosis builds only: 1 = two threads of two blocks print cycle stamps of the phases (device printf)
+#endif
+#define SV_FCK(i) do { if (SV_FRONT_CLK) fck[i] = clock64(); } while (0)
+
+template <int NT, int KT>
+__device__ __forceinline__ void front_body(const EngineView& ev, const LatentPtrTable& ptab, const LatentMeta& m, int r, int k,
+                                           int want_w, double* sm) {
+  constexpr int MP = 16 * NT, LD = MP + 2, NTH = 256;
+  constexpr int PW = (NT < 4) ? NT : 0;            // the wave that carries the mean chain
+  const int tid = threadIdx.x;
+  const int item = r * ev.K + k, lane = tid & 63, wave = tid >> 6, li = lane & 15, lg = lane >> 4;
+  const int M = m.M;
+  const LatentPtrs& pt = ptab.p[k];
+  double* Li = sm;               // MP*LD
+  double* Ls = Li + MP * LD;     // MP*LD: L_S, then Vt
+  double* ul = Ls + MP * LD;
+  double* zl = ul + MP;
+  double* szl = zl + MP;
+  double* czl = szl + MP;
+  double* ml = czl + MP;         // the mean
+  double* red = ml + MP;         // 4
+  int* next = (int*)(red + 4);   // tile counter (one double slot; red + 5 unused)
+  double* wsc = red + 6;         // 64 + SV_PRE_LDS (want_w)
+  long long fck[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  SV_FCK(0);
+  const KPar p = make_kpar(m, ev.theta + 2 * k);
+  const long long base = m.offTT + (long long)r * m.PT;      // Linv, Vt: packed lower triangles
+  const long long vbase = m.offM + (long long)r * M;
+  const double* cv = pt.cholvec + (long long)r * m.P;
+  // every global load of the block's inputs is requested before the first LDS store: one exposed memory latency
+  const double zv = (tid < M) ? ev.Zs[vbase + tid] : 0.0;
+  const double mv = (tid < M) ? pt.mean[(long long)r * M + tid] : 0.0;
+  if (NT <= 2) {
+    constexpr int NV = (MP * MP + NTH - 1) / NTH;
+    const double* sl = ev.Linv + base;
+    double vl[NV], vs[NV];
+#pragma unroll
+    for (int u = 0; u < NV; ++u) {
+      const int e = tid + u * NTH, i = e / MP, j = e % MP;
+      const bool ok = e < MP * MP && i < M && j <= i;
+      vl[u] = ok ? sl[sv_tri_off(i) + j] : 0.0;
+      vs[u] = ok ? cv[i * (i + 1) / 2 + j] : 0.0;
+    }
+#pragma unroll
+    for (int u = 0; u < NV; ++u) {
+      const int e = tid + u * NTH, i = e / MP, j = e % MP;
+      if (e < MP * MP) {
+        Li[i * LD + j] = vl[u];
+        Ls[i * LD + j] = vs[u];
+      }
+    }
+  } else {
+    stage_matrix_dma<NT>(Li, ev.Linv + base, M, tid, NTH);     // (lands behind the loads below; the barrier waits)
+    for (int e0 = tid; e0 < MP * MP; e0 += 4 * NTH) {      // L_S from the row-major tril vector, four loads in flight
+      double v[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int e = e0 + u * NTH, i = e / MP, j = e % MP;
+        v[u] = (e < MP * MP && i < M && j <= i) ? cv[i * (i + 1) / 2 + j] : 0.0;
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int e = e0 + u * NTH, i = e / MP, j = e % MP;
+        if (e < MP * MP) Ls[i * LD + j] = v[u];
+      }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the DMA pieces of Linv have landed
+  }
+  if (tid < MP) {
+    zl[tid] = zv;
+    ml[tid] = mv;
+    if (KT == SV_PERIODIC) sv_sincos_quarter(zv * p.q4, szl[tid], czl[tid]);
+  }
+  if (tid == 0) *next = 0;
+  SV_FCK(1);
+  __syncthreads();
+  SV_FCK(2);
+
+  // ---- waves < NT: panel `wave` of Vt = Linv L_S; wave PW: ut = Linv m, a = Linv^T ut (the mean as column 0 of a panel)
+  double part = 0.0;
+  d4 V[NT];
+  {
+    const int c = wave % NT;     // (waves >= NT recompute a panel they never store: no wave-uniform branch around the chain)
+    d4 P[NT];
+#pragma unroll
+    for (int b = 0; b < NT; ++b)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) P[b][q] = Ls[(16 * b + 4 * q + lg) * LD + 16 * c + li];
+    tri_chain<NT, 0>(V, Li, LD, P, li, lg);
+    if (wave < NT) {
+#pragma unroll
+      for (int a = 0; a < NT; ++a)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) part = fma(V[a][q], V[a][q], part);
+    }
+  }
+  d4 U[NT], A[NT];
+  if (wave == PW) {
+    d4 Pm[NT];
+#pragma unroll
+    for (int b = 0; b < NT; ++b)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) Pm[b][q] = (li == 0) ? ml[16 * b + 4 * q + lg] : 0.0;
+    tri_chain<NT, 0>(U, Li, LD, Pm, li, lg);
+    tri_chain<NT, 1>(A, Li, LD, U, li, lg);
+    if (lane < M) part += -2.0 * log(Li[lane * LD + lane]) - 2.0 * log(fabs(Ls[lane * LD + lane]));
+  }
+  SV_FCK(3);
+  __syncthreads();               // every wave is done reading L_S: its buffer becomes Vt
+  if (wave < NT) {
+    const int c = wave;
+#pragma unroll
+    for (int a = 0; a < NT; ++a)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int i = 16 * a + 4 * q + lg, j = 16 * c + li;
+        Ls[i * LD + j] = V[a][q];                                               // (exact zeros above the diagonal and in the padding)
+        if (i < M && j <= i) ev.Vt[base + sv_tri_off(i) + j] = V[a][q];
+        if (i < M && j == i && !(i & 1)) ev.Vt[base + sv_tri_off(i) + i + 1] = 0.0;   // the pad of an odd-length row
+      }
+  }
+  if (wave == PW) {
+#pragma unroll
+    for (int a = 0; a < NT; ++a)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int i = 16 * a + 4 * q + lg;
+        if (li == 0) {
+          ul[i] = U[a][q];                                                       // (zero beyond M: padded rows of Linv)
+          if (i < M) {
+            ev.ut[vbase + i] = U[a][q];
+            ev.a[vbase + i] = A[a][q];
+            part = fma(U[a][q], U[a][q], part);
+            wsc[i] = A[a][q];
+          }
+        }
+      }
+  }
+  part = wave_sum(part);
+  if (lane == 0) red[wave] = part;
+  SV_FCK(4);
+  __syncthreads();
+  SV_FCK(5);
+  if (tid == 0) ev.klpart[item] = 0.5 * (((red[0] + red[1]) + (red[2] + red[3])) - (double)M);     // fixed order
+  // ---- the class path's W on the last wave, ahead of its share of the tiles
+  if (want_w && wave == 3) spike_pre_item(ev, item, r, k, m, (lane < M) ? wsc[lane] : 0.0, wsc + 64);
+  // ---- quadrature statistics [r][k][q]
+  times_tiles<NT, KT, true>(p, Li, Ls, ul, zl, szl, czl, ev.tq, (long long)r * ev.Q, ev.Q, ev.muq, ev.varq,
+                            ((long long)r * ev.K + k) * ev.Q, 1LL, 1, next, tid);
+  if (SV_FRONT_CLK) {
+    SV_FCK(6);
+    if ((blockIdx.x == 101 || blockIdx.x == 202) && (tid == 0 || tid == 192)) {
+      printf("FCK kt %d tid %d: %lld %lld %lld %lld %lld %lld\n", KT, tid, fck[1] - fck[0], fck[2] - fck[0], fck[3] - fck[0],
+             fck[4] - fck[0], fck[5] - fck[0], fck[6] - fck[0]);
+    }
+  }
+}
+
+template <int NT>
+__global__ __launch_bounds__(256) void k_front(EngineView ev, LatentPtrTable ptab, int want_w) {
+  extern __shared__ double sm[];
+  const int r = blockIdx.x / ev.K, k = blockIdx.x % ev.K;
+  const LatentMeta m = ev.meta[k];
+  if (m.ktype == SV_RBF) front_body<NT, SV_RBF>(ev, ptab, m, r, k, want_w, sm);
+  else front_body<NT, SV_PERIODIC>(ev, ptab, m, r, k, want_w, sm);
 }
 
 // ------------------------------------------------------------------------- k_quad_ell_mfma

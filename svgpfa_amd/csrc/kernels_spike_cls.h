@@ -66,19 +66,6 @@ __global__ __launch_bounds__(64) void k_spike_pre(EngineView ev) {
 // One register pass over the rows' spikes: harmonics h0 .. h0 + HB - 1 of every row (lane) of the tile.
 //   acc[NV n + 0] = sum_s cos((h0 + n) theta_s)   [+1] = sin   ([+2], [+3]: the same weighted by t_s, NV = 4)
 // (cos, sin) of the multiples by rotation (error ~ n ulp); a later pass starts from one direct sincos of h0 theta.
-// Rows of a tile's transposed times that cls_pass reads (it fetches a group of SV_CLS_PF spikes' times ahead of the loop
-// and a further group in every iteration, unconditionally): rows 0 .. sv_cls_rows_read(maxlen) - 1.  The host pads the
-// array behind the last tile by SV_CLS_TT_PAD doubles so that the read-ahead of the LAST tile stays inside the allocation
-// (inside the array it lands in the next tile).
-#define SV_CLS_PF 4
-#define SV_CLS_TT_PAD (2 * SV_CLS_PF * 64)
-__host__ __device__ constexpr int sv_cls_rows_read(int maxlen) {
-  return (maxlen <= 0) ? SV_CLS_PF : ((maxlen + SV_CLS_PF - 1) / SV_CLS_PF) * SV_CLS_PF + SV_CLS_PF;
-}
-static_assert(64 * sv_cls_rows_read(1) <= 64 * 1 + SV_CLS_TT_PAD && 64 * sv_cls_rows_read(2) <= 64 * 2 + SV_CLS_TT_PAD &&
-              64 * sv_cls_rows_read(3) <= 64 * 3 + SV_CLS_TT_PAD && 64 * sv_cls_rows_read(4) <= 64 * 4 + SV_CLS_TT_PAD &&
-              64 * sv_cls_rows_read(5) <= 64 * 5 + SV_CLS_TT_PAD, "tt padding shorter than the class kernel's read-ahead");
-
 template <int NV, int HB>
 __device__ __forceinline__ void cls_pass(const double* __restrict__ tt, int maxlen, int len, int lane, double t0,
                                          double sc, int h0, double (&acc)[NV * HB]) {

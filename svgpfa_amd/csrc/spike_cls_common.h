@@ -235,48 +235,42 @@ __device__ __forceinline__ void cls_coefficients(const EngineView& ev, int k, in
 // W[r][k][2 n + {0, 1}] = s2 c_n (Abar_n, Bbar_n),  Abar_n = sum_j a_j cos(n phi_j),  Bbar_n = sum_j a_j sin(n phi_j),
 // phi_j = w (z_j - t0): the posterior mean at a spike is mu_s = sum_n [cos(n theta_s) W_2n + sin(n theta_s) W_2n+1].
 // Entries beyond H are written as zeros (k_spike_cls works in whole register passes).  By ONE wavefront (all 64 lanes
-// call); aj = a_lane of the item (0 beyond M); scratch: SV_PRE_LDS doubles of LDS (4 harmonics x (cos, sin) per round,
-// then the coefficients).
-#define SV_PRE_LDS (8 * 65 + 3 * (SV_FH + 1))
+// call); aj = a_lane of the item (0 beyond M); scratch: SV_PRE_LDS doubles of LDS.
+// Lane = HARMONIC: lane n walks the item's inducing points (a_j and phi_j are broadcast LDS reads) with one direct sincos of
+// n phi_j each -- M independent iterations per lane, no sum across lanes.  (Round 3 had lane = inducing point, harmonics
+// by rotation, and a transposed LDS reduction per four harmonics: a dependent chain of ~10 us on the one wave of
+// k_prep_mfma that carried it.)
+#define SV_PRE_LDS (2 * 64 + 3 * (SV_FH + 1))
 __device__ inline void spike_pre_item(const EngineView& ev, int item, int r, int k, const LatentMeta& m, double aj,
                                       double* scratch) {
-  double* red = scratch;
-  double* cf = scratch + 8 * 65;
+  double* al = scratch;                    // a_j
+  double* pl = scratch + 64;               // phi_j in quarter turns
+  double* cf = scratch + 128;
   const int lane = threadIdx.x & 63;
   const SpikeItem it = ev.sitem[item];
   if (it.H < 0) return;
-  const int H = it.H;
+  const int H = it.H, M = m.M;
   const double sc = it.sc, t0 = it.t0;
   const KPar p = make_kpar(m, ev.theta + 2 * k);
   double zj = t0;
-  if (lane < m.M) zj = ev.Zs[m.offM + (long long)r * m.M + lane];
-  else aj = 0.0;
+  if (lane < M) zj = ev.Zs[m.offM + (long long)r * M + lane];
+  al[lane] = (lane < M) ? aj : 0.0;
+  pl[lane] = (zj - t0) * sc;
   cls_coefficients(ev, k, m.ktype, p.h, sc, H, cf);
-  double sphi = 0.0, cphi = 1.0;
-  if (lane < m.M) sv_sincos_quarter((zj - t0) * sc, sphi, cphi);
   double* W = ev.Wb + (long long)item * SV_WCOLS;
   for (int c = 2 * (H + 1) + lane; c < SV_WCOLS; c += 64) W[c] = 0.0;
-  double cj = 1.0, sj = 0.0;
-  for (int nb = 0; nb <= H; nb += 4) {
-    lds_wave_fence();                      // cf ready (first round); the previous round's rows are consumed
-#pragma unroll
-    for (int jj = 0; jj < 4; ++jj) {
-      red[(2 * jj + 0) * 65 + lane] = aj * cj;
-      red[(2 * jj + 1) * 65 + lane] = aj * sj;
-      const double tq = cj * cphi - sj * sphi;
-      sj = fma(sj, cphi, cj * sphi);
-      cj = tq;
+  lds_wave_fence();
+  for (int n = lane; n <= H; n += 64) {
+    const double dn = (double)n;
+    double sa = 0.0, sb = 0.0;
+    for (int j = 0; j < M; ++j) {
+      double sn, cs;
+      sv_sincos_quarter(pl[j] * dn, sn, cs);
+      sa = fma(al[j], cs, sa);
+      sb = fma(al[j], sn, sb);
     }
-    lds_wave_fence();
-    // transposed reduction: lane (v, eighth) sums 8 of the 64 lane-partials of row v, the eighths are added by shuffles
-    const int v = lane & 7, qd = lane >> 3;
-    double sum = 0.0;
-#pragma unroll
-    for (int e = 0; e < 8; ++e) sum += red[v * 65 + qd * 8 + e];
-    sum += __shfl_xor(sum, 8, 64);
-    sum += __shfl_xor(sum, 16, 64);
-    sum += __shfl_xor(sum, 32, 64);
-    const int n = nb + (lane >> 1);
-    if (lane < 8 && n <= H) W[2 * n + (lane & 1)] = p.s2 * cf[n] * sum;
+    const double w = p.s2 * cf[n];
+    W[2 * n + 0] = w * sa;
+    W[2 * n + 1] = w * sb;
   }
 }

@@ -1,0 +1,18 @@
+// Host-side launch wrappers of the class path's kernels (kernels_spike_cls.h).  Those kernels live in a translation unit
+// of their own, spike_cls_api.hip, compiled with -mllvm -disable-machine-licm: their work loops are persistent (a block
+// strides over (tile, class) items), and the compiler's machine-level loop-invariant code motion hoists every fp64
+// polynomial constant of the loop body (sincos: 14 doubles) into registers that stay live across the whole loop --
+// with it the kernels spill 60-97 registers, without it 32-65, and run 38 + 38 us instead of 47 + 43 at the north-star
+// size (round 4; the same flag slows k_quad_ell_mfma down by 8 %, hence not the whole library).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "engine_common.h"
+
+void sv_launch_spike_classes(const EngineView& v, hipStream_t s);
+void sv_launch_spike_pre(const EngineView& v, hipStream_t s);
+// nv: 4 / 2 = the kernel of the classes with / without time-weighted moments, 0 = both kinds in one launch; dc: the rows'
+// dC partials wanted (needs W)
+void sv_launch_spike_cls(const EngineView& v, const double* C, int nv, int dc, int full, unsigned grid, hipStream_t s);
+void sv_launch_spike_comb(const EngineView& v, bool full, hipStream_t s);
+int sv_spike_cls_blocks_per_cu();      // resident single-wave blocks per CU of the largest class kernel (0 on error)

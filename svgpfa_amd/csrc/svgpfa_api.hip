@@ -15,7 +15,7 @@
 #include "kernels_item_bwd.h"
 #include "kernels_mfma.h"
 #include "kernels_spike.h"
-#include "kernels_spike_cls.h"
+#include "spike_cls_launch.h"
 
 typedef LatentPtrTable PtrTable;
 
@@ -62,6 +62,7 @@ struct svgpfa_engine {
   // boundary -- a drained chip -- less: one rank's shard of cfg3, ms per evaluation, two kernels -> one: 2-way 0.405 -> 0.386,
   // 4-way 0.266 -> 0.249, 8-way 0.198 -> 0.176; at the full 5 000 items 0.655 / 0.659).  SVGPFA_CLS_FUSED=0 / 1 forces it.
   int cls_fused = -1;
+  bool front = true;                            // k_front instead of k_prep_mfma + k_times_fwd_mfma in svgpfa_elbo (SVGPFA_FRONT=0: off)
   bool cls_on = true;                           // false: problem too small for the class path's extra launches (set_spikes)
   double series_min_pairs = 1e7;                // SVGPFA_SERIES_MIN_PAIRS: fewest (spike, inducing point) pairs for the class path
   bool cls_valid = false;                       // the class table of the spike pass belongs to the current kernel build
@@ -272,6 +273,8 @@ int svgpfa_create(const svgpfa_dims* d, int device, svgpfa_engine** out) {
     v.rbf_series = (rs && atoi(rs) == 0) ? 0 : 1;
     const char* mp = getenv("SVGPFA_SERIES_MIN_PAIRS");
     if (mp) e->series_min_pairs = atof(mp);
+    const char* fr = getenv("SVGPFA_FRONT");
+    e->front = !(fr && atoi(fr) == 0);
     const char* ps = getenv("SVGPFA_PERIODIC_SERIES");
     v.per_series = (ps && atoi(ps) == 0) ? 0 : 1;
   }
@@ -280,7 +283,7 @@ int svgpfa_create(const svgpfa_dims* d, int device, svgpfa_engine** out) {
     hipDeviceProp_t prop;
     HIPCHK(e, hipGetDeviceProperties(&prop, device));
     int bc = 0, bp = 0;
-    HIPCHK(e, hipOccupancyMaxActiveBlocksPerMultiprocessor(&bc, (const void*)k_spike_cls<4, true>, 64, 0));
+    bc = sv_spike_cls_blocks_per_cu();
     HIPCHK(e, hipOccupancyMaxActiveBlocksPerMultiprocessor(&bp, (const void*)k_spike<true, double, true>, 64, 0));
     e->grid_cls = std::max(8, prop.multiProcessorCount * std::max(1, bc));
     e->grid_pair = std::max(8, (prop.multiProcessorCount * std::max(1, bp)) & ~7);
@@ -288,6 +291,7 @@ int svgpfa_create(const svgpfa_dims* d, int device, svgpfa_engine** out) {
 
   int rc = 0;
   DISPATCH_NT(e->NT, rc = allow_lds(e, (k_prep_mfma<NT_>), lds_prep_mfma(NT_));
+              if (!rc) rc = allow_lds(e, (k_front<NT_>), sv_front_lds(NT_));
               if (!rc) rc = allow_lds(e, (k_times_fwd_mfma<NT_>), lds_times_mfma(NT_));
               if (!rc) rc = allow_lds(e, (k_item_bwd<NT_, true>), lds_item_bwd(NT_, 4, true));
               if (!rc) rc = allow_lds(e, (k_item_bwd<NT_, false>), lds_item_bwd(NT_, 4, false)));
@@ -603,7 +607,7 @@ static void launch_build(svgpfa_engine* e, int write_aux, const SnapTable* snap,
 // Classes of the spike pass's class path for the current kernel snapshot (needs the spikes' windows): they ride in the
 // kernel build's launch (launch_build); this separate kernel serves a build that ran before the spikes were set.
 static void launch_classes(svgpfa_engine* e) {
-  hipLaunchKernelGGL(k_spike_classes, dim3((e->v.R + 3) / 4), dim3(256), 0, e->stream, e->v);
+  sv_launch_spike_classes(e->v, e->stream);
   e->cls_valid = true;
 }
 
@@ -702,6 +706,13 @@ static void launch_prep(svgpfa_engine* e, const PtrTable& pt, bool want_w = fals
                                         want_w ? 1 : 0));
 }
 
+// k_prep_mfma + the quadrature pass of k_times_fwd_mfma in one launch (svgpfa_elbo)
+static void launch_front(svgpfa_engine* e, const PtrTable& pt, bool want_w) {
+  EngineView& v = e->v;
+  DISPATCH_NT(e->NT, hipLaunchKernelGGL(k_front<NT_>, dim3(v.R * v.K), dim3(256), sv_front_lds(NT_), e->stream, v, pt,
+                                        want_w ? 1 : 0));
+}
+
 // quadrature statistics into the engine's [r][k][q] buffers
 static int launch_times_quad(svgpfa_engine* e, hipStream_t st) {
   EngineView& v = e->v;
@@ -767,30 +778,22 @@ static void launch_pair_pass(svgpfa_engine* e, hipStream_t sk, bool full, bool w
 // rest; both stride fixed grids over work lists that live on the device.
 static void launch_spike_pass(svgpfa_engine* e, hipStream_t sk, bool full, bool want_c, const double* C, bool have_w) {
   EngineView& v = e->v;
-  const dim3 bs(64);
-  const dim3 gi(v.R * v.K);
-  const dim3 gc((unsigned)std::min<long long>((long long)v.ntiles * v.K, e->grid_cls));
+  const unsigned gc = (unsigned)std::min<long long>((long long)v.ntiles * v.K, e->grid_cls);
   if (v.ntiles > 0 && e->cls_on) {
     // one launch for all classes (shards), or the classes with time-weighted moments (periodic, when Z / theta gradients are
     // wanted) in a kernel of their own
     const bool fused = e->cls_fused == 1 || (e->cls_fused < 0 && (long long)v.R * v.K <= 4096);
     const bool tw = !fused && full && v.ntype[SV_PERIODIC] > 0;
-    if (full && want_c && !have_w) hipLaunchKernelGGL(k_spike_pre, gi, bs, 0, sk, v);
+    const int dc = (full && want_c) ? 1 : 0;
+    if (dc && !have_w) sv_launch_spike_pre(v, sk);
     if (fused) {
-      if (full && want_c) hipLaunchKernelGGL((k_spike_cls_all<1>), gc, bs, 0, sk, v, C, 1);
-      else hipLaunchKernelGGL((k_spike_cls_all<0>), gc, bs, 0, sk, v, C, full ? 1 : 0);
-    } else if (full && want_c) {
-      if (tw) hipLaunchKernelGGL((k_spike_cls<4, 1>), gc, bs, 0, sk, v, C, 1);
-      hipLaunchKernelGGL((k_spike_cls<2, 1>), gc, bs, 0, sk, v, C, 1);
+      sv_launch_spike_cls(v, C, 0, dc, (dc || full) ? 1 : 0, gc, sk);
     } else {
-      if (tw) hipLaunchKernelGGL((k_spike_cls<4, 0>), gc, bs, 0, sk, v, C, 1);
-      hipLaunchKernelGGL((k_spike_cls<2, 0>), gc, bs, 0, sk, v, C, full ? 1 : 0);
+      if (tw) sv_launch_spike_cls(v, C, 4, dc, 1, gc, sk);
+      sv_launch_spike_cls(v, C, 2, dc, (dc || full) ? 1 : 0, gc, sk);
     }
   }
-  if (!v.comb_fold && e->cls_on) {
-    if (full) hipLaunchKernelGGL(k_spike_comb<true>, gi, bs, 0, sk, v);
-    else hipLaunchKernelGGL(k_spike_comb<false>, gi, bs, 0, sk, v);
-  }
+  if (!v.comb_fold && e->cls_on) sv_launch_spike_comb(v, full, sk);
   launch_pair_pass(e, sk, full, want_c, C);
 }
 
@@ -815,7 +818,10 @@ static int enqueue_elbo(svgpfa_engine* e, const PtrTable& pt, const ElboPlan& pl
   hipStream_t sm = e->stream;
   // the class path's W rides in k_prep when this evaluation's spike pass wants dC
   const bool have_w = pl.run_spike && pl.full && (mask & 2u) && e->cls_on && v.ntiles > 0;
-  launch_prep(e, pt, have_w);
+  // whitened parameters (ut, a, Vt, KL), the class path's W and the quadrature statistics: one launch (k_front);
+  // SVGPFA_FRONT=0 keeps k_prep_mfma and k_times_fwd_mfma as launches of their own
+  if (e->front) launch_front(e, pt, have_w);
+  else launch_prep(e, pt, have_w);
   // ---- spike pass (fp64 VALU bound): needs only a = Kzz^-1 m (and W) from k_prep
   if (pl.run_spike) {
     const int evp = timing_begin(e, 0, sm);
@@ -823,7 +829,7 @@ static int enqueue_elbo(svgpfa_engine* e, const PtrTable& pt, const ElboPlan& pl
     timing_end(e, evp, sm);
   }
   // ---- quadrature chain (f64 MFMA): posterior statistics at the nodes -> ELL term and its adjoints
-  if ((rc = launch_times_quad(e, sm))) return rc;
+  if (!e->front && (rc = launch_times_quad(e, sm))) return rc;
   if ((rc = launch_quad_ell(e, sm, C, d, (mask & 2u) ? 1 : 0, pl.want_lat ? 1 : 0))) return rc;
   // ---- per-item adjoints + backward + the fixed-order cross-trial reductions in one kernel
   const int evb = timing_begin(e, 1, sm);

@@ -178,7 +178,7 @@ def test_not_positive_definite_raises():
 
 @pytest.mark.parametrize("env", [{"SVGPFA_COMB_FOLD": "0"}, {"SVGPFA_COMB_FOLD": "1"}, {"SVGPFA_TILE_NW": "2"},
                                  {"SVGPFA_TILE_NW": "4"}, {"SVGPFA_CLS_FUSED": "0"}, {"SVGPFA_CLS_FUSED": "1"},
-                                 {"SVGPFA_ELL_PARTS": "3"}, {"SVGPFA_TIMES_NW": "2"}],
+                                 {"SVGPFA_ELL_PARTS": "3"}, {"SVGPFA_FRONT": "0"}, {"SVGPFA_FRONT": "0", "SVGPFA_TIMES_NW": "2"}],
                          ids=lambda e: "-".join(f"{k[7:].lower()}{v}" for k, v in e.items()))
 def test_launch_switches_agree_with_the_default(monkeypatch, env):
     """Every launch-strategy switch of the engine (README.md, environment) at its non-default values against the default
@@ -192,7 +192,7 @@ def test_launch_switches_agree_with_the_default(monkeypatch, env):
         prob["theta"][k] = prob["theta"][k] * np.array([lsc, psc][:len(prob["theta"][k])])
     outs = []
     for e in ({}, env):
-        for var in ("SVGPFA_COMB_FOLD", "SVGPFA_TILE_NW", "SVGPFA_CLS_FUSED", "SVGPFA_ELL_PARTS", "SVGPFA_TIMES_NW"):
+        for var in ("SVGPFA_COMB_FOLD", "SVGPFA_TILE_NW", "SVGPFA_CLS_FUSED", "SVGPFA_ELL_PARTS", "SVGPFA_TIMES_NW", "SVGPFA_FRONT"):
             monkeypatch.delenv(var, raising=False)
         for k, v in e.items():
             monkeypatch.setenv(k, v)
