@@ -65,7 +65,7 @@ __global__ __launch_bounds__(64) void k_spike_pre(EngineView ev) {
 // ------------------------------------------------------------------------------------------------ k_spike_cls
 // One register pass over the rows' spikes: harmonics h0 .. h0 + HB - 1 of every row (lane) of the tile.
 //   acc[NV n + 0] = sum_s cos((h0 + n) theta_s)   [+1] = sin   ([+2], [+3]: the same weighted by t_s, NV = 4)
-// (cos, sin) of the multiples by rotation (error ~ n ulp); a later pass starts from one direct sincos of h0 theta.
+// (cos, sin) of the multiples by the three-term recurrence; a later pass starts from direct sincos of (h0 - 1) theta, h0 theta.
 template <int NV, int HB>
 __device__ __forceinline__ void cls_pass(const double* __restrict__ tt, int maxlen, int len, int lane, double t0,
                                          double sc, int h0, double (&acc)[NV * HB]) {
@@ -93,9 +93,20 @@ __device__ __forceinline__ void cls_pass(const double* __restrict__ tt, int maxl
       if (i0 + u < len) {
         const double t = tc[u];
         const double ph = (t - t0) * sc;
-        double s1, c1, cn = 1.0, sn = 0.0;
+        // (cos, sin) of the multiples of theta by the three-term recurrence  f((n + 1) theta) = 2 cos(theta) f(n theta) -
+        // f((n - 1) theta): ONE FMA per value (the rotation by theta it replaces: two multiplies and two FMAs per pair --
+        // with the two accumulations 4 instead of 6 instructions per spike and harmonic).  Its rounding error grows like
+        // n^2 u in the worst case (theta near a multiple of pi) against n u for the rotation: <= 64^2 u = 5e-13 at the
+        // largest harmonic this path admits, on terms that enter the sums with the series' fast-decaying coefficients.
+        double s1, c1, cn = 1.0, sn = 0.0, cp, sp;
         sv_sincos_quarter(ph, s1, c1);
-        if (h0 > 0) sv_sincos_quarter(ph * (double)h0, sn, cn);
+        cp = c1;                                         // cos(-theta), sin(-theta): the values "before" harmonic 0
+        sp = -s1;
+        if (h0 > 0) {
+          sv_sincos_quarter(ph * (double)h0, sn, cn);
+          sv_sincos_quarter(ph * (double)(h0 - 1), sp, cp);
+        }
+        const double k2 = c1 + c1;
 #pragma unroll
         for (int n = 0; n < HB; ++n) {
           acc[NV * n + 0] += cn;
@@ -104,19 +115,26 @@ __device__ __forceinline__ void cls_pass(const double* __restrict__ tt, int maxl
             acc[NV * n + 2] = fma(t, cn, acc[NV * n + 2]);
             acc[NV * n + 3] = fma(t, sn, acc[NV * n + 3]);
           }
-          const double tq = cn * c1 - sn * s1;          // (cos, sin) of (n + 1) theta: rotation by theta
-          sn = fma(sn, c1, cn * s1);
-          cn = tq;
+          const double cq = fma(k2, cn, -cp), sq = fma(k2, sn, -sp);
+          cp = cn;
+          sp = sn;
+          cn = cq;
+          sn = sq;
         }
       }
     }
   }
 }
 
-// What follows a pass, 16 columns at a time: the rows' sums go through a (swizzled, conflict-free) LDS tile
-// Ut[row][16] so that the tile's partial A-moments  Apart[member][col] = sum_rows C[neuron(row), member] U[row][col]
-// come out of 16 v_mfma_f64_16x16x4_f64 (A operand: the gathered embedding weights cg, B operand: U); and, DC, the
-// rows' own dC partials  dcl[member][row] += sum_cols U[row][col] W[member][col]  on the VALU (W is wave-uniform).
+// What follows a pass.  The rows' sums go, 16 columns at a time, through a (swizzled, conflict-free) LDS tile Ut[row][16]
+// so that the tile's partial A-moments  Apart[member][col] = sum_rows C[neuron(row), member] U[row][col]  come out of 16
+// v_mfma_f64_16x16x4_f64 (A operand: the gathered embedding weights cg, B operand: U); and, DC, the rows' own dC partials
+// dcl[member][row] += sum_cols U[row][col] W[member][col]  on the VALU (W is wave-uniform).
+// Order (round 4; diagnosis builds had shown the flush to take as long as the pass over the spikes, 16 of an item's 36 us):
+// every LOAD of the flush -- W, then the embedding weights -- is issued and consumed before its first STORE to global
+// memory, and the A-moment tiles stay in registers until the end: a wait for a load is then never a wait for an earlier
+// store as well (one counter serves both on this chip).  The dC rows come first, while all accumulators are live anyway;
+// their sums run as two independent FMA chains per member (cos / sin columns) instead of one of 2 HB links.
 template <int NV, int HB, int DC>
 __device__ __forceinline__ void cls_flush(const EngineView& ev, const double* __restrict__ C, const double (&acc)[NV * HB],
                                           int neuron, int nrows, int memk, int nmem, int tile, int g, int r, int h0, int H,
@@ -128,6 +146,40 @@ __device__ __forceinline__ void cls_flush(const EngineView& ev, const double* __
   for (int c = 0; c < NV * HB; ++c) asm volatile("" ::"v"(acc[c]));
   return;
 #endif
+  if (DC == 1) {
+    // W of the members for this pass's harmonics, staged through the (idle) transpose tile: [member][2 HB], entries
+    // beyond the last harmonic are zeros (spike_pre_item).  Coalesced loads, all in flight, then broadcast reads.
+    constexpr int WP = 2 * HB, NWV = (SV_CLS_MAXMEM * WP + 63) / 64;      // doubles per member and pass; per lane at most
+    const int tot = nmem * WP;
+    double wv[NWV];
+#pragma unroll
+    for (int u = 0; u < NWV; ++u) {
+      wv[u] = 0.0;
+      if (u * 64 < tot) {                  // wave-uniform: only the loads the class's members need
+        const int e = u * 64 + lane, sm = (e < tot) ? e / WP : 0, c = (e < tot) ? e % WP : 0;
+        const int mk = __shfl(memk, sm, 64);
+        const int col = 2 * h0 + c;
+        wv[u] = ev.Wb[((long long)r * K + mk) * SV_WCOLS + (col < SV_WCOLS ? col : 0)];
+        if (col >= SV_WCOLS) wv[u] = 0.0;
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < NWV; ++u)
+      if (u * 64 + lane < tot) Ut[u * 64 + lane] = wv[u];
+    lds_wave_fence();
+    for (int s = 0; s < nmem; ++s) {
+      const double* Wk = Ut + s * WP;
+      double v0 = 0.0, v1 = 0.0;
+#pragma unroll
+      for (int n = 0; n < HB; ++n) {
+        v0 = fma(acc[NV * n + 0], Wk[2 * n + 0], v0);
+        v1 = fma(acc[NV * n + 1], Wk[2 * n + 1], v1);
+      }
+      const double v = v0 + v1;
+      dcl[s * 64 + lane] = (h0 == 0) ? v : dcl[s * 64 + lane] + v;
+    }
+    lds_wave_fence();                      // the tile is free for the transposes
+  }
   // embedding weights in A-operand layout: cg[i] = C[neuron(row 4 i + lg)][member li]  (unconditional loads from valid
   // addresses, then masked: padding rows carry neuron 0).  Fetched here, behind the pass, so that they do not occupy 32
   // registers through it; C (N K doubles) stays in L1 / L2.
@@ -142,59 +194,38 @@ __device__ __forceinline__ void cls_flush(const EngineView& ev, const double* __
 #pragma unroll
     for (int i = 0; i < 16; ++i) cg[i] = (4 * i + lg < nrows && li < nmem) ? cg[i] : 0.0;
   }
+  constexpr int NCH = NV * HB / 16;
+  d4 D[NCH];
 #pragma unroll
-  for (int c0 = 0; c0 < NV * HB; c0 += 16) {
+  for (int ch = 0; ch < NCH; ++ch) {
+    const int c0 = 16 * ch;
+    D[ch] = (d4){0.0, 0.0, 0.0, 0.0};
     if (NV * h0 + c0 < ncol) {             // wave-uniform: whole chunks beyond the last harmonic are skipped
 #pragma unroll
       for (int c = 0; c < 16; ++c) Ut[lane * 16 + (c ^ li)] = acc[c0 + c];
       lds_wave_fence();
-      d4 D = {0.0, 0.0, 0.0, 0.0};
+      d4 Dc = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
       for (int i = 0; i < 16; ++i) {
         const int row = 4 * i + lg;
-        D = __builtin_amdgcn_mfma_f64_16x16x4f64(cg[i], Ut[row * 16 + (li ^ (row & 15))], D, 0, 0, 0);
+        Dc = __builtin_amdgcn_mfma_f64_16x16x4f64(cg[i], Ut[row * 16 + (li ^ (row & 15))], Dc, 0, 0, 0);
       }
-      const int col = NV * h0 + c0 + li;
-      if (col < ncol) {
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const int s = lg + 4 * q;        // f64 accumulator layout: register q holds row (lane >> 4) + 4 q
-          const int mk = __shfl(memk, s < nmem ? s : 0, 64);
-          if (s < nmem) ev.Apart[((long long)tile * K + mk) * SV_ACOLS + col] = D[q];
-        }
-      }
+      D[ch] = Dc;
       lds_wave_fence();                    // the tile is free for the next chunk
     }
   }
-  if (DC == 1) {
-    // W of the members for this pass's harmonics, staged through the (now idle) transpose tile: [member][2 HB], entries
-    // beyond the last harmonic are zeros (k_spike_pre).  Coalesced loads, all in flight, then broadcast reads.
-    constexpr int WP = 2 * HB;                       // doubles per member and pass
-    const int tot = nmem * WP;
-    double wv[(SV_CLS_MAXMEM * WP + 63) / 64];
+  // ---- stores: the tile's A-moment partials (f64 accumulator layout: register q holds row (lane >> 4) + 4 q = member)
+  int mkq[4];
 #pragma unroll
-    for (int u = 0; u < (SV_CLS_MAXMEM * WP + 63) / 64; ++u) {
-      const int e = u * 64 + lane, sm = (e < tot) ? e / WP : 0, c = (e < tot) ? e % WP : 0;
-      const int mk = __shfl(memk, sm, 64);
-      const int col = 2 * h0 + c;
-      wv[u] = ev.Wb[((long long)r * K + mk) * SV_WCOLS + (col < SV_WCOLS ? col : 0)];
-      if (col >= SV_WCOLS) wv[u] = 0.0;
+  for (int q = 0; q < 4; ++q) mkq[q] = __shfl(memk, (lg + 4 * q < nmem) ? lg + 4 * q : 0, 64);
+#pragma unroll
+  for (int ch = 0; ch < NCH; ++ch) {
+    const int col = NV * h0 + 16 * ch + li;
+    if (col < ncol) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+        if (lg + 4 * q < nmem) ev.Apart[((long long)tile * K + mkq[q]) * SV_ACOLS + col] = D[ch][q];
     }
-#pragma unroll
-    for (int u = 0; u < (SV_CLS_MAXMEM * WP + 63) / 64; ++u)
-      if (u * 64 + lane < tot) Ut[u * 64 + lane] = wv[u];
-    lds_wave_fence();
-    for (int s = 0; s < nmem; ++s) {
-      const double* Wk = Ut + s * WP;
-      double v = 0.0;
-#pragma unroll
-      for (int n = 0; n < HB; ++n) {
-        v = fma(acc[NV * n + 0], Wk[2 * n + 0], v);
-        v = fma(acc[NV * n + 1], Wk[2 * n + 1], v);
-      }
-      dcl[s * 64 + lane] = (h0 == 0) ? v : dcl[s * 64 + lane] + v;
-    }
-    lds_wave_fence();                                // the tile is free for the next pass
   }
 }
 
