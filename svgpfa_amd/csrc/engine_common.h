@@ -23,6 +23,8 @@
 
 #include "sv_math.h"
 
+typedef double d4 __attribute__((ext_vector_type(4)));      // accumulator tile of v_mfma_f64_16x16x4_f64
+
 #define SV_RBF 0
 #define SV_PERIODIC 1
 #define SV_MAX_M 64

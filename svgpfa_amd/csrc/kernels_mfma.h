@@ -21,7 +21,6 @@
 #include "engine_common.h"
 #include "spike_cls_common.h"
 
-typedef double d4 __attribute__((ext_vector_type(4)));
 
 // D[a] = sum_b sum_r mfma(Afrag(a, b, r), B[b][r]);  Mat is lower triangular (zero padded).
 // MODE 0: A = Mat   -> tiles b <= a, Afrag = Mat[16a + (l&15)][16b + 4r + (l>>4)]

@@ -139,7 +139,7 @@ template <int NV, int HB, int DC>
 __device__ __forceinline__ void cls_flush(const EngineView& ev, const double* __restrict__ C, const double (&acc)[NV * HB],
                                           int neuron, int nrows, int memk, int nmem, int tile, int g, int r, int h0, int H,
                                           double* Ut, double* dcl) {
-  const int lane = threadIdx.x, li = lane & 15, lg = lane >> 4, K = ev.K;
+  const int lane = threadIdx.x & 63, li = lane & 15, lg = lane >> 4, K = ev.K;
   const int ncol = NV * (H + 1);           // valid columns of the class's moment rows
 #if defined(SV_CLS_DIAG) && SV_CLS_DIAG == 1     // diagnosis build: no flush (results are wrong), the pass alone is timed
 #pragma unroll
@@ -234,7 +234,7 @@ __device__ __forceinline__ void cls_flush(const EngineView& ev, const double* __
 // item changes between this path and the pair loop; pieces of an oversize segment go to their slot
 __device__ __forceinline__ void cls_emit_rows(const EngineView& ev, const SpikeRow& row, int r, int memk, int nmem,
                                               const double* dcl) {
-  const int lane = threadIdx.x, K = ev.K;
+  const int lane = threadIdx.x & 63, K = ev.K;
   if (row.len <= 0) return;
   for (int s = 0; s < nmem; ++s) {
     const int k = __shfl(memk, s, 64);
@@ -257,7 +257,7 @@ template <int NV, int DC>
 __device__ __forceinline__ void cls_item(const EngineView& ev, const double* __restrict__ C, const SpikeClassTab* cls,
                                          int g, int ord, double* Ut, double* dcl) {
   constexpr int HBM = (NV == 2) ? 24 : 16;          // largest register pass: 48 / 64 accumulators
-  const int lane = threadIdx.x, K = ev.K, R = ev.R;
+  const int lane = threadIdx.x & 63, K = ev.K, R = ev.R;      // (a wave of a larger block in k_ell_cls)
   const SpikeTile tl = ev.tiles_ord[ord];           // tiles in cost order (a copy: one dependent load less than through an index)
   const int r = tl.trial, tile = tl.id;
   // everything the item needs that hangs off (tile, class), requested together
@@ -328,6 +328,42 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 8))) void
   const int ncls = cls->ncls;
   const int nitems = ev.ntiles * ncls;
   for (int w = blockIdx.x; w < nitems; w += gridDim.x) {
+    const int g = w % ncls;
+    if (full && cls->type[g] == SV_PERIODIC) cls_item<4, DC>(ev, C, cls, g, w / ncls, Ut, dcl);
+    else cls_item<2, DC>(ev, C, cls, g, w / ncls, Ut, dcl);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ k_ell_cls
+// Small shards (up to 4 096 items, fp64): the quadrature term's two roles (kernels_mfma.h quad_ell_mfma_body) AND the class
+// items of the spike pass in ONE launch -- blocks [0, nell) are the ELL blocks of k_quad_ell_mfma<KS, 2>, every wave of the
+// blocks behind them is a class worker of k_spike_cls_all (its own slice of the block's LDS; workers stride over the
+// (tile, class) items).  Neither depends on the other (both follow k_front, both precede k_item_bwd), each is ONE
+// under-filled round of the chip on a shard (8-way shard of cfg3: 504 blocks of four waves for 24 us, ~1 000 single-wave
+// items for 25 us), and two kernels share the chip best inside one launch: 49 -> ~30 us.
+// grid = nell + ceil(workers / 4) blocks of 256 threads; dynamic LDS = max(ELL roles, 4 worker slices).
+#define SV_CLS_SLICE (64 * 16 + SV_CLS_MAXMEM * 64)       // doubles of LDS per class worker: transpose tile + dC rows
+template <int KS, int DC>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_ell_cls(EngineView ev,
+                                                                                             const double* __restrict__ C,
+                                                                                             const double* d, int want_sums,
+                                                                                             int want_lat, int parts, int lc0,
+                                                                                             int lc1, int full, int nell) {
+  extern __shared__ double sm[];
+  if ((int)blockIdx.x < nell) {
+    const int nb = ev.R * parts;
+    if ((int)blockIdx.x < nb) quad_ell_mfma_body<KS, 0, double>(ev, C, d, want_sums, 1, parts, lc0, blockIdx.x, sm);
+    else quad_ell_mfma_body<KS, 1, double>(ev, C, d, 1, 0, parts, lc1, blockIdx.x - nb, sm);
+    return;
+  }
+  const int wave = threadIdx.x >> 6;
+  double* Ut = sm + wave * SV_CLS_SLICE;
+  double* dcl = Ut + 64 * 16;
+  const SpikeClassTab* cls = ev.cls;
+  const int ncls = cls->ncls;
+  const int nitems = ev.ntiles * ncls;
+  const int nwork = ((int)gridDim.x - nell) * 4;
+  for (int w = ((int)blockIdx.x - nell) * 4 + wave; w < nitems; w += nwork) {
     const int g = w % ncls;
     if (full && cls->type[g] == SV_PERIODIC) cls_item<4, DC>(ev, C, cls, g, w / ncls, Ut, dcl);
     else cls_item<2, DC>(ev, C, cls, g, w / ncls, Ut, dcl);

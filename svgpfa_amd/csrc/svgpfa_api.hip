@@ -62,6 +62,9 @@ struct svgpfa_engine {
   // boundary -- a drained chip -- less: one rank's shard of cfg3, ms per evaluation, two kernels -> one: 2-way 0.405 -> 0.386,
   // 4-way 0.266 -> 0.249, 8-way 0.198 -> 0.176; at the full 5 000 items 0.655 / 0.659).  SVGPFA_CLS_FUSED=0 / 1 forces it.
   int cls_fused = -1;
+  int n_cu = 256;                               // compute units of the device
+  bool ell_cls = true;                          // small shards: ELL blocks and class items in one launch (SVGPFA_ELL_CLS=0: off)
+  int build_mode = -1;                          // kernel build above M = 16: -1 by size, 0 k_build_reg, 1 k_build_mfma (SVGPFA_BUILD=reg|mfma)
   bool front = true;                            // k_front instead of k_prep_mfma + k_times_fwd_mfma in svgpfa_elbo (SVGPFA_FRONT=0: off)
   bool cls_on = true;                           // false: problem too small for the class path's extra launches (set_spikes)
   double series_min_pairs = 1e7;                // SVGPFA_SERIES_MIN_PAIRS: fewest (spike, inducing point) pairs for the class path
@@ -273,6 +276,10 @@ int svgpfa_create(const svgpfa_dims* d, int device, svgpfa_engine** out) {
     v.rbf_series = (rs && atoi(rs) == 0) ? 0 : 1;
     const char* mp = getenv("SVGPFA_SERIES_MIN_PAIRS");
     if (mp) e->series_min_pairs = atof(mp);
+    const char* ec = getenv("SVGPFA_ELL_CLS");
+    e->ell_cls = !(ec && atoi(ec) == 0);
+    const char* br = getenv("SVGPFA_BUILD");
+    if (br) e->build_mode = !strcmp(br, "reg") ? 0 : (!strcmp(br, "mfma") ? 1 : -1);
     const char* fr = getenv("SVGPFA_FRONT");
     e->front = !(fr && atoi(fr) == 0);
     const char* ps = getenv("SVGPFA_PERIODIC_SERIES");
@@ -285,11 +292,16 @@ int svgpfa_create(const svgpfa_dims* d, int device, svgpfa_engine** out) {
     int bc = 0, bp = 0;
     bc = sv_spike_cls_blocks_per_cu();
     HIPCHK(e, hipOccupancyMaxActiveBlocksPerMultiprocessor(&bp, (const void*)k_spike<true, double, true>, 64, 0));
+    e->n_cu = prop.multiProcessorCount;
     e->grid_cls = std::max(8, prop.multiProcessorCount * std::max(1, bc));
     e->grid_pair = std::max(8, (prop.multiProcessorCount * std::max(1, bp)) & ~7);
   }
 
   int rc = 0;
+  if (e->NT == 2) rc = allow_lds(e, (k_build_mfma<2>), sv_build_mfma_lds(2, v.K, true));
+  else if (e->NT == 3) rc = allow_lds(e, (k_build_mfma<3>), sv_build_mfma_lds(3, v.K, true));
+  else if (e->NT == 4) rc = allow_lds(e, (k_build_mfma<4>), sv_build_mfma_lds(4, v.K, true));
+  if (rc) return rc;
   DISPATCH_NT(e->NT, rc = allow_lds(e, (k_prep_mfma<NT_>), lds_prep_mfma(NT_));
               if (!rc) rc = allow_lds(e, (k_front<NT_>), sv_front_lds(NT_));
               if (!rc) rc = allow_lds(e, (k_times_fwd_mfma<NT_>), lds_times_mfma(NT_));
@@ -595,12 +607,32 @@ static void launch_build(svgpfa_engine* e, int write_aux, const SnapTable* snap,
   if (e->Mmax <= 16) {
     hipLaunchKernelGGL(k_build_reg<16>, dim3(v.K * ((v.R + 3) / 4) + extra), dim3(64), sv_build_lds(16, v.K, c), e->stream, v,
                        write_aux, snap ? 1 : 0, snap ? *snap : none, c);
-  } else if (e->Mmax <= 32) {
-    hipLaunchKernelGGL(k_build_reg<32>, dim3(v.K * ((v.R + 1) / 2) + extra), dim3(64), sv_build_lds(32, v.K, c), e->stream, v,
-                       write_aux, snap ? 1 : 0, snap ? *snap : none, c);
-  } else {   // M <= 64 (checked at creation): one item per wave, 64 rows, 256 VGPRs of matrix data
-    hipLaunchKernelGGL(k_build_reg<64>, dim3(v.K * v.R + extra), dim3(64), sv_build_lds(64, v.K, c), e->stream, v, write_aux,
-                       snap ? 1 : 0, snap ? *snap : none, c);
+  } else if (e->build_mode == 0 || (e->build_mode < 0 && e->Mmax <= 32)) {
+    // register-resident kernels: the default up to M = 32 (cfg3: 38.6 us against 50-65 us for the blocked kernel at one, two
+    // or four items per wave -- with ~2 500 waves either is one round of the chip and the shorter single-wave latency wins);
+    // SVGPFA_BUILD=reg forces them above
+    if (e->Mmax <= 32)
+      hipLaunchKernelGGL(k_build_reg<32>, dim3(v.K * ((v.R + 1) / 2) + extra), dim3(64), sv_build_lds(32, v.K, c), e->stream, v,
+                         write_aux, snap ? 1 : 0, snap ? *snap : none, c);
+    else
+      hipLaunchKernelGGL(k_build_reg<64>, dim3(v.K * v.R + extra), dim3(64), sv_build_lds(64, v.K, c), e->stream, v, write_aux,
+                         snap ? 1 : 0, snap ? *snap : none, c);
+  } else {                         // M > 32 (SVGPFA_BUILD=mfma: M > 16): blocked, tile products on the f64 MFMA (k_build_mfma;
+                                   // cfg5: 1.13 ms against 1.62 ms for k_build_reg<64>, which holds 64 x 64 doubles per item in registers)
+    switch (e->NT) {
+      case 2:
+        hipLaunchKernelGGL(k_build_mfma<2>, dim3(v.K * ((v.R + sv_build_ipw(2) - 1) / sv_build_ipw(2)) + extra), dim3(64), sv_build_mfma_lds(2, v.K, c), e->stream,
+                           v, write_aux, snap ? 1 : 0, snap ? *snap : none, c);
+        break;
+      case 3:
+        hipLaunchKernelGGL(k_build_mfma<3>, dim3(v.K * ((v.R + sv_build_ipw(3) - 1) / sv_build_ipw(3)) + extra), dim3(64), sv_build_mfma_lds(3, v.K, c), e->stream,
+                           v, write_aux, snap ? 1 : 0, snap ? *snap : none, c);
+        break;
+      default:
+        hipLaunchKernelGGL(k_build_mfma<4>, dim3(v.K * v.R + extra), dim3(64), sv_build_mfma_lds(4, v.K, c), e->stream, v,
+                           write_aux, snap ? 1 : 0, snap ? *snap : none, c);
+        break;
+    }
   }
 }
 
@@ -776,13 +808,17 @@ static void launch_pair_pass(svgpfa_engine* e, hipStream_t sk, bool full, bool w
 // wanted (only with full); have_w: k_prep made the class path's W (else k_spike_pre does, here).  Class path (cosine
 // series, kernels_spike_cls.h) for the (trial, latent) items it serves, the pair-by-pair pass (kernels_spike.h) for the
 // rest; both stride fixed grids over work lists that live on the device.
+// one launch for all classes of the class path (shards), or the classes with time-weighted moments (periodic, when Z / theta
+// gradients are wanted) in a kernel of their own
+static bool cls_one_launch(const svgpfa_engine* e) {
+  return e->cls_fused == 1 || (e->cls_fused < 0 && (long long)e->v.R * e->v.K <= 4096);
+}
+
 static void launch_spike_pass(svgpfa_engine* e, hipStream_t sk, bool full, bool want_c, const double* C, bool have_w) {
   EngineView& v = e->v;
   const unsigned gc = (unsigned)std::min<long long>((long long)v.ntiles * v.K, e->grid_cls);
   if (v.ntiles > 0 && e->cls_on) {
-    // one launch for all classes (shards), or the classes with time-weighted moments (periodic, when Z / theta gradients are
-    // wanted) in a kernel of their own
-    const bool fused = e->cls_fused == 1 || (e->cls_fused < 0 && (long long)v.R * v.K <= 4096);
+    const bool fused = cls_one_launch(e);
     const bool tw = !fused && full && v.ntype[SV_PERIODIC] > 0;
     const int dc = (full && want_c) ? 1 : 0;
     if (dc && !have_w) sv_launch_spike_pre(v, sk);
@@ -823,25 +859,47 @@ static int enqueue_elbo(svgpfa_engine* e, const PtrTable& pt, const ElboPlan& pl
   if (e->front) launch_front(e, pt, have_w);
   else launch_prep(e, pt, have_w);
   // ---- spike pass (fp64 VALU bound): needs only a = Kzz^-1 m (and W) from k_prep
+  // Small shards (one launch for all classes, fp64, quadrature statistics already made by k_front): the ELL blocks and the
+  // class items share ONE launch (k_ell_cls) -- both follow k_front, both precede k_item_bwd, neither fills the chip.
+  const bool merged = e->ell_cls && e->front && pl.run_spike && e->cls_on && v.ntiles > 0 && cls_one_launch(e) &&
+                      e->precision == SVGPFA_PRECISION_FP64;
+  // Blocks per trial of the merged launch's ELL part: its blocks and the class workers' blocks hold the same 64 KB of LDS, two
+  // per CU, so the ELL part may take at most half of the chip's 2 x CUs slots or the class items queue up behind it (measured
+  // with the engine's usual four blocks per trial: 504 ELL blocks, 48.6 us = the two kernels one after the other)
+  int parts_m = e->ell_parts;
+  while (merged && parts_m > 1 && (long long)v.R * parts_m * 2 > e->n_cu) parts_m >>= 1;
+  EngineView ve = v;               // this evaluation's view: the number of ELL partials follows the blocks per trial
+  if (merged) ve.nell = v.R * parts_m;
   if (pl.run_spike) {
     const int evp = timing_begin(e, 0, sm);
-    launch_spike_pass(e, sm, pl.full, (mask & 2u) != 0, C, have_w);
+    if (merged) {
+      const bool full = pl.full, want_c = (mask & 2u) != 0;
+      const int dc = (full && want_c) ? 1 : 0;          // (have_w holds whenever dc does: k_front made W)
+      const unsigned workers = (unsigned)std::min<long long>((long long)v.ntiles * v.K, e->grid_cls);
+      const size_t lds_ell = pl.want_lat ? std::max(lds_qell_mfma(e, 0), lds_qell_mfma(e, 1)) : lds_qell_mfma(e, 0);
+      HIPCHK(e, sv_launch_ell_cls(ve, C, d, e->KKT, dc, want_c ? 1 : 0, pl.want_lat ? 1 : 0, parts_m, e->ell_lc[0], e->ell_lc[1],
+                                  full ? 1 : 0, workers, lds_ell, sm));
+      if (!v.comb_fold) sv_launch_spike_comb(v, full, sm);
+      launch_pair_pass(e, sm, full, want_c, C);
+    } else {
+      launch_spike_pass(e, sm, pl.full, (mask & 2u) != 0, C, have_w);
+    }
     timing_end(e, evp, sm);
   }
   // ---- quadrature chain (f64 MFMA): posterior statistics at the nodes -> ELL term and its adjoints
   if (!e->front && (rc = launch_times_quad(e, sm))) return rc;
-  if ((rc = launch_quad_ell(e, sm, C, d, (mask & 2u) ? 1 : 0, pl.want_lat ? 1 : 0))) return rc;
+  if (!merged && (rc = launch_quad_ell(e, sm, C, d, (mask & 2u) ? 1 : 0, pl.want_lat ? 1 : 0))) return rc;
   // ---- per-item adjoints + backward + the fixed-order cross-trial reductions in one kernel
   const int evb = timing_begin(e, 1, sm);
   if (mask & (4u | 8u)) {
     DISPATCH_NT(e->NT, hipLaunchKernelGGL((k_item_bwd<NT_, true>), dim3(v.R * v.K), dim3(64 * e->tile_nw),
-                                          lds_item_bwd(NT_, e->tile_nw, true), sm, v, pt, mask, C, d, shared));
+                                          lds_item_bwd(NT_, e->tile_nw, true), sm, ve, pt, mask, C, d, shared));
   } else {
     DISPATCH_NT(e->NT, hipLaunchKernelGGL((k_item_bwd<NT_, false>), dim3(v.R * v.K), dim3(64 * e->tile_nw),
-                                          lds_item_bwd(NT_, e->tile_nw, false), sm, v, pt, mask, C, d, shared));
+                                          lds_item_bwd(NT_, e->tile_nw, false), sm, ve, pt, mask, C, d, shared));
   }
   timing_end(e, evb, sm);
-  hipLaunchKernelGGL(k_fin_items, dim3(v.nth_total + SV_FIN_NS), dim3(256), 0, sm, v, mask, shared);
+  hipLaunchKernelGGL(k_fin_items, dim3(v.nth_total + SV_FIN_NS), dim3(256), 0, sm, ve, mask, shared);
   HIPCHK(e, hipGetLastError());
   return SVGPFA_OK;
 }

@@ -178,7 +178,8 @@ def test_not_positive_definite_raises():
 
 @pytest.mark.parametrize("env", [{"SVGPFA_COMB_FOLD": "0"}, {"SVGPFA_COMB_FOLD": "1"}, {"SVGPFA_TILE_NW": "2"},
                                  {"SVGPFA_TILE_NW": "4"}, {"SVGPFA_CLS_FUSED": "0"}, {"SVGPFA_CLS_FUSED": "1"},
-                                 {"SVGPFA_ELL_PARTS": "3"}, {"SVGPFA_FRONT": "0"}, {"SVGPFA_FRONT": "0", "SVGPFA_TIMES_NW": "2"}],
+                                 {"SVGPFA_ELL_PARTS": "3"}, {"SVGPFA_FRONT": "0"}, {"SVGPFA_FRONT": "0", "SVGPFA_TIMES_NW": "2"},
+                                 {"SVGPFA_BUILD": "mfma"}, {"SVGPFA_BUILD": "reg"}, {"SVGPFA_ELL_CLS": "0"}],
                          ids=lambda e: "-".join(f"{k[7:].lower()}{v}" for k, v in e.items()))
 def test_launch_switches_agree_with_the_default(monkeypatch, env):
     """Every launch-strategy switch of the engine (README.md, environment) at its non-default values against the default
@@ -186,13 +187,13 @@ def test_launch_switches_agree_with_the_default(monkeypatch, env):
     lengthscales a factor 4.5 apart): where a cross-wave / cross-block sum is dealt differently the results agree to
     rounding (1e-12 of the array maximum), not bit for bit."""
     from oracle import svgpfa_oracle as orc
-    prob = synthetic.make_problem(R=5, N=12, K=5, M=[10, 12, 9, 16, 11], kernels="mix", seed=13, n_quad=60, rate=25.0,
+    prob = synthetic.make_problem(R=5, N=12, K=5, M=[10, 24, 9, 40, 11], kernels="mix", seed=13, n_quad=60, rate=25.0,
                                   jitter=1.0)
     for k, (lsc, psc) in enumerate([(1.0, 1.0), (1.0, 1.0), (4.5, 1.0), (0.9, 1.07), (1.0, 0.93)]):
         prob["theta"][k] = prob["theta"][k] * np.array([lsc, psc][:len(prob["theta"][k])])
     outs = []
     for e in ({}, env):
-        for var in ("SVGPFA_COMB_FOLD", "SVGPFA_TILE_NW", "SVGPFA_CLS_FUSED", "SVGPFA_ELL_PARTS", "SVGPFA_TIMES_NW", "SVGPFA_FRONT"):
+        for var in ("SVGPFA_COMB_FOLD", "SVGPFA_TILE_NW", "SVGPFA_CLS_FUSED", "SVGPFA_ELL_PARTS", "SVGPFA_TIMES_NW", "SVGPFA_FRONT", "SVGPFA_BUILD", "SVGPFA_ELL_CLS"):
             monkeypatch.delenv(var, raising=False)
         for k, v in e.items():
             monkeypatch.setenv(k, v)
@@ -203,8 +204,9 @@ def test_launch_switches_agree_with_the_default(monkeypatch, env):
         eng.close()
     ref = orc.elbo_and_grads(orc.from_numpy_problem(prob), 15)
     assert abs(outs[0][0][0] - float(ref["elbo"])) <= 1e-9 * abs(float(ref["elbo"]))
+    tol = 1e-10 if "SVGPFA_BUILD" in env else 1e-12       # (another factorisation order: rounding of the Cholesky itself)
     for a, b in zip(outs[0], outs[1]):
-        assert rel_err(b, a) < 1e-12
+        assert rel_err(b, a) < tol
 
 
 def _drop_spikes(prob, keep_trial):
