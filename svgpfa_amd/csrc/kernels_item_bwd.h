@@ -569,7 +569,7 @@ __device__ __forceinline__ void item_bwd_body(const EngineView& ev, const int r,
         for (int b = 0; b <= a; ++b)
 #pragma unroll
           for (int q = 0; q < 4; ++q)
-            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(X0[b][q], Li[(16 * a + li) * LD + 16 * b + 4 * q + lg], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(X0[b][q], lds_frag(&Li[(16 * a + li) * LD + 16 * b + 4 * q + lg]), acc, 0, 0, 0);
         KwT[a] = acc;
       }
       if (tile == wave) SV_CK(6);
@@ -582,7 +582,7 @@ __device__ __forceinline__ void item_bwd_body(const EngineView& ev, const int r,
           for (int b = 0; b < NT; ++b)
 #pragma unroll
             for (int q = 0; q < 4; ++q)
-              acc = __builtin_amdgcn_mfma_f64_16x16x4f64(Dl[(16 * a + li) * LD + 16 * b + 4 * q + lg], X0[b][q], acc, 0, 0, 0);
+              acc = __builtin_amdgcn_mfma_f64_16x16x4f64(lds_frag(&Dl[(16 * a + li) * LD + 16 * b + 4 * q + lg]), X0[b][q], acc, 0, 0, 0);
           Gk[a] = acc;                                            // E kappa(t, Z): independent of KwT
         }
       }

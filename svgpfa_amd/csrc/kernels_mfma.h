@@ -36,8 +36,8 @@ __device__ __forceinline__ void tri_chain(d4 (&D)[NT], const double* Mat, int LD
       if (MODE == 0 ? (b <= a) : (b >= a)) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          double av = (MODE == 0) ? Mat[(16 * a + li) * LD + 16 * b + 4 * r + lg]
-                                  : Mat[(16 * b + 4 * r + lg) * LD + 16 * a + li];
+          double av = (MODE == 0) ? lds_frag(&Mat[(16 * a + li) * LD + 16 * b + 4 * r + lg])
+                                  : lds_frag(&Mat[(16 * b + 4 * r + lg) * LD + 16 * a + li]);
           acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, B[b][r], acc, 0, 0, 0);
         }
       }
