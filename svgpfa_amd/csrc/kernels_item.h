@@ -26,16 +26,23 @@
 // (reference semantics: later evaluations keep using the matrices of the last buildKernelsMatrices() call).
 // dynamic LDS of k_build_reg<MP> (bytes); cls: with the class riders, whose series workspace has one row per latent
 __host__ __device__ constexpr size_t sv_build_lds(int MP, int K, bool cls) {
-  const size_t lt = (size_t)64 * MP, rider = cls ? (sizeof(SpikeClassScratch) + 7) / 8 + (size_t)K * (SV_FH + 3) : 0;
+  const size_t lt = (size_t)32 * (MP + 1) + 64, rider = cls ? (sizeof(SpikeClassScratch) + 7) / 8 + (size_t)K * (SV_FH + 3) : 0;
   return 8 * (lt > rider ? lt : rider);
 }
 
-template <int MP>
-__global__ __launch_bounds__(64) void k_build_reg(EngineView ev, int write_aux, int snap, SnapTable st, int cls) {
+// WPE: waves per SIMD the compiler leaves room for.  At MP = 32 the kernel takes 185 registers (two waves per SIMD: 2 048
+// single-wave blocks resident), and the north-star size launches 3 010 blocks -- TWO rounds of a latency-bound kernel (39.9 us
+// against 19.4 us for the one round of an 8-way shard).  The WPE = 3 instantiation (168 registers, 10 spilled) holds 3 072
+// blocks at once: one round of 31 us.  On a launch that is one round either way it is the slower one (23.7 against ~20 us
+// at 1 516 blocks), so the host picks it only above 2 048 blocks (launch_build).
+template <int MP, int WPE = 1>
+__global__ __launch_bounds__(64, WPE) void k_build_reg(EngineView ev, int write_aux, int snap, SnapTable st, int cls) {
   constexpr int IPW = 64 / MP;
-  // Lt[item][q][i] = L[i][q]  (column-major: conflict-free writes); the rider blocks in front use the same bytes
-  extern __shared__ double smraw[];        // max(IPW MP MP, class rider: sv_build_lds) doubles
-  double (*Lt)[MP][MP] = reinterpret_cast<double (*)[MP][MP]>(smraw);
+  // Lt: column q of an item's L at q MP - q (q - 1) / 2, rows i >= q only (column-major: conflict-free writes; packed:
+  // 8.4 KB per block at MP = 32, so that LDS does not cap the resident blocks below what the registers allow); the rider
+  // blocks in front use the same bytes
+  extern __shared__ double smraw[];        // max(IPW MP (MP + 1) / 2, class rider: sv_build_lds) doubles
+  constexpr int PK = MP * (MP + 1) / 2;
   const int lane = threadIdx.x, sub = lane / MP, i = lane % MP, lbase = lane - i;
   const int rp = (ev.R + IPW - 1) / IPW;
   const int nser = snap ? ev.K : 0, ncb = (snap && cls) ? ev.R : 0;
@@ -117,14 +124,14 @@ __global__ __launch_bounds__(64) void k_build_reg(EngineView ev, int write_aux, 
   // step j: column j of L (all rows i >= j) and row j of Linv (all columns), pivots through v_rsq_f64 + 2 Newton
   double x[MP];
   bool bad = false;
-  const double* Lrow = &Lt[sub][0][0];
+  double* Lrow = smraw + sub * PK;
 #pragma unroll
   for (int j = 0; j < MP; ++j) {
     double s = a[j];
     double sx = (i == j) ? 1.0 : 0.0;
 #pragma unroll
     for (int q = 0; q < j; ++q) {
-      const double l = Lrow[q * MP + j];        // L[j][q]: same address in every lane of the item
+      const double l = Lrow[q * MP - q * (q - 1) / 2 + (j - q)];        // L[j][q]: same address in every lane of the item
       s = fma(-a[q], l, s);
       sx = fma(-l, x[q], sx);                   // lanes c > j: x[q] = 0 for q < c, so X[j][c] stays 0
     }
@@ -135,7 +142,9 @@ __global__ __launch_bounds__(64) void k_build_reg(EngineView ev, int write_aux, 
     ri = ri * fma(-0.5 * d * ri, ri, 1.5);
     a[j] = (i > j) ? s * ri : ((i == j) ? d * ri : 0.0);
     x[j] = sx * ri;
-    Lt[sub][j][i] = a[j];
+    // (lanes above the diagonal store to a dump slot of their own: a select on the address, where a conditional store
+    // put a branch into each of the MP unrolled steps and the register allocation fell apart -- 112 spills at MP = 32)
+    smraw[(i >= j) ? sub * PK + j * MP - j * (j - 1) / 2 + (i - j) : IPW * PK + lane] = a[j];
     lds_wave_fence();
     __builtin_amdgcn_sched_barrier(0);          // keep later rows' LDS reads from being hoisted (register pressure)
   }

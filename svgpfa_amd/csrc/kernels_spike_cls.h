@@ -35,6 +35,25 @@
 #include "engine_common.h"
 #include "kernels_mfma.h"
 #include "spike_cls_common.h"
+#include "spike_pair_common.h"
+
+// The pair-by-pair pass as a RIDER of a class kernel's workers (fp64): behind its class items worker `worker` strides over
+// the (chunk, latent) items the class path does not serve (pair_pass; it leaves at once when there are none, the usual
+// case).  The pass used to be a launch of its own behind the class kernels: 4.5-5 us per evaluation for finding nothing.
+// DC / full select the variant exactly as launch_pair_pass does for k_spike; lds: sv_pair_lds_doubles(full) doubles.
+template <int DC>
+__device__ __forceinline__ void cls_pair_rider(const EngineView& ev, const double* __restrict__ C, int full, double* lds,
+                                               int worker, int nworkers) {
+  if (DC == 1) pair_pass<true, double, true>(ev, C, lds, worker, nworkers);        // (DC == 1 implies full and dC wanted)
+  else if (full) pair_pass<true, double, false>(ev, C, lds, worker, nworkers);
+  else pair_pass<false, double, true>(ev, C, lds, worker, nworkers);
+}
+// doubles of LDS of a single-wave class block: the transpose tile and the dC rows, or the rider's area
+template <int NV, int DC>
+__host__ __device__ constexpr int sv_cls_block_lds() {
+  const int own = 64 * 16 + (DC == 1 ? SV_CLS_MAXMEM * 64 : 1), ride = (NV == 2) ? sv_pair_lds_doubles(true) : 0;
+  return own > ride ? own : ride;
+}
 
 // ------------------------------------------------------------------------------------------------ k_spike_classes
 // The class table and the per-trial entries for the engine's kernel SNAPSHOT, when the spikes arrived after the kernel
@@ -293,12 +312,14 @@ __device__ __forceinline__ void cls_item(const EngineView& ev, const double* __r
 // NV = 4: the classes that carry the time-weighted moments (periodic classes when Z / theta gradients are wanted: `full`);
 // NV = 2: all others.  Two kernels rather than one: the NV = 2 pass needs a third fewer registers.
 // DC: 1 = the rows' dC partials wanted (needs W).
+// pair: the pair-by-pair pass rides behind the class items (NV = 2 launches only: that kernel runs in every evaluation).
 template <int NV, int DC>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 8))) void k_spike_cls(EngineView ev,
                                                                                              const double* __restrict__ C,
-                                                                                             int full) {
-  __shared__ double Ut[64 * 16];
-  __shared__ double dcl[DC == 1 ? SV_CLS_MAXMEM * 64 : 1];
+                                                                                             int full, int pair) {
+  __shared__ double lds[sv_cls_block_lds<NV, DC>()];
+  double* Ut = lds;
+  double* dcl = lds + 64 * 16;
   const SpikeClassTab* cls = ev.cls;
   const int ncls = cls->ncls;
   int mine = 0;                                  // classes this kernel serves (scalar loop, ncls <= 32)
@@ -314,6 +335,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 8))) void
     }
     cls_item<NV, DC>(ev, C, cls, g, w / mine, Ut, dcl);
   }
+  if (NV == 2 && pair) {
+    lds_wave_fence();
+    cls_pair_rider<DC>(ev, C, full, lds, blockIdx.x, gridDim.x);
+  }
 }
 
 // Both kinds of class in ONE launch (the default up to R K = 4096 items, svgpfa_engine::cls_fused): work item = (tile, class)
@@ -321,9 +346,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 8))) void
 template <int DC>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 8))) void k_spike_cls_all(EngineView ev,
                                                                                                  const double* __restrict__ C,
-                                                                                                 int full) {
-  __shared__ double Ut[64 * 16];
-  __shared__ double dcl[DC == 1 ? SV_CLS_MAXMEM * 64 : 1];
+                                                                                                 int full, int pair) {
+  __shared__ double lds[sv_cls_block_lds<2, DC>()];
+  double* Ut = lds;
+  double* dcl = lds + 64 * 16;
   const SpikeClassTab* cls = ev.cls;
   const int ncls = cls->ncls;
   const int nitems = ev.ntiles * ncls;
@@ -331,6 +357,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 8))) void
     const int g = w % ncls;
     if (full && cls->type[g] == SV_PERIODIC) cls_item<4, DC>(ev, C, cls, g, w / ncls, Ut, dcl);
     else cls_item<2, DC>(ev, C, cls, g, w / ncls, Ut, dcl);
+  }
+  if (pair) {
+    lds_wave_fence();
+    cls_pair_rider<DC>(ev, C, full, lds, blockIdx.x, gridDim.x);
   }
 }
 
@@ -348,7 +378,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                                                                                              const double* __restrict__ C,
                                                                                              const double* d, int want_sums,
                                                                                              int want_lat, int parts, int lc0,
-                                                                                             int lc1, int full, int nell) {
+                                                                                             int lc1, int full, int nell, int pair) {
   extern __shared__ double sm[];
   if ((int)blockIdx.x < nell) {
     const int nb = ev.R * parts;
@@ -368,7 +398,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     if (full && cls->type[g] == SV_PERIODIC) cls_item<4, DC>(ev, C, cls, g, w / ncls, Ut, dcl);
     else cls_item<2, DC>(ev, C, cls, g, w / ncls, Ut, dcl);
   }
+  if (pair) {                  // (the worker's slice holds sv_pair_lds_doubles(true) doubles: static_assert below)
+    lds_wave_fence();
+    cls_pair_rider<DC>(ev, C, full, Ut, ((int)blockIdx.x - nell) * 4 + wave, nwork);
+  }
 }
+static_assert(SV_CLS_SLICE >= sv_pair_lds_doubles(true), "a class worker's LDS slice must hold the pair-by-pair rider's area");
 
 // ------------------------------------------------------------------------------------------------ k_spike_comb
 // Per (trial, latent): the class's moments A_n, B_n (At_n, Bt_n) = the trial's tile partials added in tile order, then per

@@ -64,6 +64,8 @@ struct svgpfa_engine {
   int cls_fused = -1;
   int n_cu = 256;                               // compute units of the device
   bool ell_cls = true;                          // small shards: ELL blocks and class items in one launch (SVGPFA_ELL_CLS=0: off)
+  bool pair_ride = true;                        // the pair-by-pair pass rides in the class kernels' launch (SVGPFA_PAIR_RIDE=0: own launch)
+  int build_wpe = -1;                           // k_build_reg<32>: -1 by grid size, 2 / 3 waves per SIMD forced (SVGPFA_BUILD_WPE)
   int build_mode = -1;                          // kernel build above M = 16: -1 by size, 0 k_build_reg, 1 k_build_mfma (SVGPFA_BUILD=reg|mfma)
   bool front = true;                            // k_front instead of k_prep_mfma + k_times_fwd_mfma in svgpfa_elbo (SVGPFA_FRONT=0: off)
   bool cls_on = true;                           // false: problem too small for the class path's extra launches (set_spikes)
@@ -280,6 +282,10 @@ int svgpfa_create(const svgpfa_dims* d, int device, svgpfa_engine** out) {
     e->ell_cls = !(ec && atoi(ec) == 0);
     const char* br = getenv("SVGPFA_BUILD");
     if (br) e->build_mode = !strcmp(br, "reg") ? 0 : (!strcmp(br, "mfma") ? 1 : -1);
+    const char* pr = getenv("SVGPFA_PAIR_RIDE");
+    e->pair_ride = !(pr && atoi(pr) == 0);
+    const char* bw = getenv("SVGPFA_BUILD_WPE");
+    if (bw) e->build_wpe = (atoi(bw) == 3) ? 3 : 2;
     const char* fr = getenv("SVGPFA_FRONT");
     e->front = !(fr && atoi(fr) == 0);
     const char* ps = getenv("SVGPFA_PERIODIC_SERIES");
@@ -611,10 +617,17 @@ static void launch_build(svgpfa_engine* e, int write_aux, const SnapTable* snap,
     // register-resident kernels: the default up to M = 32 (cfg3: 38.6 us against 50-65 us for the blocked kernel at one, two
     // or four items per wave -- with ~2 500 waves either is one round of the chip and the shorter single-wave latency wins);
     // SVGPFA_BUILD=reg forces them above
-    if (e->Mmax <= 32)
-      hipLaunchKernelGGL(k_build_reg<32>, dim3(v.K * ((v.R + 1) / 2) + extra), dim3(64), sv_build_lds(32, v.K, c), e->stream, v,
-                         write_aux, snap ? 1 : 0, snap ? *snap : none, c);
-    else
+    if (e->Mmax <= 32) {
+      // more blocks than fit the chip at two waves per SIMD: the three-wave instantiation, one round instead of two
+      const unsigned nblk = (unsigned)(v.K * ((v.R + 1) / 2) + extra);
+      const bool three = e->build_wpe == 3 || (e->build_wpe < 0 && nblk > 8u * (unsigned)e->n_cu && nblk <= 12u * (unsigned)e->n_cu);
+      if (three)
+        hipLaunchKernelGGL((k_build_reg<32, 3>), dim3(nblk), dim3(64), sv_build_lds(32, v.K, c), e->stream, v, write_aux,
+                           snap ? 1 : 0, snap ? *snap : none, c);
+      else
+        hipLaunchKernelGGL((k_build_reg<32, 1>), dim3(nblk), dim3(64), sv_build_lds(32, v.K, c), e->stream, v, write_aux,
+                           snap ? 1 : 0, snap ? *snap : none, c);
+    } else
       hipLaunchKernelGGL(k_build_reg<64>, dim3(v.K * v.R + extra), dim3(64), sv_build_lds(64, v.K, c), e->stream, v, write_aux,
                          snap ? 1 : 0, snap ? *snap : none, c);
   } else {                         // M > 32 (SVGPFA_BUILD=mfma: M > 16): blocked, tile products on the f64 MFMA (k_build_mfma;
@@ -814,23 +827,33 @@ static bool cls_one_launch(const svgpfa_engine* e) {
   return e->cls_fused == 1 || (e->cls_fused < 0 && (long long)e->v.R * e->v.K <= 4096);
 }
 
+// The pair-by-pair pass rides in the class kernel's launch (fp64, class path running: cls_pair_rider) instead of taking a
+// launch of its own; SVGPFA_PAIR_RIDE=0 keeps the launch.
+static bool pair_rides(const svgpfa_engine* e) {
+  return e->pair_ride && e->cls_on && e->v.ntiles > 0 && e->precision == SVGPFA_PRECISION_FP64;
+}
+
 static void launch_spike_pass(svgpfa_engine* e, hipStream_t sk, bool full, bool want_c, const double* C, bool have_w) {
   EngineView& v = e->v;
   const unsigned gc = (unsigned)std::min<long long>((long long)v.ntiles * v.K, e->grid_cls);
+  const bool ride = pair_rides(e);
   if (v.ntiles > 0 && e->cls_on) {
     const bool fused = cls_one_launch(e);
     const bool tw = !fused && full && v.ntype[SV_PERIODIC] > 0;
     const int dc = (full && want_c) ? 1 : 0;
     if (dc && !have_w) sv_launch_spike_pre(v, sk);
+    // a rider needs workers for the pair items even when the class items are few: the grid of the pair pass's own launch
+    const long long npair = (long long)v.nchunks * v.K;
+    const unsigned gr = ride ? std::max(gc, (unsigned)std::min<long long>((npair + 7) & ~7LL, e->grid_cls)) : gc;
     if (fused) {
-      sv_launch_spike_cls(v, C, 0, dc, (dc || full) ? 1 : 0, gc, sk);
+      sv_launch_spike_cls(v, C, 0, dc, (dc || full) ? 1 : 0, ride ? 1 : 0, gr, sk);
     } else {
-      if (tw) sv_launch_spike_cls(v, C, 4, dc, 1, gc, sk);
-      sv_launch_spike_cls(v, C, 2, dc, (dc || full) ? 1 : 0, gc, sk);
+      if (tw) sv_launch_spike_cls(v, C, 4, dc, 1, 0, gc, sk);
+      sv_launch_spike_cls(v, C, 2, dc, (dc || full) ? 1 : 0, ride ? 1 : 0, gr, sk);
     }
   }
   if (!v.comb_fold && e->cls_on) sv_launch_spike_comb(v, full, sk);
-  launch_pair_pass(e, sk, full, want_c, C);
+  if (!ride) launch_pair_pass(e, sk, full, want_c, C);
 }
 
 static int check_ready(svgpfa_engine* e) {
@@ -877,10 +900,11 @@ static int enqueue_elbo(svgpfa_engine* e, const PtrTable& pt, const ElboPlan& pl
       const int dc = (full && want_c) ? 1 : 0;          // (have_w holds whenever dc does: k_front made W)
       const unsigned workers = (unsigned)std::min<long long>((long long)v.ntiles * v.K, e->grid_cls);
       const size_t lds_ell = pl.want_lat ? std::max(lds_qell_mfma(e, 0), lds_qell_mfma(e, 1)) : lds_qell_mfma(e, 0);
+      const bool ride = pair_rides(e);
       HIPCHK(e, sv_launch_ell_cls(ve, C, d, e->KKT, dc, want_c ? 1 : 0, pl.want_lat ? 1 : 0, parts_m, e->ell_lc[0], e->ell_lc[1],
-                                  full ? 1 : 0, workers, lds_ell, sm));
+                                  full ? 1 : 0, ride ? 1 : 0, workers, lds_ell, sm));
       if (!v.comb_fold) sv_launch_spike_comb(v, full, sm);
-      launch_pair_pass(e, sm, full, want_c, C);
+      if (!ride) launch_pair_pass(e, sm, full, want_c, C);
     } else {
       launch_spike_pass(e, sm, pl.full, (mask & 2u) != 0, C, have_w);
     }

@@ -179,7 +179,10 @@ def test_not_positive_definite_raises():
 @pytest.mark.parametrize("env", [{"SVGPFA_COMB_FOLD": "0"}, {"SVGPFA_COMB_FOLD": "1"}, {"SVGPFA_TILE_NW": "2"},
                                  {"SVGPFA_TILE_NW": "4"}, {"SVGPFA_CLS_FUSED": "0"}, {"SVGPFA_CLS_FUSED": "1"},
                                  {"SVGPFA_ELL_PARTS": "3"}, {"SVGPFA_FRONT": "0"}, {"SVGPFA_FRONT": "0", "SVGPFA_TIMES_NW": "2"},
-                                 {"SVGPFA_BUILD": "mfma"}, {"SVGPFA_BUILD": "reg"}, {"SVGPFA_ELL_CLS": "0"}],
+                                 {"SVGPFA_BUILD": "mfma"}, {"SVGPFA_BUILD": "reg"}, {"SVGPFA_ELL_CLS": "0"},
+                                 {"SVGPFA_PAIR_RIDE": "0"}, {"SVGPFA_PAIR_RIDE": "0", "SVGPFA_RBF_SERIES": "0"},
+                                 {"SVGPFA_PAIR_RIDE": "0", "SVGPFA_ELL_CLS": "0", "SVGPFA_RBF_SERIES": "0"},
+                                 {"SVGPFA_CLS_FUSED": "0", "SVGPFA_RBF_SERIES": "0"}],
                          ids=lambda e: "-".join(f"{k[7:].lower()}{v}" for k, v in e.items()))
 def test_launch_switches_agree_with_the_default(monkeypatch, env):
     """Every launch-strategy switch of the engine (README.md, environment) at its non-default values against the default
@@ -193,8 +196,10 @@ def test_launch_switches_agree_with_the_default(monkeypatch, env):
         prob["theta"][k] = prob["theta"][k] * np.array([lsc, psc][:len(prob["theta"][k])])
     outs = []
     for e in ({}, env):
-        for var in ("SVGPFA_COMB_FOLD", "SVGPFA_TILE_NW", "SVGPFA_CLS_FUSED", "SVGPFA_ELL_PARTS", "SVGPFA_TIMES_NW", "SVGPFA_FRONT", "SVGPFA_BUILD", "SVGPFA_ELL_CLS"):
+        for var in ("SVGPFA_COMB_FOLD", "SVGPFA_TILE_NW", "SVGPFA_CLS_FUSED", "SVGPFA_ELL_PARTS", "SVGPFA_TIMES_NW", "SVGPFA_FRONT", "SVGPFA_BUILD", "SVGPFA_ELL_CLS", "SVGPFA_PAIR_RIDE", "SVGPFA_RBF_SERIES"):
             monkeypatch.delenv(var, raising=False)
+        if "SVGPFA_RBF_SERIES" in env:             # both runs with the RBF latents pair by pair: the rider has work to do
+            monkeypatch.setenv("SVGPFA_RBF_SERIES", env["SVGPFA_RBF_SERIES"])
         for k, v in e.items():
             monkeypatch.setenv(k, v)
         eng, P = _engine(prob)
@@ -207,6 +212,23 @@ def test_launch_switches_agree_with_the_default(monkeypatch, env):
     tol = 1e-10 if "SVGPFA_BUILD" in env else 1e-12       # (another factorisation order: rounding of the Cholesky itself)
     for a, b in zip(outs[0], outs[1]):
         assert rel_err(b, a) < tol
+
+
+def test_build_reg_three_waves_per_simd_agrees_with_two(monkeypatch):
+    """k_build_reg<32> has two instantiations (two / three waves per SIMD; the host picks by grid size, SVGPFA_BUILD_WPE
+    forces one): the same arithmetic in the same order -- Kzz, its Cholesky factor, and an evaluation agree to rounding."""
+    prob = synthetic.make_problem(R=7, N=9, K=4, M=[32, 17, 25, 30], kernels="mix", seed=21, n_quad=40, rate=15.0, jitter=1.0)
+    outs = []
+    for wpe in ("2", "3"):
+        monkeypatch.setenv("SVGPFA_BUILD_WPE", wpe)
+        eng, P = _engine(prob)
+        shared, gm, gc, gz = eng.elbo(P["mean"], P["cholVecs"], P["C"], P["d"], 15)
+        eng.sync()
+        outs.append([shared.cpu().numpy()] + [t.cpu().numpy() for t in gm + gc + gz] +
+                    [eng.get_kzz_chol(k).cpu().numpy() for k in range(prob["K"])])
+        eng.close()
+    for a, b in zip(*outs):
+        assert rel_err(b, a) < 1e-12
 
 
 def _drop_spikes(prob, keep_trial):

@@ -56,6 +56,17 @@ def test_guard_flags_any_exec_dependent_instruction_in_front_of_the_restore(tmp_
     assert _scan_text(tmp_path, BAD.replace("v_mov_b32_e32 v224, v154", "v_readfirstlane_b32 s12, v154")) == []
 
 
+def test_guard_stops_at_a_nested_region(tmp_path):
+    """A join block without an exec restore of its own that goes on into a nested `if` (round 4: k_ell_cls<16, 0>, a flow
+    block followed by s_and_saveexec ... s_or_b64 exec): the restore belongs to the nested region, and the code in front of
+    the s_and_saveexec ran under the block's own mask -- not a finding.  The prologue ends at any other write of EXEC."""
+    nested = BAD.replace("\ts_or_b64 exec, exec, s[6:7]\n",
+                         "\ts_and_saveexec_b64 s[2:3], s[34:35]\n\tds_bpermute_b32 v50, v1, v42\n\ts_or_b64 exec, exec, s[2:3]\n")
+    assert _scan_text(tmp_path, nested) == []
+    branch = BAD.replace("\ts_or_b64 exec, exec, s[6:7]\n", "\ts_cbranch_vccnz .LBB17_405\n\ts_or_b64 exec, exec, s[6:7]\n")
+    assert _scan_text(tmp_path, branch) == []
+
+
 def test_build_refuses_to_pass_with_nothing_scanned(tmp_path):
     import __graft_entry__ as ge
     import pytest
@@ -87,7 +98,9 @@ def test_no_scratch_outside_the_class_kernels():
     stopped inlining the kernel body (cfg5: 11.4 -> 14.0 ms); the bodies are force-inlined since.  Only the class kernels of
     the spike pass (k_spike_cls*: per-item set-up and flush, not their spike loops) may hold spilled registers: <= 320 bytes
     per lane in the one-kind kernels (268 in k_spike_cls<4, 1>), <= 512 in k_spike_cls_all, which carries both kinds' passes
-    (392 with the dC rows)."""
+    (392 with the dC rows).  Round 4: the three-waves-per-SIMD instantiation of k_build_reg<32> (168 registers, chosen by the
+    host when the grid would need two rounds at two waves per SIMD) parks five doubles on the stack -- five stores and five
+    loads per wave, once each, outside its pivot loop: <= 64 bytes."""
     import __graft_entry__ as ge
     ge.build()
     ru = ge.resource_usage()
@@ -96,6 +109,7 @@ def test_no_scratch_outside_the_class_kernels():
         ru = ge.resource_usage()
     assert ru, "build() kept no resource report"
     cls = lambda k: "k_spike_cls" in k or "k_ell_cls" in k          # (k_ell_cls: the class items beside the ELL blocks, small shards)
-    bad = {k: v["scratch"] for k, v in ru.items() if v.get("scratch", 0) > 0 and not cls(k)}
+    few = lambda k, v: "k_build_regILi32ELi3E" in k and v.get("scratch", 0) <= 64
+    bad = {k: v["scratch"] for k, v in ru.items() if v.get("scratch", 0) > 0 and not cls(k) and not few(k, v)}
     assert not bad, bad
     assert all(v.get("scratch", 0) <= (512 if ("k_spike_cls_all" in k or "k_ell_cls" in k) else 320) for k, v in ru.items())

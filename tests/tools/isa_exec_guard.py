@@ -24,6 +24,10 @@ COPY = re.compile(r"^\s*(v_mov_b32_e32|v_mov_b64_e32|v_accvgpr_write_b32|v_accvg
 VECTOR_SRC = re.compile(r"^[av]\[?[\d:]+\]?$")
 # instructions whose effect does not depend on EXEC (or that have none): allowed in front of the restore
 PROLOGUE_OK = re.compile(r"^\s*(v_writelane_b32|v_readlane_b32|v_readfirstlane_b32|s_\w+)\b")
+# the prologue of a join block ends where EXEC is written by anything but the restore (`s_and_saveexec` opens a nested
+# region: an `s_or_b64 exec` behind it closes THAT region, and what stands in front of it ran under the block's full mask) or
+# where control leaves the block
+PROLOGUE_END = re.compile(r"^\s*(s_\w+_saveexec_b64\b|s_\w+\s+exec\b|s_cbranch_\w+|s_branch\b|s_endpgm\b|s_setpc_b64\b)")
 # everything else that executes per lane
 EXEC_DEPENDENT = re.compile(r"^\s*(v_|ds_|global_|buffer_|scratch_|flat_|tbuffer_|image_)\w+")
 
@@ -58,6 +62,9 @@ def scan(path):
         if EXEC_RESTORE.match(s):
             for p in pending:
                 findings.append((func, block) + p)
+            block = None
+            continue
+        if PROLOGUE_END.match(s):
             block = None
             continue
         c = COPY.match(s)
