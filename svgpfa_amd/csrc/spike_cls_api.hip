@@ -2,6 +2,7 @@
 #include "spike_cls_launch.h"
 
 #include <algorithm>
+#include <cstdlib>
 
 #include "kernels_spike_cls.h"
 
@@ -42,7 +43,12 @@ static hipError_t launch_ell_cls_t(const EngineView& v, const double* C, const d
     if (st != hipSuccess) return st;
     allowed = true;
   }
-  const int nell = v.R * parts * (want_lat ? 2 : 1);
+  int nell = v.R * parts * (want_lat ? 2 : 1);
+  {   // diagnosis only (results are wrong): SVGPFA_ELLCLS_DIAG=1 launches the ELL blocks alone, =2 the class workers alone
+    static const int diag = getenv("SVGPFA_ELLCLS_DIAG") ? atoi(getenv("SVGPFA_ELLCLS_DIAG")) : 0;
+    if (diag == 1) workers = 0;
+    if (diag == 2) nell = 0;
+  }
   const unsigned grid = (unsigned)nell + (workers + 3) / 4;
   hipLaunchKernelGGL((k_ell_cls<KS, DC>), dim3(grid), dim3(256), lds, s, v, C, d, want_sums, want_lat, parts, lc0, lc1, full, nell, pair);
   return hipGetLastError();
