@@ -589,7 +589,8 @@ def main():
                          else "none: no committed PMC digest was taken on this device code (csrc %s)" % kernel_source_sha(),
                          "algorithmic_bytes_per_launch": work.get("bytes_spike"),
                          "kernel": "spike pass = k_spike_cls<4> + k_spike_cls<2> + k_spike_comb (class path, fp64; its weights W "
-                                   "ride in k_prep) + k_spike (pair by pair%s)" % (", fp32" if mixed else ""),
+                                   "ride in k_front) + the pair-by-pair pass (%s)" %
+                                   ("k_spike, fp32" if mixed else "a rider of k_spike_cls<2>'s workers"),
                          "kernel_avg_ms": spike_avg_ms, "kernel_launches": launches,
                          "executed_fp64_flops_per_launch": exec_flops,
                          "class_path_flops_per_launch": cls_flops, "pair_loop_flops_per_launch": pair_flops,

@@ -219,6 +219,14 @@ __device__ __forceinline__ double lds_frag(const double* p) {
 #endif
 }
 
+__device__ __forceinline__ float lds_frag(const float* p) {
+#if SV_LDS_VOLATILE
+  return *(const volatile __attribute__((address_space(3))) float*)p;
+#else
+  return *p;
+#endif
+}
+
 // LDS hand-off between lanes of ONE wavefront (no s_barrier needed)
 __device__ __forceinline__ void lds_wave_fence() {
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");

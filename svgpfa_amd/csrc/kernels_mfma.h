@@ -757,7 +757,7 @@ __device__ __forceinline__ void quad_ell_mfma_body(const EngineView& ev, const d
           const int lr = (lt - lt0) * 16;     // row of this tile inside the resident chunk
           accT h = {0, 0, 0, 0};
 #pragma unroll
-          for (int c = 0; c < KS; ++c) h = X::mfma(LM[(lr + li) * LDK + 4 * c + lg], bfrag[c], h);
+          for (int c = 0; c < KS; ++c) h = X::mfma(lds_frag(&LM[(lr + li) * LDK + 4 * c + lg]), bfrag[c], h);
           T afrag[KKT][4];                    // looped rows, transposed, for the sum product (independent of E)
           if (want_sums) {
 #pragma unroll
