@@ -200,10 +200,12 @@ __device__ __forceinline__ void cls_flush(const EngineView& ev, const double* __
     lds_wave_fence();                      // the tile is free for the transposes
   }
   // embedding weights in A-operand layout: cg[i] = C[neuron(row 4 i + lg)][member li]  (unconditional loads from valid
-  // addresses, then masked: padding rows carry neuron 0).  Fetched here, behind the pass, so that they do not occupy 32
-  // registers through it; C (N K doubles) stays in L1 / L2.
+  // addresses, then masked: padding rows carry neuron 0).  Fetched behind the pass, so that they do not occupy 32
+  // registers through it -- and behind the FIRST chunk's transposed store (round 4: the store frees that chunk's 32
+  // accumulator registers, which the 16 weights then take; requested in front of it, accumulators, weights and the products'
+  // tiles were live together and 10-25 registers went to the stack); C (N K doubles) stays in L1 / L2.
   double cg[16];
-  {
+  auto load_cg = [&]() {
     const int mk = __shfl(memk, li < nmem ? li : 0, 64);
     int nu[16];
 #pragma unroll
@@ -212,16 +214,20 @@ __device__ __forceinline__ void cls_flush(const EngineView& ev, const double* __
     for (int i = 0; i < 16; ++i) cg[i] = C[(long long)nu[i] * K + mk];          // sixteen independent loads in flight
 #pragma unroll
     for (int i = 0; i < 16; ++i) cg[i] = (4 * i + lg < nrows && li < nmem) ? cg[i] : 0.0;
-  }
+  };
   constexpr int NCH = NV * HB / 16;
   d4 D[NCH];
 #pragma unroll
   for (int ch = 0; ch < NCH; ++ch) {
     const int c0 = 16 * ch;
     D[ch] = (d4){0.0, 0.0, 0.0, 0.0};
-    if (NV * h0 + c0 < ncol) {             // wave-uniform: whole chunks beyond the last harmonic are skipped
+    if (ch == 0 || NV * h0 + c0 < ncol) {  // wave-uniform: whole chunks beyond the last harmonic are skipped (chunk 0 never is)
 #pragma unroll
       for (int c = 0; c < 16; ++c) Ut[lane * 16 + (c ^ li)] = acc[c0 + c];
+      if (ch == 0) {
+        __builtin_amdgcn_sched_barrier(0);
+        load_cg();
+      }
       lds_wave_fence();
       d4 Dc = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
@@ -380,10 +386,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                                                                                              int want_lat, int parts, int lc0,
                                                                                              int lc1, int full, int nell, int pair) {
   extern __shared__ double sm[];
-  if ((int)blockIdx.x < nell) {
-    const int nb = ev.R * parts;
-    if ((int)blockIdx.x < nb) quad_ell_mfma_body<KS, 0, double>(ev, C, d, want_sums, 1, parts, lc0, blockIdx.x, sm);
-    else quad_ell_mfma_body<KS, 1, double>(ev, C, d, 1, 0, parts, lc1, blockIdx.x - nb, sm);
+  // (ELL blocks first.  The class workers' blocks first -- they are the long ones -- was measured in round 4: 8-way shard
+  // 42.4 against 43.7 us, 4-way 68 against 55: the ELL blocks then start behind the workers on the same SIMDs.)
+  const int nwb = (int)gridDim.x - nell, bid = (int)blockIdx.x - nell;
+  if (bid < 0) {
+    const int nb = ev.R * parts, blk = (int)blockIdx.x;
+    if (blk < nb) quad_ell_mfma_body<KS, 0, double>(ev, C, d, want_sums, 1, parts, lc0, blk, sm);
+    else quad_ell_mfma_body<KS, 1, double>(ev, C, d, 1, 0, parts, lc1, blk - nb, sm);
     return;
   }
   const int wave = threadIdx.x >> 6;
@@ -392,15 +401,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   const SpikeClassTab* cls = ev.cls;
   const int ncls = cls->ncls;
   const int nitems = ev.ntiles * ncls;
-  const int nwork = ((int)gridDim.x - nell) * 4;
-  for (int w = ((int)blockIdx.x - nell) * 4 + wave; w < nitems; w += nwork) {
+  const int nwork = nwb * 4;
+  for (int w = bid * 4 + wave; w < nitems; w += nwork) {
     const int g = w % ncls;
     if (full && cls->type[g] == SV_PERIODIC) cls_item<4, DC>(ev, C, cls, g, w / ncls, Ut, dcl);
     else cls_item<2, DC>(ev, C, cls, g, w / ncls, Ut, dcl);
   }
   if (pair) {                  // (the worker's slice holds sv_pair_lds_doubles(true) doubles: static_assert below)
     lds_wave_fence();
-    cls_pair_rider<DC>(ev, C, full, Ut, ((int)blockIdx.x - nell) * 4 + wave, nwork);
+    cls_pair_rider<DC>(ev, C, full, Ut, bid * 4 + wave, nwork);
   }
 }
 static_assert(SV_CLS_SLICE >= sv_pair_lds_doubles(true), "a class worker's LDS slice must hold the pair-by-pair rider's area");

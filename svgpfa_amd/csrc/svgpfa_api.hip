@@ -891,6 +891,7 @@ static int enqueue_elbo(svgpfa_engine* e, const PtrTable& pt, const ElboPlan& pl
   // with the engine's usual four blocks per trial: 504 ELL blocks, 48.6 us = the two kernels one after the other)
   int parts_m = e->ell_parts;
   while (merged && parts_m > 1 && (long long)v.R * parts_m * 2 > e->n_cu) parts_m >>= 1;
+  if (merged && getenv("SVGPFA_ELLCLS_PARTS")) parts_m = std::max(1, std::min(e->ell_parts, atoi(getenv("SVGPFA_ELLCLS_PARTS"))));   // (experiments)
   EngineView ve = v;               // this evaluation's view: the number of ELL partials follows the blocks per trial
   if (merged) ve.nell = v.R * parts_m;
   if (pl.run_spike) {
