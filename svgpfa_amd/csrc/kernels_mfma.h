@@ -820,10 +820,26 @@ __device__ __forceinline__ void quad_ell_mfma_body(const EngineView& ev, const d
 
 // ROLE 0: dC / dd / ELL only (no latent-side gradient wanted).  ROLE 2: both roles in one launch (blocks [0, nb) role 0,
 // [nb, 2 nb) role 1): measured faster than two launches at every size.
+// ncomb > 0 (round 4): behind the ELL blocks ceil(ncomb / 4) RIDER blocks combine the class path's spike moments of the
+// ncomb = R K (trial, latent) items, one item per wave (spike_comb_item: the work of k_spike_comb, which needs the class
+// kernels in front of this launch and k_item_bwd behind it -- exactly this kernel's place on the stream -- and was a
+// launch of 9.5 us for 5 000 single-wave blocks of a few microseconds each).
 template <int KS, int ROLE, typename T = double>
 __global__ __launch_bounds__(512) void k_quad_ell_mfma(EngineView ev, const double* C, const double* d,
-                                                       int want_sums, int write_ell, int parts, int lc0, int lc1) {
+                                                       int want_sums, int write_ell, int parts, int lc0, int lc1,
+                                                       int ncomb, int comb_full) {
   extern __shared__ double sm[];
+  const int nell = ev.R * parts * (ROLE == 2 ? 2 : 1);
+  if ((int)blockIdx.x >= nell) {                       // rider blocks (only launched with ncomb > 0)
+    const int nwb = (int)blockDim.x >> 6, wave = (int)threadIdx.x >> 6;
+    const int item = ((int)blockIdx.x - nell) * nwb + wave;
+    if (item < ncomb) {
+      double* lds = sm + wave * SV_COMB_LDS;
+      if (comb_full) spike_comb_item<true>(ev, item, lds);
+      else spike_comb_item<false>(ev, item, lds);
+    }
+    return;
+  }
   if (ROLE == 2) {
     const int nb = ev.R * parts;
     if ((int)blockIdx.x < nb)

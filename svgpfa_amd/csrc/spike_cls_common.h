@@ -274,3 +274,80 @@ __device__ inline void spike_pre_item(const EngineView& ev, int item, int r, int
     W[2 * n + 1] = w * sb;
   }
 }
+
+// The combine of one (trial, latent) item by ONE wavefront (all 64 lanes call; lds: SV_COMB_LDS doubles of its own) -- the
+// body of k_spike_comb (kernels_spike_cls.h), and of the rider blocks of k_quad_ell_mfma that do the same work inside the
+// ELL kernel's launch at full size (kernels_mfma.h).
+#define SV_COMB_LDS (SV_ACOLS + 3 * (SV_FH + 1))
+template <bool FULL>
+__device__ __forceinline__ void spike_comb_item(const EngineView& ev, const int item, double* lds) {
+  double* Fs = lds;                        // SV_ACOLS moments
+  double* cf = lds + SV_ACOLS;             // 3 x (SV_FH + 1) coefficients
+  const int lane = threadIdx.x & 63, K = ev.K;
+  const SpikeItem it = ev.sitem[item];
+  if (it.H < 0) return;
+  const int r = item / K, k = item % K;
+  const LatentMeta m = ev.meta[k];
+  const int M = m.M;
+  const int H = it.H;
+  const double sc = it.sc, t0 = it.t0;
+  const KPar p = make_kpar(m, ev.theta + 2 * k);
+  const bool TW = FULL && m.ktype == SV_PERIODIC;
+  const int NV = TW ? 4 : 2, ncol = NV * (H + 1);
+  const int tl0 = ev.tile_first[r], tl1 = ev.tile_first[r + 1];
+  double zj = t0, aj = 0.0;
+  if (lane < M) {                          // requested before the coefficients are computed
+    zj = ev.Zs[m.offM + (long long)r * M + lane];
+    aj = ev.a[m.offM + (long long)r * M + lane];
+  }
+  cls_coefficients(ev, k, m.ktype, p.h, sc, H, cf);
+  for (int c = lane; c < ncol; c += 64) {
+    double s = 0.0;
+    for (int t = tl0; t < tl1; t += 8) {            // eight tiles' partials in flight, added in tile order
+      double v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = ev.Apart[((long long)(t + u < tl1 ? t + u : t) * K + k) * SV_ACOLS + c];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) s += (t + u < tl1) ? v[u] : 0.0;
+    }
+    Fs[c] = s;
+  }
+  lds_wave_fence();
+  double t0acc = 0.0, t1acc = 0.0;
+  if (lane < M) {
+    double sphi, cphi;
+    sv_sincos_quarter((zj - t0) * sc, sphi, cphi);
+    const double* cN = cf;
+    const double* gN = cf + (SV_FH + 1);
+    const double* eN = cf + 2 * (SV_FH + 1);
+    double cj = 1.0, sj = 0.0, P0 = 0.0, P1 = 0.0, d0 = 0.0, d1 = 0.0;
+    for (int n = 0; n <= H; ++n) {
+      const double An = Fs[n * NV + 0], Bn = Fs[n * NV + 1];
+      const double Cc = fma(cj, An, sj * Bn), Ss = fma(cj, Bn, -(sj * An));
+      P0 = fma(cN[n], Cc, P0);
+      if (FULL) {
+        const double en = eN[n];
+        P1 = fma(en, Ss, P1);
+        d0 = fma(gN[n], Cc, d0);
+        if (TW) d1 = fma(en, fma(cj, Fs[n * NV + 3], -(sj * Fs[n * NV + 2])) - zj * Ss, d1);
+      }
+      const double tq = cj * cphi - sj * sphi;
+      sj = fma(sj, cphi, cj * sphi);
+      cj = tq;
+    }
+    const long long o = (long long)r * ev.sumM + m.colM + lane;
+    ev.P0t[o] = P0;
+    if (FULL) {
+      ev.P1t[o] = P1;
+      t0acc = aj * d0;
+      t1acc = aj * d1;
+    }
+  }
+  if (FULL) {
+    const double ts0 = wave_sum(t0acc), ts1 = wave_sum(t1acc);
+    if (lane == 0) {
+      ev.Tt[(long long)item * 2 + 0] = ts0;
+      ev.Tt[(long long)item * 2 + 1] = ts1;
+    }
+  }
+}

@@ -64,6 +64,7 @@ struct svgpfa_engine {
   int cls_fused = -1;
   int n_cu = 256;                               // compute units of the device
   bool ell_cls = true;                          // small shards: ELL blocks and class items in one launch (SVGPFA_ELL_CLS=0: off)
+  bool comb_ride = true;                        // the moments' combine rides in the ELL kernel's launch at full size (SVGPFA_COMB_RIDE=0: own launch)
   bool pair_ride = true;                        // the pair-by-pair pass rides in the class kernels' launch (SVGPFA_PAIR_RIDE=0: own launch)
   int build_wpe = -1;                           // k_build_reg<32>: -1 by grid size, 2 / 3 waves per SIMD forced (SVGPFA_BUILD_WPE)
   int build_mode = -1;                          // kernel build above M = 16: -1 by size, 0 k_build_reg, 1 k_build_mfma (SVGPFA_BUILD=reg|mfma)
@@ -282,6 +283,8 @@ int svgpfa_create(const svgpfa_dims* d, int device, svgpfa_engine** out) {
     e->ell_cls = !(ec && atoi(ec) == 0);
     const char* br = getenv("SVGPFA_BUILD");
     if (br) e->build_mode = !strcmp(br, "reg") ? 0 : (!strcmp(br, "mfma") ? 1 : -1);
+    const char* cr = getenv("SVGPFA_COMB_RIDE");
+    e->comb_ride = !(cr && atoi(cr) == 0);
     const char* pr = getenv("SVGPFA_PAIR_RIDE");
     e->pair_ride = !(pr && atoi(pr) == 0);
     const char* bw = getenv("SVGPFA_BUILD_WPE");
@@ -706,28 +709,33 @@ static int fill_ptrs(svgpfa_engine* e, PtrTable& pt, const double* const* mean, 
   return SVGPFA_OK;
 }
 
-static int launch_quad_ell(svgpfa_engine* e, hipStream_t st, const double* C, const double* d, int want_cd, int want_lat) {
+// ncomb > 0: the combine of the class path's spike moments rides behind the ELL blocks (rider blocks, one item per wave)
+static int launch_quad_ell(svgpfa_engine* e, hipStream_t st, const double* C, const double* d, int want_cd, int want_lat,
+                           int ncomb = 0, int comb_full = 0) {
   EngineView& v = e->v;
   // role 0 (dC, dd and the ELL value) always runs: its column sums give sum E; role 1 (latent adjoints) rides in the
   // same launch when some latent-side gradient is wanted
   dim3 gm(v.R * e->ell_parts), bm(64 * e->ell_nw);
+  const unsigned nrb = ncomb > 0 ? (unsigned)((ncomb + e->ell_nw - 1) / e->ell_nw) : 0u;      // rider blocks
+  const size_t lrid = ncomb > 0 ? (size_t)e->ell_nw * SV_COMB_LDS * sizeof(double) : 0;
   const bool f32 = e->precision == SVGPFA_PRECISION_MIXED;
   if (want_lat) {
-    const size_t l2 = std::max(lds_qell_mfma(e, 0), lds_qell_mfma(e, 1));
+    const size_t l2 = std::max(std::max(lds_qell_mfma(e, 0), lds_qell_mfma(e, 1)), lrid);
     if (f32) {
-      DISPATCH_KS(e->KKT, hipLaunchKernelGGL((k_quad_ell_mfma<KS_, 2, float>), dim3(2 * gm.x), bm, l2, st, v, C, d,
-                                             want_cd, 1, e->ell_parts, e->ell_lc[0], e->ell_lc[1]));
+      DISPATCH_KS(e->KKT, hipLaunchKernelGGL((k_quad_ell_mfma<KS_, 2, float>), dim3(2 * gm.x + nrb), bm, l2, st, v, C, d,
+                                             want_cd, 1, e->ell_parts, e->ell_lc[0], e->ell_lc[1], ncomb, comb_full));
     } else {
-      DISPATCH_KS(e->KKT, hipLaunchKernelGGL((k_quad_ell_mfma<KS_, 2, double>), dim3(2 * gm.x), bm, l2, st, v, C, d,
-                                             want_cd, 1, e->ell_parts, e->ell_lc[0], e->ell_lc[1]));
+      DISPATCH_KS(e->KKT, hipLaunchKernelGGL((k_quad_ell_mfma<KS_, 2, double>), dim3(2 * gm.x + nrb), bm, l2, st, v, C, d,
+                                             want_cd, 1, e->ell_parts, e->ell_lc[0], e->ell_lc[1], ncomb, comb_full));
     }
   } else {
+    const size_t l0 = std::max(lds_qell_mfma(e, 0), lrid);
     if (f32) {
-      DISPATCH_KS(e->KKT, hipLaunchKernelGGL((k_quad_ell_mfma<KS_, 0, float>), gm, bm, lds_qell_mfma(e, 0), st, v, C,
-                                             d, want_cd, 1, e->ell_parts, e->ell_lc[0], e->ell_lc[1]));
+      DISPATCH_KS(e->KKT, hipLaunchKernelGGL((k_quad_ell_mfma<KS_, 0, float>), dim3(gm.x + nrb), bm, l0, st, v, C,
+                                             d, want_cd, 1, e->ell_parts, e->ell_lc[0], e->ell_lc[1], ncomb, comb_full));
     } else {
-      DISPATCH_KS(e->KKT, hipLaunchKernelGGL((k_quad_ell_mfma<KS_, 0, double>), gm, bm, lds_qell_mfma(e, 0), st, v, C,
-                                             d, want_cd, 1, e->ell_parts, e->ell_lc[0], e->ell_lc[1]));
+      DISPATCH_KS(e->KKT, hipLaunchKernelGGL((k_quad_ell_mfma<KS_, 0, double>), dim3(gm.x + nrb), bm, l0, st, v, C,
+                                             d, want_cd, 1, e->ell_parts, e->ell_lc[0], e->ell_lc[1], ncomb, comb_full));
     }
   }
   HIPCHK(e, hipGetLastError());
@@ -833,7 +841,8 @@ static bool pair_rides(const svgpfa_engine* e) {
   return e->pair_ride && e->cls_on && e->v.ntiles > 0 && e->precision == SVGPFA_PRECISION_FP64;
 }
 
-static void launch_spike_pass(svgpfa_engine* e, hipStream_t sk, bool full, bool want_c, const double* C, bool have_w) {
+static void launch_spike_pass(svgpfa_engine* e, hipStream_t sk, bool full, bool want_c, const double* C, bool have_w,
+                              bool comb_rides = false) {
   EngineView& v = e->v;
   const unsigned gc = (unsigned)std::min<long long>((long long)v.ntiles * v.K, e->grid_cls);
   const bool ride = pair_rides(e);
@@ -852,7 +861,7 @@ static void launch_spike_pass(svgpfa_engine* e, hipStream_t sk, bool full, bool 
       sv_launch_spike_cls(v, C, 2, dc, (dc || full) ? 1 : 0, ride ? 1 : 0, gr, sk);
     }
   }
-  if (!v.comb_fold && e->cls_on) sv_launch_spike_comb(v, full, sk);
+  if (!v.comb_fold && e->cls_on && !comb_rides) sv_launch_spike_comb(v, full, sk);
   if (!ride) launch_pair_pass(e, sk, full, want_c, C);
 }
 
@@ -892,6 +901,9 @@ static int enqueue_elbo(svgpfa_engine* e, const PtrTable& pt, const ElboPlan& pl
   int parts_m = e->ell_parts;
   while (merged && parts_m > 1 && (long long)v.R * parts_m * 2 > e->n_cu) parts_m >>= 1;
   if (merged && getenv("SVGPFA_ELLCLS_PARTS")) parts_m = std::max(1, std::min(e->ell_parts, atoi(getenv("SVGPFA_ELLCLS_PARTS"))));   // (experiments)
+  // Full size (two class kernels, the combine not folded into k_item_bwd): the combine rides behind the ELL blocks of
+  // k_quad_ell_mfma, which follows the class kernels on this stream anyway (SVGPFA_COMB_RIDE=0: a launch of its own)
+  const bool comb_rides = e->comb_ride && !merged && pl.run_spike && e->cls_on && v.ntiles > 0 && !v.comb_fold;
   EngineView ve = v;               // this evaluation's view: the number of ELL partials follows the blocks per trial
   if (merged) ve.nell = v.R * parts_m;
   if (pl.run_spike) {
@@ -907,13 +919,14 @@ static int enqueue_elbo(svgpfa_engine* e, const PtrTable& pt, const ElboPlan& pl
       if (!v.comb_fold) sv_launch_spike_comb(v, full, sm);
       if (!ride) launch_pair_pass(e, sm, full, want_c, C);
     } else {
-      launch_spike_pass(e, sm, pl.full, (mask & 2u) != 0, C, have_w);
+      launch_spike_pass(e, sm, pl.full, (mask & 2u) != 0, C, have_w, comb_rides);
     }
     timing_end(e, evp, sm);
   }
   // ---- quadrature chain (f64 MFMA): posterior statistics at the nodes -> ELL term and its adjoints
   if (!e->front && (rc = launch_times_quad(e, sm))) return rc;
-  if (!merged && (rc = launch_quad_ell(e, sm, C, d, (mask & 2u) ? 1 : 0, pl.want_lat ? 1 : 0))) return rc;
+  if (!merged && (rc = launch_quad_ell(e, sm, C, d, (mask & 2u) ? 1 : 0, pl.want_lat ? 1 : 0, comb_rides ? v.R * v.K : 0,
+                                       pl.full ? 1 : 0))) return rc;
   // ---- per-item adjoints + backward + the fixed-order cross-trial reductions in one kernel
   const int evb = timing_begin(e, 1, sm);
   if (mask & (4u | 8u)) {

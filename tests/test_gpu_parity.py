@@ -182,7 +182,9 @@ def test_not_positive_definite_raises():
                                  {"SVGPFA_BUILD": "mfma"}, {"SVGPFA_BUILD": "reg"}, {"SVGPFA_ELL_CLS": "0"},
                                  {"SVGPFA_PAIR_RIDE": "0"}, {"SVGPFA_PAIR_RIDE": "0", "SVGPFA_RBF_SERIES": "0"},
                                  {"SVGPFA_PAIR_RIDE": "0", "SVGPFA_ELL_CLS": "0", "SVGPFA_RBF_SERIES": "0"},
-                                 {"SVGPFA_CLS_FUSED": "0", "SVGPFA_RBF_SERIES": "0"}],
+                                 {"SVGPFA_CLS_FUSED": "0", "SVGPFA_RBF_SERIES": "0"},
+                                 {"SVGPFA_COMB_FOLD": "0", "SVGPFA_ELL_CLS": "0"},      # the combine rides in the ELL kernel's launch
+                                 {"SVGPFA_COMB_FOLD": "0", "SVGPFA_ELL_CLS": "0", "SVGPFA_CLS_FUSED": "0", "SVGPFA_COMB_RIDE": "0"}],
                          ids=lambda e: "-".join(f"{k[7:].lower()}{v}" for k, v in e.items()))
 def test_launch_switches_agree_with_the_default(monkeypatch, env):
     """Every launch-strategy switch of the engine (README.md, environment) at its non-default values against the default
@@ -196,7 +198,7 @@ def test_launch_switches_agree_with_the_default(monkeypatch, env):
         prob["theta"][k] = prob["theta"][k] * np.array([lsc, psc][:len(prob["theta"][k])])
     outs = []
     for e in ({}, env):
-        for var in ("SVGPFA_COMB_FOLD", "SVGPFA_TILE_NW", "SVGPFA_CLS_FUSED", "SVGPFA_ELL_PARTS", "SVGPFA_TIMES_NW", "SVGPFA_FRONT", "SVGPFA_BUILD", "SVGPFA_ELL_CLS", "SVGPFA_PAIR_RIDE", "SVGPFA_RBF_SERIES"):
+        for var in ("SVGPFA_COMB_FOLD", "SVGPFA_TILE_NW", "SVGPFA_CLS_FUSED", "SVGPFA_ELL_PARTS", "SVGPFA_TIMES_NW", "SVGPFA_FRONT", "SVGPFA_BUILD", "SVGPFA_ELL_CLS", "SVGPFA_PAIR_RIDE", "SVGPFA_RBF_SERIES", "SVGPFA_COMB_RIDE"):
             monkeypatch.delenv(var, raising=False)
         if "SVGPFA_RBF_SERIES" in env:             # both runs with the RBF latents pair by pair: the rider has work to do
             monkeypatch.setenv("SVGPFA_RBF_SERIES", env["SVGPFA_RBF_SERIES"])
