@@ -191,12 +191,16 @@ class ShardedLBFGS:
 
     def __init__(self, local_params=(), shared_params=(), lr=1.0, max_iter=20, max_eval=None, tolerance_grad=1e-7,
                  tolerance_change=1e-9, history_size=100, line_search_fn=None, group=None, flat=None, shared=False,
-                 maximize=False, host_max=None):
+                 maximize=False, host_max=None, after_sync=None):
         if line_search_fn not in (None, "strong_wolfe"):
             raise RuntimeError("only 'strong_wolfe' is supported")
         if maximize and flat is None:
             raise ValueError("maximize=True needs flat mode")
         self._maximize = bool(maximize)
+        # flat mode: called right after every host read-back that follows a closure (the stream is idle then): a closure
+        # that defers a device-side status check (SVLowerBound.evalFlat(defer_status=True): the Cholesky of a kernel
+        # rebuild) surfaces it here, from inside step(), without a synchronisation of its own
+        self._after_sync = after_sync
         self._flat = flat
         if flat is not None:
             if not (flat.dim() == 1 and flat.is_contiguous()):
@@ -428,7 +432,10 @@ class ShardedLBFGS:
         """Host copy of a small device vector `out` whose first nsum entries are local partial sums, entries `maxes`
         local partial maxima and entries `extra` already global: ONE transfer (and at most one all-gather)."""
         if self._world == 1:
-            return out.double().cpu().numpy()
+            vals = out.double().cpu().numpy()
+            if self._after_sync is not None:
+                self._after_sync()
+            return vals
         idx = list(range(nsum)) + list(maxes)
         loc = out[idx] if len(idx) != out.numel() else out
         rs, rm = self._reduce(loc[:nsum], loc[nsum:] if maxes else None)
@@ -437,6 +444,8 @@ class ShardedLBFGS:
             vals[:nsum] = rs.double().cpu().numpy()
         if maxes:
             vals[list(maxes)] = rm.double().cpu().numpy()
+        if self._after_sync is not None:
+            self._after_sync()
         return vals
 
     def _vectors(self):
@@ -594,6 +603,8 @@ class ShardedLBFGS:
             else:
                 rbuf.copy_(pack)
             pending[0] = False
+            if self._after_sync is not None:
+                self._after_sync()
             a = rbuf.numpy()
             return sign * float(a[0]), sign * a[1:]
 

@@ -178,9 +178,16 @@ class SVEM_PyTorch:
             from svgpfa_amd.stats.shardedLBFGS import ShardedLBFGS
             # maximise the bound: the optimiser takes (value, gradient) as the engine leaves them and changes the sign
             # on the copy of the gradient it has to keep anyway
-            optimizer = ShardedLBFGS(flat=flat, shared=not per_trial, maximize=True, **optim_params)
+            # closures that rebuild the kernel matrices defer the Cholesky status to the optimiser's own read-back of the
+            # value (SVLowerBound.checkStatus): the LinAlgError still comes out of optimizer.step()
+            defer = hasattr(model, "checkStatus")
+            optimizer = ShardedLBFGS(flat=flat, shared=not per_trial, maximize=True,
+                                     after_sync=model.checkStatus if defer else None, **optim_params)
             with torch.no_grad():
-                optimizer.step(lambda: model.evalFlat(group))
+                if defer:
+                    optimizer.step(lambda: model.evalFlat(group, defer_status=True))
+                else:
+                    optimizer.step(lambda: model.evalFlat(group))
             lowerBound = evalFunc()
             state = optimizer.state[optimizer._params[0]]
             return {"lowerBound": lowerBound, "nfeval": state["func_evals"], "niter": state["n_iter"]}

@@ -428,6 +428,7 @@ class SVLowerBound:
         exchange their status (one small max-reduction) and raise together -- otherwise the healthy ranks would wait in
         the next collective for a rank that has already left the EM step through the exception."""
         err = None
+        self._status_pending = False
         try:
             self._engine.sync()
         except SVGPFAEngineError as e:
@@ -448,15 +449,28 @@ class SVLowerBound:
                 raise ValueError(f"{what} tensors must stay contiguous fp64 tensors on {self._device}")
 
     # ------------------------------------------------------------------------------ compute
-    def buildKernelsMatrices(self):
+    def buildKernelsMatrices(self, defer_status=False):
         """svLowerBound.py:77-78: Kzz + eps I, its Cholesky (raises LinAlgError if not PD).  Ktz blocks are
-        recomputed on the fly by the engine from this snapshot of Z and the kernel parameters."""
+        recomputed on the fly by the engine from this snapshot of Z and the kernel parameters.
+        defer_status (not part of the reference's signature; the EM loop's flat closures use it): only enqueue -- the
+        status of the factorisation is surfaced by the next checkStatus() / any call that waits for the engine, and
+        evaluations enqueued in between run on whatever the failed factorisation left (no fault: no address depends on
+        it) and are discarded with the exception."""
         self._ensure_engine()
         theta = self._theta()
         self._check_live(self._Z + theta, "inducing point / kernel parameter")
         self._engine.build_kernels(self._Z, theta)
-        self._sync(agree=True)
+        if defer_status:
+            self._status_pending = True
+        else:
+            self._sync(agree=True)
         self._stats_token = None
+
+    def checkStatus(self):
+        """Surface the status of a kernel rebuild enqueued with defer_status=True (raises LinAlgError like
+        buildKernelsMatrices(); with trials sharded over ranks every rank must call it at the same point)."""
+        if getattr(self, "_status_pending", False):
+            self._sync(agree=True)
 
     def eval(self):
         """svLowerBound.py:47-54."""
@@ -556,7 +570,7 @@ class SVLowerBound:
             self._gflat[group] = (flat, views)
         return self._gflat[group]
 
-    def evalFlat(self, group):
+    def evalFlat(self, group, defer_status=False):
         """(value, gradient) of one EM closure without an autograd graph: value = the lower bound (group "emb": the
         expected log-likelihood with the latent statistics of the latest computeSVPosteriorOnLatentsStats() frozen,
         svEM.py:225-232), gradient = d value / d flatParams(group), a view of an engine-owned buffer that the NEXT
@@ -565,7 +579,9 @@ class SVLowerBound:
         if self.flatParams(group) is None:
             raise ValueError(f"group {group!r} is not available as a flat buffer")
         if self._engine is None or group in ("theta", "Z"):
-            self.buildKernelsMatrices()
+            # defer_status: the caller reads the value back anyway and calls checkStatus() behind that wait (ShardedLBFGS
+            # after_sync): one synchronisation per closure instead of two, and no gap in the GPU's queue behind the rebuild
+            self.buildKernelsMatrices(defer_status=defer_status and self._engine is not None)
         eng, K = self._engine, self._K
         if group == "emb":
             if self._stats_token is None:
