@@ -588,8 +588,9 @@ def main():
                          "traffic_source": ("profiles/%s @ csrc %s" % (traffic[1], traffic[3])) if traffic
                          else "none: no committed PMC digest was taken on this device code (csrc %s)" % kernel_source_sha(),
                          "algorithmic_bytes_per_launch": work.get("bytes_spike"),
-                         "kernel": "spike pass = k_spike_cls<4> + k_spike_cls<2> + k_spike_comb (class path, fp64; its weights W "
-                                   "ride in k_front) + the pair-by-pair pass (%s)" %
+                         "kernel": "spike pass = k_spike_cls<4> + k_spike_cls<2> (class path, fp64; its weights W ride in k_front, "
+                                   "the moments' combine in the ELL kernel's launch at this size: neither is in this time) "
+                                   "+ the pair-by-pair pass (%s)" %
                                    ("k_spike, fp32" if mixed else "a rider of k_spike_cls<2>'s workers"),
                          "kernel_avg_ms": spike_avg_ms, "kernel_launches": launches,
                          "executed_fp64_flops_per_launch": exec_flops,
