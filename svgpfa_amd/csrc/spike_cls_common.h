@@ -260,6 +260,36 @@ __device__ inline void spike_pre_item(const EngineView& ev, int item, int r, int
   double* W = ev.Wb + (long long)item * SV_WCOLS;
   for (int c = 2 * (H + 1) + lane; c < SV_WCOLS; c += 64) W[c] = 0.0;
   lds_wave_fence();
+  const int NH = H + 1;
+  if (NH <= 32) {
+    // Few harmonics (the usual case: 14 .. 21): with lane = harmonic alone a third of the wave walks all M inducing points
+    // -- ~1 100 issued instructions per item, a sixth of k_front's VALU work at the north-star size (round 4).  The
+    // inducing points are dealt over G groups of NH lanes (lane = harmonic n + NH g walks j = g, g + G, ...), and the G
+    // partial sums of a harmonic are added in group order.
+    const int G = (NH <= 16) ? 4 : ((NH <= 21) ? 3 : 2);
+    const int g = lane / NH, n = lane - g * NH;
+    double sa = 0.0, sb = 0.0;
+    if (g < G) {
+      const double dn = (double)n;
+      for (int j = g; j < M; j += G) {
+        double sn, cs;
+        sv_sincos_quarter(pl[j] * dn, sn, cs);
+        sa = fma(al[j], cs, sa);
+        sb = fma(al[j], sn, sb);
+      }
+    }
+    double ta = 0.0, tb = 0.0;
+    for (int gg = 0; gg < G; ++gg) {                 // (every lane takes part in the shuffles; sources n + NH gg < 64)
+      ta += __shfl(sa, n + NH * gg, 64);
+      tb += __shfl(sb, n + NH * gg, 64);
+    }
+    if (g == 0) {
+      const double w = p.s2 * cf[n];
+      W[2 * n + 0] = w * ta;
+      W[2 * n + 1] = w * tb;
+    }
+    return;
+  }
   for (int n = lane; n <= H; n += 64) {
     const double dn = (double)n;
     double sa = 0.0, sb = 0.0;
