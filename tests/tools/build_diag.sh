@@ -6,7 +6,7 @@ cd "$(dirname "$0")/../.."
 one() {
   name=$1; flags=$2; d=/tmp/build_diag_$name; mkdir -p $d
   base="/opt/rocm/bin/hipcc -O3 --offload-arch=gfx950 -std=c++17 -fPIC $flags -c"
-  $base svgpfa_amd/csrc/svgpfa_api.hip -o $d/a.o 2> $d/a.log &
+  $base -mllvm -amdgpu-mfma-vgpr-form svgpfa_amd/csrc/svgpfa_api.hip -o $d/a.o 2> $d/a.log &
   $base svgpfa_amd/csrc/lbfgs_api.hip -o $d/b.o 2> $d/b.log &
   $base -mllvm -disable-machine-licm svgpfa_amd/csrc/spike_cls_api.hip -o $d/c.o 2> $d/c.log &
   wait
