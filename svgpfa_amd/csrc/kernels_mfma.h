@@ -595,6 +595,7 @@ __global__ __launch_bounds__(256) void k_front(EngineView ev, LatentPtrTable pta
 // Operand layouts of the two 16x16x4 MFMAs are the same (A: row = lane & 15, k = lane >> 4; B: k = lane >> 4, col = lane & 15);
 // the ACCUMULATOR layouts differ: f64 register q holds row (lane >> 4) + 4 q, f32 register q holds row 4 (lane >> 4) + q.
 // An accumulator tile is used as the B operand of step q of the next product, so the k index of step q is that row.
+#define SV_ELL_OFF (-1.0e5)      // exponent offset of a padded neuron: 2^(h + SV_ELL_OFF) == 0 exactly (fp64: clamped to 2^-1100; fp32: v_exp_f32)
 typedef float f4 __attribute__((ext_vector_type(4)));
 template <typename T> struct EllT;
 template <> struct EllT<double> {
@@ -683,8 +684,11 @@ __device__ __forceinline__ void quad_ell_mfma_body(const EngineView& ev, const d
     __syncthreads();
   };
 
+  // Padding of the looped index is folded into the data instead of masked per element (round 4: two selects and a compare
+  // per element were an eighth of this issue-bound loop's VALU instructions): a padded node has weight 0 (ROLE 0), a padded
+  // neuron the offset SV_ELL_OFF = -1e5 in the exponent (ROLE 1), and 2^(h - 1e5) is an exact 0 in either arithmetic.
   for (int i = tid; i < Lp; i += NTH)
-    lv[i] = (T)((ROLE == 0) ? ((i < Q) ? ev.wq[(long long)r * Q + i] : 0.0) : ((i < N) ? d[i] * L2E : 0.0));
+    lv[i] = (T)((ROLE == 0) ? ((i < Q) ? ev.wq[(long long)r * Q + i] : 0.0) : ((i < N) ? d[i] * L2E : SV_ELL_OFF));
   if (LC == LT) fill_lm(0);     // common case: the whole looped matrix stays resident
   else __syncthreads();
 
@@ -741,7 +745,8 @@ __device__ __forceinline__ void quad_ell_mfma_body(const EngineView& ev, const d
     lds_wave_fence();
     const int oi = ot * 16 + li;              // own index of this lane's column
     const bool ook = active && oi < ((ROLE == 0) ? N : Q);
-    const T ov = (T)(!ook ? 0.0 : ((ROLE == 0) ? d[oi] * L2E : ev.wq[(long long)r * Q + oi]));
+    // (the own index's padding likewise: ROLE 0 the exponent offset, ROLE 1 the weight 0)
+    const T ov = (T)(!ook ? ((ROLE == 0) ? SV_ELL_OFF : 0.0) : ((ROLE == 0) ? d[oi] * L2E : ev.wq[(long long)r * Q + oi]));
     T bfrag[KS];                              // own rows as the B operand of the h product
 #pragma unroll
     for (int c = 0; c < KS; ++c) bfrag[c] = ow[li * LDK + 4 * c + lg];
@@ -770,9 +775,7 @@ __device__ __forceinline__ void quad_ell_mfma_body(const EngineView& ev, const d
           for (int q = 0; q < 4; ++q) {
             const int l = lt * 16 + X::row(lg, q);   // looped index of this element's row
             // ROLE 0: E = w_q 2^(h + d_n) ; ROLE 1: E^T = w_q 2^(h^T + d_n)
-            const T x = (ROLE == 0) ? lv[l] * X::exp2(h[q] + ov) : ov * X::exp2(h[q] + lv[l]);
-            const bool lok = l < lrows_tot;
-            E[q] = (ook && lok) ? x : (T)0;
+            E[q] = (ROLE == 0) ? lv[l] * X::exp2(h[q] + ov) : ov * X::exp2(h[q] + lv[l]);     // exact 0 where l or the own index is padding
             colsum += E[q];
           }
           if (want_sums) {
