@@ -602,7 +602,9 @@ template <> struct EllT<double> {
   typedef d4 acc;
   static __device__ __forceinline__ acc mfma(double a, double b, acc c) { return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0); }
   static __device__ __forceinline__ int row(int lg, int q) { return lg + 4 * q; }
-  static __device__ __forceinline__ double exp2(double x) { return sv_exp2(x); }
+  // the unclamped kernel: for every FINITE argument v_cvt_i32_f64 saturates and v_ldexp_f64 overflows to inf / underflows to 0,
+  // exactly what the clamp to [-1100, 1100] gave (two more instructions per exponential, a tenth of this loop's VALU work)
+  static __device__ __forceinline__ double exp2(double x) { return sv_exp2_neg(x); }
 };
 template <> struct EllT<float> {
   typedef f4 acc;
