@@ -219,7 +219,7 @@ __device__ __forceinline__ void times_tiles(const KPar& p, const double* Li, con
         } else {
           const int j = 16 * a + 4 * q + jo;
           const double cs = fma(stq, szl[j], ctq * czl[j]);            // cos(2 pi (t - z) / p)
-          X0[a][q] = p.s2 * sv_exp2_neg(fmin(fma(cs, p.h2, -p.h2), 0.0));
+          X0[a][q] = p.s2 * sv_exp2_neg(fma(cs, p.h2, -p.h2));     // (cs may exceed 1 by a rounding: 2^(+1e-16 h2) is harmless; k_item_bwd evaluates the same expression)
         }
       }
     d4 Kw[NT];
