@@ -118,12 +118,17 @@ __device__ __forceinline__ void cls_pass(const double* __restrict__ tt, int maxl
         // n^2 u in the worst case (theta near a multiple of pi) against n u for the rotation: <= 64^2 u = 5e-13 at the
         // largest harmonic this path admits, on terms that enter the sums with the series' fast-decaying coefficients.
         double s1, c1, cn = 1.0, sn = 0.0, cp, sp;
-        sv_sincos_quarter(ph, s1, c1);
+        sv_sincos_quarter_sc(ph, s1, c1);
         cp = c1;                                         // cos(-theta), sin(-theta): the values "before" harmonic 0
         sp = -s1;
         if (h0 > 0) {
-          sv_sincos_quarter(ph * (double)h0, sn, cn);
-          sv_sincos_quarter(ph * (double)(h0 - 1), sp, cp);
+          // (a real branch on the wave-uniform h0: left to itself the compiler evaluates both sincos for every spike and
+          // selects -- 60 of the ~210 instructions a spike costs in the first pass, which at the north-star shape is the
+          // only pass; round 4, read off the device assembly.  The empty asm cannot be speculated, and the arguments hang on it.)
+          double phh = ph;
+          asm volatile("" : "+v"(phh));
+          sv_sincos_quarter_sc(phh * (double)h0, sn, cn);
+          sv_sincos_quarter_sc(phh * (double)(h0 - 1), sp, cp);
         }
         const double k2 = c1 + c1;
 #pragma unroll
