@@ -874,12 +874,16 @@ __device__ __forceinline__ void item_bwd_body(const EngineView& ev, const int r,
           double kt, bz, b0, b1;
           if (KT == SV_PERIODIC) {      // sin / cos of the inducing points' phases are in LDS since phase 1: angle addition
             const double cs = fma(czl[i], czc, szl[i] * szc), sn = fma(szl[i], czc, -(czl[i] * szc));
-            kt = sv_exp2_neg(fmin(fma(cs, p.h2, -p.h2), 0.0));
-            bz = sn;
+            kt = sv_exp2_neg_sc(fma(cs, p.h2, -p.h2));      // (coefficients in SGPRs: in these conditional blocks the compiler
+            bz = sn;                                        //  rebuilt every one of them in a VGPR pair, 18 v_mov per element)
             b0 = 0.5 - 0.5 * cs;
             b1 = (zl[i] - zc) * sn;
           } else {
-            kern_eval<KT>(zl[i] - zc, p, kt, bz, b0, b1);
+            const double dl = zl[i] - zc, q2 = dl * dl;
+            kt = sv_exp2_neg_sc(-q2 * p.h2);
+            bz = dl;
+            b0 = q2;
+            b1 = 0.0;
           }
           double ak = Am[a][q] * kt;
           gz = -(ak * bz);
