@@ -67,7 +67,7 @@ struct svgpfa_engine {
   bool comb_ride = true;                        // the moments' combine rides in the ELL kernel's launch at full size (SVGPFA_COMB_RIDE=0: own launch)
   bool pair_ride = true;                        // the pair-by-pair pass rides in the class kernels' launch (SVGPFA_PAIR_RIDE=0: own launch)
   int build_wpe = -1;                           // k_build_reg<32>: -1 by grid size, 2 / 3 waves per SIMD forced (SVGPFA_BUILD_WPE)
-  int build_mode = -1;                          // kernel build above M = 16: -1 by size, 0 k_build_reg, 1 k_build_mfma (SVGPFA_BUILD=reg|mfma)
+  int build_mode = -1;                          // kernel build at 16 < M <= 32: -1 / 0 k_build_reg, 1 k_build_mfma (SVGPFA_BUILD=mfma); above 32 always k_build_mfma
   bool front = true;                            // k_front instead of k_prep_mfma + k_times_fwd_mfma in svgpfa_elbo (SVGPFA_FRONT=0: off)
   bool cls_on = true;                           // false: problem too small for the class path's extra launches (set_spikes)
   double series_min_pairs = 1e7;                // SVGPFA_SERIES_MIN_PAIRS: fewest (spike, inducing point) pairs for the class path
@@ -282,7 +282,7 @@ int svgpfa_create(const svgpfa_dims* d, int device, svgpfa_engine** out) {
     const char* ec = getenv("SVGPFA_ELL_CLS");
     e->ell_cls = !(ec && atoi(ec) == 0);
     const char* br = getenv("SVGPFA_BUILD");
-    if (br) e->build_mode = !strcmp(br, "reg") ? 0 : (!strcmp(br, "mfma") ? 1 : -1);
+    if (br) e->build_mode = !strcmp(br, "mfma") ? 1 : -1;
     const char* cr = getenv("SVGPFA_COMB_RIDE");
     e->comb_ride = !(cr && atoi(cr) == 0);
     const char* pr = getenv("SVGPFA_PAIR_RIDE");
@@ -616,11 +616,11 @@ static void launch_build(svgpfa_engine* e, int write_aux, const SnapTable* snap,
   if (e->Mmax <= 16) {
     hipLaunchKernelGGL(k_build_reg<16>, dim3(v.K * ((v.R + 3) / 4) + extra), dim3(64), sv_build_lds(16, v.K, c), e->stream, v,
                        write_aux, snap ? 1 : 0, snap ? *snap : none, c);
-  } else if (e->build_mode == 0 || (e->build_mode < 0 && e->Mmax <= 32)) {
-    // register-resident kernels: the default up to M = 32 (cfg3: 38.6 us against 50-65 us for the blocked kernel at one, two
-    // or four items per wave -- with ~2 500 waves either is one round of the chip and the shorter single-wave latency wins);
-    // SVGPFA_BUILD=reg forces them above
-    if (e->Mmax <= 32) {
+  } else if (e->Mmax <= 32 && e->build_mode != 1) {
+    // register-resident kernel: the default up to M = 32 (cfg3: 38.6 us against 50-65 us for the blocked kernel at one, two
+    // or four items per wave -- the shorter single-wave latency wins).  (Its M = 64 instantiation -- 64 x 64 doubles per
+    // item in registers, 1.62 ms at cfg5 against 1.13 -- was removed in round 4.)
+    {
       // more blocks than fit the chip at two waves per SIMD: the three-wave instantiation, one round instead of two
       const unsigned nblk = (unsigned)(v.K * ((v.R + 1) / 2) + extra);
       const bool three = e->build_wpe == 3 || (e->build_wpe < 0 && nblk > 8u * (unsigned)e->n_cu && nblk <= 12u * (unsigned)e->n_cu);
@@ -630,9 +630,7 @@ static void launch_build(svgpfa_engine* e, int write_aux, const SnapTable* snap,
       else
         hipLaunchKernelGGL((k_build_reg<32, 1>), dim3(nblk), dim3(64), sv_build_lds(32, v.K, c), e->stream, v, write_aux,
                            snap ? 1 : 0, snap ? *snap : none, c);
-    } else
-      hipLaunchKernelGGL(k_build_reg<64>, dim3(v.K * v.R + extra), dim3(64), sv_build_lds(64, v.K, c), e->stream, v, write_aux,
-                         snap ? 1 : 0, snap ? *snap : none, c);
+    }
   } else {                         // M > 32 (SVGPFA_BUILD=mfma: M > 16): blocked, tile products on the f64 MFMA (k_build_mfma;
                                    // cfg5: 1.13 ms against 1.62 ms for k_build_reg<64>, which holds 64 x 64 doubles per item in registers)
     switch (e->NT) {

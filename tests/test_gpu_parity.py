@@ -179,7 +179,7 @@ def test_not_positive_definite_raises():
 @pytest.mark.parametrize("env", [{"SVGPFA_COMB_FOLD": "0"}, {"SVGPFA_COMB_FOLD": "1"}, {"SVGPFA_TILE_NW": "2"},
                                  {"SVGPFA_TILE_NW": "4"}, {"SVGPFA_CLS_FUSED": "0"}, {"SVGPFA_CLS_FUSED": "1"},
                                  {"SVGPFA_ELL_PARTS": "3"}, {"SVGPFA_FRONT": "0"}, {"SVGPFA_FRONT": "0", "SVGPFA_TIMES_NW": "2"},
-                                 {"SVGPFA_BUILD": "mfma"}, {"SVGPFA_BUILD": "reg"}, {"SVGPFA_ELL_CLS": "0"},
+                                 {"SVGPFA_BUILD": "mfma"}, {"SVGPFA_ELL_CLS": "0"},
                                  {"SVGPFA_PAIR_RIDE": "0"}, {"SVGPFA_PAIR_RIDE": "0", "SVGPFA_RBF_SERIES": "0"},
                                  {"SVGPFA_PAIR_RIDE": "0", "SVGPFA_ELL_CLS": "0", "SVGPFA_RBF_SERIES": "0"},
                                  {"SVGPFA_CLS_FUSED": "0", "SVGPFA_RBF_SERIES": "0"},
