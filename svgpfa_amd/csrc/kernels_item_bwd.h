@@ -532,6 +532,8 @@ __device__ __forceinline__ void item_bwd_body(const EngineView& ev, const int r,
       int jo = lg;
       asm volatile("" : "+v"(jo));
       d4 X0[NT];
+      d4 csv[(KT == SV_PERIODIC && FULL) ? NT : 1];      // cos of the pair's phase, kept for the adjoint (FULL; round 4: 16 registers
+                                                          // the kernel has to spare since phase 1 lost its transposes, two FMAs per pair)
 #pragma unroll
       for (int a = 0; a < NT; ++a)
 #pragma unroll
@@ -542,6 +544,7 @@ __device__ __forceinline__ void item_bwd_body(const EngineView& ev, const int r,
             X0[a][q] = p.s2 * sv_exp2_neg(-(dd * dd) * p.h2);
           } else {
             const double cs = fma(stq, szl[j], ctq * czl[j]);
+            if (FULL) csv[a][q] = cs;
             X0[a][q] = p.s2 * sv_exp2_neg(fma(cs, p.h2, -p.h2));
           }
         }
@@ -617,14 +620,14 @@ __device__ __forceinline__ void item_bwd_body(const EngineView& ev, const int r,
 #pragma unroll
           for (int q = 0; q < 4; ++q) {
             const int j = 16 * a + 4 * q + jo;
-            const double gkk = Gk[a][q] * (X0[a][q] * inv_s2);    // gk * ktil
+            const double gkk = Gk[a][q] * X0[a][q];               // gk * kappa: the factor 1 / s2 (kappa -> ktil) goes onto the sums
             const double dd = tq - zl[j];
             if (KT == SV_RBF) {
               const double gd = gkk * dd;
               dz[a][q] += gd;                                    // bz = delta
               th0 = fma(gd, dd, th0);                            // b0 = delta^2
             } else {
-              const double cs = fma(stq, szl[j], ctq * czl[j]);
+              const double cs = csv[a][q];
               const double sn = fma(stq, czl[j], -(ctq * szl[j]));
               const double gsn = gkk * sn;
               dz[a][q] += gsn;                                   // bz = sin(2 pi delta / p)
@@ -683,7 +686,7 @@ __device__ __forceinline__ void item_bwd_body(const EngineView& ev, const int r,
         if (FULL) {
           z = wpart[MP + tid];
           for (int w = 1; w < NWB; ++w) z += wpart[w * 2 * MP + MP + tid];
-          z *= p.cz;
+          z *= p.cz * inv_s2;
         }
       }
       gq[tid] = g;
@@ -699,8 +702,8 @@ __device__ __forceinline__ void item_bwd_body(const EngineView& ev, const int r,
           t1s += tred[2 * w + 1];
         }
       }
-      thq[0] = p.c0 * t0s;
-      thq[1] = p.c1 * t1s;
+      thq[0] = p.c0 * inv_s2 * t0s;
+      thq[1] = p.c1 * inv_s2 * t1s;
     }
     for (int w = 1; w < NWB; ++w) {
       if (wave == w) gt_tiles(false);
