@@ -760,24 +760,29 @@ __device__ __forceinline__ void quad_ell_mfma_body(const EngineView& ev, const d
       if (LC < LT) fill_lm(lt0 * 16);         // block-uniform: every wave takes part, active or not
       const int lt1 = (lt0 + LC < LT) ? lt0 + LC : LT;
       if (active)
-        for (int lt = lt0; lt < lt1; ++lt) {
-          const int lr = (lt - lt0) * 16;     // row of this tile inside the resident chunk
+      {
+        // running pointers into the looped matrix and vector (one add each per tile: with indices recomputed from the tile
+        // number the loop carried eight 32-bit adds per tile pair, a ninth of its vector instructions)
+        const T* pA = LM + li * LDK + lg;                       // row lr + li, column 4 c + lg
+        const T* pT = LM + X::row(lg, 0) * LDK + li;            // row lr + row(lg, c), column 16 t + li
+        const T* pv = lv + lt0 * 16 + X::row(lg, 0);            // element lt 16 + row(lg, q)
+        constexpr int RS = (sizeof(T) == 8) ? 4 : 1;            // row(lg, c) = row(lg, 0) + RS c  (f64: lg + 4 c; f32: 4 lg + c)
+        for (int lt = lt0; lt < lt1; ++lt, pA += 16 * LDK, pT += 16 * LDK, pv += 16) {
           accT h = {0, 0, 0, 0};
 #pragma unroll
-          for (int c = 0; c < KS; ++c) h = X::mfma(lds_frag(&LM[(lr + li) * LDK + 4 * c + lg]), bfrag[c], h);
+          for (int c = 0; c < KS; ++c) h = X::mfma(lds_frag(pA + 4 * c), bfrag[c], h);
           T afrag[KKT][4];                    // looped rows, transposed, for the sum product (independent of E)
           if (want_sums) {
 #pragma unroll
             for (int t = 0; t < KKT; ++t)
 #pragma unroll
-              for (int c = 0; c < 4; ++c) afrag[t][c] = LM[(lr + X::row(lg, c)) * LDK + 16 * t + li];
+              for (int c = 0; c < 4; ++c) afrag[t][c] = pT[RS * c * LDK + 16 * t];
           }
           accT E;
 #pragma unroll
           for (int q = 0; q < 4; ++q) {
-            const int l = lt * 16 + X::row(lg, q);   // looped index of this element's row
-            // ROLE 0: E = w_q 2^(h + d_n) ; ROLE 1: E^T = w_q 2^(h^T + d_n)
-            E[q] = (ROLE == 0) ? lv[l] * X::exp2(h[q] + ov) : ov * X::exp2(h[q] + lv[l]);     // exact 0 where l or the own index is padding
+            // ROLE 0: E = w_q 2^(h + d_n) ; ROLE 1: E^T = w_q 2^(h^T + d_n); exact 0 where the looped or the own index is padding
+            E[q] = (ROLE == 0) ? pv[RS * q] * X::exp2(h[q] + ov) : ov * X::exp2(h[q] + pv[RS * q]);
             colsum += E[q];
           }
           if (want_sums) {
@@ -787,6 +792,7 @@ __device__ __forceinline__ void quad_ell_mfma_body(const EngineView& ev, const d
               for (int c = 0; c < 4; ++c) acc[t] = X::mfma(afrag[t][c], E[c], acc[t]);
           }
         }
+      }
       if (LC < LT) __syncthreads();           // all waves done with this chunk before it is overwritten
     }
     esum += (double)colsum;
