@@ -9,7 +9,10 @@ the named synthetic workload (seeded), inputs already resident i
                     groups -- the closure of the reference's svLBFGS.py:162-174 (headline)
   variant "estep" : ELBO + gradients of the variational parameters, kernels not rebuilt --
                     the closure of the reference's svEM.py:218-223
-With N > 1 (launched by torch.distributed.run, one rank per GPU) the 500 trials are sharded by
+With N > 1 -- one rank per GPU, started either by torch.distributed.run (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in
+the environment; WORLD_SIZE must equal --gpus) or, when `python bench.py --gpus N` is run bare, by this script itself
+(launch_ranks: N child interpreters, the parent never touches a GPU and relays rank 0's line; any rank failing, or a
+line whose n_gpus is not N, is a non-zero exit) -- the 500 trials are sharded by
 spike count across ranks (total work fixed: "strong" scaling) and every step ends with ONE RCCL
 all-reduce of the shared vector [ELBO, ELL, KL, dC, dd, dtheta].  `value` is the BLOCKING form
 (svgpfa_amd.distributed.allreduce_shared: the compute stream waits for the reduced vector before the
@@ -348,6 +351,82 @@ def measured_traffic(config, variant, full_mask, prefix="k_spike"):
     return best
 
 
+def rank_environments(n, port, base=None):
+    """The environment of each of the n ranks of one node, as torch.distributed.run would set it."""
+    envs = []
+    for r in range(n):
+        env = dict(os.environ if base is None else base)
+        env.update(RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), SVGPFA_BENCH_LAUNCHED="1")
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # dmabuf IPC: what RCCL needs on this pool's host driver
+        envs.append(env)
+    return envs
+
+
+def launch_ranks(n, argv, script=None, timeout=None):
+    """`python bench.py --gpus N` without torch.distributed.run: start N fresh interpreters of this script (one rank per
+    GPU, RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set), relay what they print (only rank 0 prints the JSON line) and return
+    0 only if EVERY rank did and rank 0 printed a line with n_gpus == N.  The launcher itself never imports torch and never
+    touches a GPU; children are new processes (no exec of a process that has initialised one).  A rank that fails takes
+    the others down with it (they would wait in a collective for ever)."""
+    import socket
+    import subprocess
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    script = script or os.path.abspath(__file__)
+    procs = []
+    for r, env in enumerate(rank_environments(n, port)):
+        procs.append(subprocess.Popen([sys.executable, script] + list(argv), env=env,
+                                      stdout=subprocess.PIPE if r == 0 else None, text=True))
+    t_end = None if timeout is None else time.monotonic() + timeout
+    out0, rcs = None, [None] * n
+    try:
+        while any(rc is None for rc in rcs):
+            for r, p in enumerate(procs):
+                if rcs[r] is not None:
+                    continue
+                if r == 0 and out0 is None:
+                    try:
+                        out0 = p.communicate(timeout=0.2)[0]
+                    except subprocess.TimeoutExpired:
+                        pass
+                rc = p.poll()
+                if rc is not None:
+                    rcs[r] = rc
+                    if r == 0 and out0 is None:
+                        out0 = p.communicate()[0]
+                    if rc != 0:
+                        raise RuntimeError(f"rank {r} exited with code {rc}")
+            if t_end is not None and time.monotonic() > t_end:
+                raise RuntimeError(f"ranks did not finish within {timeout} s")
+            time.sleep(0.05)
+    except (RuntimeError, KeyboardInterrupt) as e:
+        for p in procs:                        # exactly the processes started here
+            if p.poll() is None:
+                p.terminate()
+        for p in procs:
+            try:
+                p.wait(timeout=10)
+            except subprocess.TimeoutExpired:
+                p.kill()
+        if out0:
+            sys.stdout.write(out0)
+        print(f"[bench] launch of {n} ranks failed: {e}", file=sys.stderr)
+        return 1
+    sys.stdout.write(out0 or "")
+    sys.stdout.flush()
+    lines = [ln for ln in (out0 or "").splitlines() if ln.startswith("{")]
+    try:
+        got = json.loads(lines[-1])["n_gpus"] if lines else None
+    except (ValueError, KeyError):
+        got = None
+    if got != n:
+        print(f"[bench] asked for --gpus {n}, rank 0 reported n_gpus = {got}", file=sys.stderr)
+        return 1
+    return 0
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -377,17 +456,25 @@ def main():
     if args.cpu_sample_trials is None:
         args.cpu_sample_trials = {"cfg2": 50, "cfg3": 200, "cfg5": 12}[args.config]
 
+    # --gpus N > 1 without a launcher's environment: this process becomes the launcher (launch_ranks) -- before torch is
+    # imported, so the parent never touches a GPU -- and relays rank 0's line.  Under torch.distributed.run (WORLD_SIZE
+    # set) the rank count must BE --gpus: a line whose n_gpus differs from what was asked for is refused, not annotated.
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(launch_ranks(args.gpus, sys.argv[1:]))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        sys.exit(f"[bench] --gpus {args.gpus} but WORLD_SIZE={world}: refusing to report a line for a rank count that was "
+                 f"not asked for (launch with --nproc-per-node {args.gpus}, or run `python bench.py --gpus {args.gpus}` "
+                 f"without a launcher and let it start its own ranks)")
+
     import torch
     import torch.distributed as dist
     from svgpfa_amd.distributed import allreduce_shared, allreduce_shared_async
     from svgpfa_amd.engine import engine_from_problem
     from svgpfa_amd.utils import synthetic
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and rank == 0:
-        print(f"[bench] note: --gpus {args.gpus} but WORLD_SIZE={world}; using WORLD_SIZE", file=sys.stderr)
     if args.single_device:
         local_rank = 0
     torch.cuda.set_device(local_rank)

@@ -1,7 +1,10 @@
 """CPU-only tests: C-ABI surface, loud failure modes, host-side sharding logic, 2-rank gloo exchange."""
 import os
 import re
+import json
 import socket
+import subprocess
+import time
 import sys
 
 import numpy as np
@@ -164,3 +167,53 @@ def test_two_rank_gloo_async_exchange_with_alternating_buffers():
         p.join(timeout=180)
         assert p.exitcode == 0
     assert q.get(timeout=5) == 0.0
+
+
+# ---- bench.py as its own launcher (`python bench.py --gpus N` without torch.distributed.run) -------------------------------
+_FAKE_RANK = """
+import json, os, sys, time
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+assert os.environ["LOCAL_RANK"] == os.environ["RANK"] and os.environ["MASTER_ADDR"] == "127.0.0.1" and int(os.environ["MASTER_PORT"]) > 0
+mode = sys.argv[1]
+if mode == "fail" and rank == 1:
+    sys.exit(3)
+if mode == "fail" and rank == 0:
+    time.sleep(60)          # waits "in a collective" for the rank that died: the launcher must end it
+if rank == 0:
+    print("noise before the line")
+    print(json.dumps({"n_gpus": 1 if mode == "wrong" else world, "value": 1.0}))
+"""
+
+
+def _bench_module():
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_under_test", os.path.join(REPO, "bench.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def test_bench_launcher_starts_its_own_ranks(tmp_path, capfd):
+    bench = _bench_module()
+    fake = tmp_path / "fake_rank.py"
+    fake.write_text(_FAKE_RANK)
+    envs = bench.rank_environments(4, 12345, base={})
+    assert [e["RANK"] for e in envs] == ["0", "1", "2", "3"] and all(e["WORLD_SIZE"] == "4" for e in envs)
+    assert all(e["HSA_ENABLE_IPC_MODE_LEGACY"] == "0" for e in envs)
+    assert bench.launch_ranks(2, ["ok"], script=str(fake), timeout=60) == 0
+    out = capfd.readouterr().out
+    assert json.loads([ln for ln in out.splitlines() if ln.startswith("{")][-1])["n_gpus"] == 2
+    t0 = time.monotonic()
+    assert bench.launch_ranks(2, ["fail"], script=str(fake), timeout=60) == 1      # a dead rank ends the run, loudly
+    assert time.monotonic() - t0 < 30
+    assert "rank 1 exited with code 3" in capfd.readouterr().err
+    assert bench.launch_ranks(2, ["wrong"], script=str(fake), timeout=60) == 1     # a line for another rank count
+    assert "n_gpus = 1" in capfd.readouterr().err
+
+
+def test_bench_refuses_a_rank_count_that_was_not_asked_for():
+    """torch.distributed.run with one rank but --gpus 2: exit non-zero before anything is measured (and before torch)."""
+    env = dict(os.environ, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    run = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "2"], env=env, capture_output=True,
+                         text=True, timeout=120)
+    assert run.returncode != 0 and "WORLD_SIZE=1" in run.stderr and not run.stdout.strip()

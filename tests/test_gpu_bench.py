@@ -46,6 +46,24 @@ def test_bench_lines_one_and_two_ranks():
     assert abs(j2["elbo"] - j1["elbo"]) <= 1e-11 * abs(j1["elbo"])
 
 
+def test_bench_starts_its_own_ranks_without_a_launcher():
+    """`python bench.py --gpus 2` with no torch.distributed.run in front: the script starts two ranks itself (here both on
+    cuda:0 over gloo), rank 0's line says n_gpus = 2 and carries the three loops' values."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    run = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "2", "--backend", "gloo",
+                          "--single-device", "--no-cpu-baseline", "--config", "cfg2", "--steps", "5", "--warmup", "1"],
+                         capture_output=True, text=True, timeout=900, cwd=REPO, env=env)
+    assert run.returncode == 0, run.stderr[-2000:]
+    j = _last_json(run.stdout)
+    assert j["n_gpus"] == 2 and j["scaling"] == "strong"
+    for key in ("value", "value_host_synced", "value_pipelined"):
+        assert j[key] > 0
+    bad = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "2", "--backend", "gloo",
+                          "--single-device", "--no-cpu-baseline", "--config", "cfg2", "--steps", "2"],
+                         capture_output=True, text=True, timeout=300, cwd=REPO, env=dict(env, WORLD_SIZE="1", RANK="0"))
+    assert bad.returncode != 0 and not bad.stdout.strip()
+
+
 def test_graft_entry_smoke_in_a_fresh_interpreter():
     """The driver's entry point exactly as it calls it: build() then smoke() in a new process (this is the path where
     the HIP library could be loaded before torch)."""
