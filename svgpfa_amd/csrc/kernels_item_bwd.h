@@ -32,25 +32,55 @@
 // the class's moments + three coefficient rows); it borrows the Gt region, which nothing else uses before the reductions
 #define SV_GATHER_SCR (SV_ACOLS + 3 * (SV_FH + 1))
 
+// ---- M x M matrices of an item in LDS: TILE-PACKED lower triangles (round 5).  A lower-triangular (Linv, Vt) or symmetric
+// (Gt, At, C + C^T's inputs) matrix is kept as its NT (NT + 1) / 2 tiles of 16 x 16 on and below the diagonal, tile (a, b),
+// a >= b, at sv_tidx(a, b) * SV_TSZ, rows of a tile SV_TS = 18 doubles apart (both MFMA fragment patterns of a tile --
+// row-major li * 18 + 4 q + lg and transposed (4 q + lg) * 18 + li -- are conflict-free ds_read_b64).  A symmetric matrix
+// is read through whichever of the two patterns the tile's position asks for.  Against full MP x (MP + 2) images: 23 KB
+// instead of 34 KB per matrix at M = 64, which is what lets two blocks of k_item_bwd<4> share a CU.
+#define SV_TS 18
+#define SV_TSZ (16 * SV_TS)
+__host__ __device__ constexpr int sv_tidx(int a, int b) { return a * (a + 1) / 2 + b; }      // a >= b
+// element (i, j) of a tile-packed lower triangle, block row of i >= block row of j
+__device__ __forceinline__ int sv_tp(int i, int j) { return sv_tidx(i >> 4, j >> 4) * SV_TSZ + (i & 15) * SV_TS + (j & 15); }
+
+// Exchange tiles of phase 1 double-buffered (one block barrier per node tile instead of two): where the LDS is to spare
+#ifndef SV_BWD_DB
+#define SV_BWD_DB 1
+#endif
+__host__ __device__ constexpr bool sv_bwd_db(int NT) { return SV_BWD_DB && NT <= 2; }
+// transcendental kernels of the node-tile loop: polynomial coefficients in SGPR pairs (sv_math.h) or left to the compiler
+#ifndef SV_BWD_SC
+#define SV_BWD_SC 1
+#endif
+#if SV_BWD_SC
+#define SV_BWD_EXP2 sv_exp2_neg_sc
+#define SV_BWD_SINCOS sv_sincos_quarter_sc
+#else
+#define SV_BWD_EXP2 sv_exp2_neg
+#define SV_BWD_SINCOS sv_sincos_quarter
+#endif
+
 // LDS layout of one block (offsets in doubles) -- ONE constexpr function shared by the kernel (which places its buffers with
-// it) and the host (which sizes the launch with it), so the two cannot disagree.  The per-wave partial sums of phase 1, the
-// gather's scratch and the Gt / At matrix of phase 2 share one region: at the north-star shape (NT = 2, 2 waves) a block
-// needs 38 KB, so four blocks (8 waves, what the registers allow) stay resident per CU.  The FULL variant keeps E in a
-// buffer of its own at every M: Vt stays staged for phase 2 (until round 4 E took Vt's place at M <= 32 and Vt was fetched
-// again behind the node tiles -- a second exposed memory latency per block for 9 KB of LDS that four blocks per CU leave
-// unused anyway).
+// it) and the host (which sizes the launch with it), so the two cannot disagree.  A block is G = NWB / NT teams of NT
+// waves; wave c of a team owns column panel c of everything (see item_bwd_body).  Region X is, in turn: the gather's
+// scratch, the per-team exchange tiles of phase 1 (kernel tile X0 and whitened tile KwT: 2 NT register images of 256
+// doubles per team), then Gt / At of phase 2.  NT = 4, one team: 9 800 doubles = 78 KB, two blocks per CU.
 struct ItemBwdLayout {
-  size_t Li, Vl, S, ul, al, zl, gt, gs, gq, gzq, szl, czl, wpart, tred, redz, redt, thq, p1l, cvd, tpl, Dl, total;
+  size_t Li, Vl, X, ul, al, zl, gt, gs, gq, gzq, szl, czl, wpart, tred, redz, redt, thq, p1l, cvd, tpl, total;
 };
 __host__ __device__ constexpr ItemBwdLayout sv_item_bwd_layout(int NT, int NWB, bool full) {
-  const size_t MP = 16 * NT, LD = MP + 2;
-  const size_t SZ = (MP * LD > SV_GATHER_SCR) ? MP * LD : SV_GATHER_SCR;
-  const bool dsep = full;
+  const size_t MP = 16 * NT, TM = (size_t)(NT * (NT + 1) / 2) * SV_TSZ;
+  const size_t G = (NWB / NT) > 0 ? (size_t)(NWB / NT) : 1;
+  size_t XS = TM;
+  if (XS < G * NT * (sv_bwd_db(NT) ? 4 : 2) * 256) XS = G * NT * (sv_bwd_db(NT) ? 4 : 2) * 256;
+  if (XS < SV_GATHER_SCR) XS = SV_GATHER_SCR;
+  (void)full;
   ItemBwdLayout o{};
   size_t p = 0;
-  o.Li = p; p += MP * LD;          // Linv
-  o.Vl = p; p += MP * LD;          // Vt; later C
-  o.S = p; p += SZ;                // gather scratch; then Gt summed over the waves (rows padded to LD), later At
+  o.Li = p; p += TM;               // Linv
+  o.Vl = p; p += TM;               // Vt; later the tiles of C on and above the diagonal
+  o.X = p; p += XS;                // gather scratch; exchange tiles of phase 1; Gt, later At
   o.ul = p; p += MP;               // ut
   o.al = p; p += MP;               // a = Linv^T ut
   o.zl = p; p += MP;               // Z
@@ -60,7 +90,7 @@ __host__ __device__ constexpr ItemBwdLayout sv_item_bwd_layout(int NT, int NWB, 
   o.gzq = p; p += MP;              // quadrature part of dZ (direct)
   o.szl = p; p += MP;              // sin of the inducing-point phases (periodic)
   o.czl = p; p += MP;              // cos
-  o.wpart = p; p += (size_t)NWB * 2 * MP;   // per-wave partial sums of gu / dz behind the node tiles
+  o.wpart = p; p += G * 2 * MP;    // per-team partial sums of gu / dz behind the node tiles
   o.tred = p; p += (size_t)NWB * 2;
   o.redz = p; p += (size_t)NT * MP;   // per-panel row sums of the dZ contraction
   o.redt = p; p += 2 * (size_t)NT;    // per-panel dtheta partials
@@ -68,8 +98,6 @@ __host__ __device__ constexpr ItemBwdLayout sv_item_bwd_layout(int NT, int NWB, 
   o.p1l = p; p += MP;              // spike partial sums P1 of the trial
   o.cvd = p; p += MP;              // 1 / diag(L_S)
   o.tpl = p; p += 8;               // spike-direct theta partials of the trial, 2 used
-  o.Dl = dsep ? p : o.Vl;          // E = Linv^T (Vt Vt^T - I) Linv (FULL): its own MP x LD buffer
-  if (dsep) p += MP * LD;
   o.total = p;
   return o;
 }
@@ -384,21 +412,138 @@ __device__ SV_GATHER_ATTR void gather_item_inputs(const EngineView& ev, const La
 }
 
 // ---- phases 1 + 2 --------------------------------------------------------------------------------------------------
+// Round 5: PANEL OWNERS.  A block is G teams of NT waves; wave c of a team owns the 16 inducing points of panel c in every
+// node tile the team processes (team g takes tiles g, g + G, ...):
+//   (1) it evaluates the raw kernel tile X0_c = kappa(nodes, z_{16 c ..}) -- every (node, inducing point) pair is evaluated
+//       once per item, whatever the number of waves -- and hands its register image to the team through LDS;
+//   (2) with all X0_b of the tile: Gk_c = E[c, :] kappa (FULL; its panel of the symmetric E = Linv^T (Vt Vt^T - I) Linv stays
+//       in REGISTERS for the whole item: the accumulator layout of E[:, c] is the A-operand layout of E[c, :]) and the
+//       whitened tile KwT_c = (Linv kappa)_c^T (row block c of Linv: c + 1 tile products), handed over likewise;
+//   (3) column c of Gt += KwT^T diag(gv) KwT: tiles (a, c), a >= c (NT - c tile products) -- every tile of Gt has ONE owner,
+//       complete at the end of the loop -- and the adjoint sums of its own inducing points.
+// Per node tile a wave issues NT + (c + 1) + (NT - c) = 2 NT + 1 tile products whatever its panel: the team is balanced by
+// construction (round 4 dealt whole node tiles over the waves: 13 tiles on 2 or 4 waves, every wave carrying all
+// NT (NT + 1) / 2 accumulator tiles of Gt -- 80 registers at M = 64, which is what kept k_item_bwd<4> at one wave per SIMD).
+// Two block barriers per node tile order the two hand-overs; no exchange tile is double-buffered (a tile's readers finish
+// in front of the barrier its next writer waits behind).
+template <int NT, int MODE>
+__device__ __forceinline__ void tri_chain_tp(d4 (&D)[NT], const double* Mat, const d4 (&B)[NT], const int orm, const int otr) {
+#pragma unroll
+  for (int a = 0; a < NT; ++a) {
+    d4 acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int b = 0; b < NT; ++b) {
+      if (MODE == 0 ? (b <= a) : (b >= a)) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const double av = (MODE == 0) ? lds_frag(&Mat[sv_tidx(a, b) * SV_TSZ + orm + 4 * q])
+                                        : lds_frag(&Mat[sv_tidx(b, a) * SV_TSZ + otr + 4 * q * SV_TS]);
+          acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, B[b][q], acc, 0, 0, 0);
+        }
+      }
+    }
+    D[a] = acc;
+  }
+}
+// A-operand fragment (row 16 a + li, column 16 b + 4 q + lg) of a SYMMETRIC tile-packed matrix (a, b compile-time)
+#define SV_SYMFRAG(Mat, a, b, q) \
+  (((a) >= (b)) ? lds_frag(&(Mat)[sv_tidx((a), (b)) * SV_TSZ + orm + 4 * (q)]) : lds_frag(&(Mat)[sv_tidx((b), (a)) * SV_TSZ + otr + 4 * (q) * SV_TS]))
+
+__device__ __forceinline__ void sv_tile_ab(int t, int& a, int& b) {
+  a = (t >= 1) + (t >= 3) + (t >= 6);
+  b = t - a * (a + 1) / 2;
+}
+
+// LDS-DMA staging of a packed lower triangle into the tile-packed image (global_load_lds, 16 bytes per lane: a wave
+// instruction fills 128 consecutive doubles of the image; pairs above the diagonal, beyond M and the tiles' row padding
+// come from a zero pair in global memory; the pair that holds a diagonal element of an odd-length row ends in the pad zero
+// its producer wrote, sv_tri_off).  23 wave instructions per matrix at M = 64.
+template <int NT>
+__device__ __forceinline__ void stage_matrix_dma_tp(double* dst, const double* src, int M, int tid, int nth) {
+  constexpr int TOT2 = NT * (NT + 1) / 2 * SV_TSZ / 2;       // pairs of doubles in the image
+  const int lane = tid & 63, wave = tid >> 6, nw = nth >> 6;
+  for (int cc = wave; cc * 64 < TOT2; cc += nw) {
+    const int e2 = cc * 64 + lane;
+    if (e2 < TOT2) {
+      const int t = e2 / (SV_TSZ / 2), rem = e2 - t * (SV_TSZ / 2), it = rem / (SV_TS / 2), jp = rem - it * (SV_TS / 2);
+      int a, b;
+      sv_tile_ab(t, a, b);
+      const int i = 16 * a + it, j = 16 * b + 2 * jp;
+      const double* g = (jp < 8 && i < M && j <= i) ? src + sv_tri_off(i) + j : sv_zero_pad;
+      __builtin_amdgcn_global_load_lds((const void*)g, (__attribute__((address_space(3))) void*)(dst + cc * 128), 16, 0, 0);
+    }
+  }
+}
+
+// Linv, Vt (tile-packed), ut, Z of the item into LDS.  M <= 32: both factors and the two vectors are requested before
+// anything is stored (one exposed memory latency); above: LDS-DMA.  The caller synchronises.
+template <int NT>
+__device__ __forceinline__ void load_factors_tp(const EngineView& ev, const LatentMeta& m, int r, double* Li, double* Vl,
+                                                double* ul, double* zl) {
+  constexpr int MP = 16 * NT, NE = NT * (NT + 1) / 2 * 256;
+  const int M = m.M, tid = threadIdx.x, nth = (int)blockDim.x;
+  const long long base = m.offTT + (long long)r * m.PT;      // Linv, Vt: packed lower triangles
+  const long long vbase = m.offM + (long long)r * M;
+  const double* sl = ev.Linv + base;
+  const double* sv = ev.Vt + base;
+  const double uv = (tid < M) ? ev.ut[vbase + tid] : 0.0;
+  const double zv = (tid < M) ? ev.Zs[vbase + tid] : 0.0;
+  if (NT <= 2) {
+    constexpr int U = (NT == 1) ? 2 : 6;
+    for (int e0 = tid; e0 < NE; e0 += U * nth) {
+      double va[U], vb[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int e = e0 + u * nth, t = e >> 8, it = (e >> 4) & 15, jt = e & 15;
+        int a, b;
+        sv_tile_ab(t, a, b);
+        const int i = 16 * a + it, j = 16 * b + jt;
+        const bool ok = e < NE && i < M && j <= i;
+        const int o = ok ? sv_tri_off(i) + j : 0;
+        const double x = sl[o], y = sv[o];
+        va[u] = ok ? x : 0.0;
+        vb[u] = ok ? y : 0.0;
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int e = e0 + u * nth, t = e >> 8, it = (e >> 4) & 15, jt = e & 15;
+        if (e < NE) {
+          Li[t * SV_TSZ + it * SV_TS + jt] = va[u];
+          Vl[t * SV_TSZ + it * SV_TS + jt] = vb[u];
+        }
+      }
+    }
+  } else {
+    stage_matrix_dma_tp<NT>(Li, sl, M, tid, nth);
+    stage_matrix_dma_tp<NT>(Vl, sv, M, tid, nth);
+  }
+  if (tid < MP) {
+    ul[tid] = uv;
+    zl[tid] = zv;
+  }
+  if (NT >= 3) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the DMA pieces have landed (a barrier follows in the caller)
+}
+
 template <int NT, int KT, bool FULL>
 __device__ __forceinline__ void item_bwd_body(const EngineView& ev, const int r, const int k, const LatentPtrs pt, unsigned mask,
                               double* sm) {
-  constexpr int MP = 16 * NT, LD = MP + 2, NTRI = NT * (NT + 1) / 2;
+  constexpr int MP = 16 * NT, TS = SV_TS, TSZ = SV_TSZ;
+  constexpr bool DB = sv_bwd_db(NT);
   const int tid = threadIdx.x;
-  const int lane = tid & 63, wave = tid >> 6, li = lane & 15, lg = lane >> 4;
-  const int NTHB = blockDim.x, NWB = NTHB >> 6;   // 2 or 4 waves per block (host: 2 when the grid is large and M <= 32)
+  const int lane = tid & 63, li = lane & 15, lg = lane >> 4;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int NTHB = blockDim.x, NWB = NTHB >> 6;   // NT G waves per block (host: G = 1, 2 or 4 teams)
+  const int G = NWB / NT;
+  const int team = wave / NT, c = wave - team * NT;        // wave-uniform (SGPRs): team and panel of this wave
+  const int orm = li * TS + lg, otr = lg * TS + li;        // row-major / transposed fragment offsets inside a tile
   const int item = r * ev.K + k;
   const LatentMeta m = ev.meta[k];
   const int M = m.M, Q = ev.Q, K = ev.K;
   const ItemBwdLayout lay = sv_item_bwd_layout(NT, NWB, FULL);   // buffer meanings: see the layout function
   double* Li = sm + lay.Li;
   double* Vl = sm + lay.Vl;
-  double* S = sm + lay.S;
-  double* Gl = S;                     // (symmetric, rows padded to LD: phase 2's Gt, later At)
+  double* X = sm + lay.X;
+  double* Gl = X;                     // (symmetric, tile-packed: phase 2's Gt, later At)
   double* ul = sm + lay.ul;
   double* al = sm + lay.al;
   double* zl = sm + lay.zl;
@@ -416,9 +561,7 @@ __device__ __forceinline__ void item_bwd_body(const EngineView& ev, const int r,
   double* p1l = sm + lay.p1l;
   double* cvd = sm + lay.cvd;
   double* tpl = sm + lay.tpl;
-  double* Dl = sm + lay.Dl;
   const KPar p = make_kpar(m, ev.theta + 2 * k);
-  const long long base = m.offTT + (long long)r * m.PT;      // Vt: packed lower triangle
   const long long vbase = m.offM + (long long)r * M;
   const bool want_lat = (mask & (1u | 4u | 8u)) != 0;
   const bool want_zt = (mask & (4u | 8u)) != 0;
@@ -427,7 +570,7 @@ __device__ __forceinline__ void item_bwd_body(const EngineView& ev, const int r,
   const GatherPre gpre = gather_issue(ev, m, pt, r, k, mask, want_zt);
 
   if (want_lat) {
-    load_factors<NT>(ev, m, r, Li, Vl, ul, zl, true);
+    load_factors_tp<NT>(ev, m, r, Li, Vl, ul, zl);
   } else if (tid < MP) {
     ul[tid] = 0.0;
     zl[tid] = 0.0;
@@ -435,10 +578,9 @@ __device__ __forceinline__ void item_bwd_body(const EngineView& ev, const int r,
   if (tid < MP) al[tid] = (tid < M) ? ev.a[vbase + tid] : 0.0;
   // The gather of phase 2's inputs (for class-path items: the combine of the spike moments) runs HERE, beside the
   // staging of the factors: between the phases, where the values are used, its memory latency was exposed (12 us of the
-  // kernel at the north-star size).  (Round 2 kept it between the phases above M = 32 after an intermediate version
-  // returned wrong sums there: a compiler defect)
+  // kernel at the north-star size).
   SV_CK(1);
-  gather_item_inputs<MP>(ev, m, pt, r, k, mask, want_zt, p, gpre, gs, p1l, cvd, gt, tpl, S);
+  gather_item_inputs<MP>(ev, m, pt, r, k, mask, want_zt, p, gpre, gs, p1l, cvd, gt, tpl, X);
   SV_CK(2);
   if (SV_BWD_STOP == 9) return;      // after the staging of the factors and the gather
 
@@ -446,56 +588,43 @@ __device__ __forceinline__ void item_bwd_body(const EngineView& ev, const int r,
     // ================================================================= phase 1: quadrature adjoints
     __syncthreads();
     if (KT == SV_PERIODIC && tid < MP) sv_sincos_quarter(zl[tid] * p.q4, szl[tid], czl[tid]);
+    // The adjoint of kappa(t, Z) at a node is gk = Linv^T [gm ut + 2 gv (Vt Vt^T - I) kt], kt = Linv kappa(t, Z), i.e.
+    //     gk = gm a + 2 gv E kappa(t, Z)      with the per-item SYMMETRIC matrix  E = Linv^T (Vt Vt^T - I) Linv
+    // one dense M x M x 16 product per tile on the RAW kernel values, independent of the whitening chain of the same tile.
+    // Rounding: E kappa and D kt (D = Linv^T (Vt Vt^T - I), round 3) both carry an absolute error of order u cond(Kzz); the
+    // MATLAB-fixture parity test (eps = 1e-5, cond 1e6) bounds it either way.  Every wave builds the panel it owns (the
+    // waves of further teams repeat their team-0 twin's chain: no wave-uniform branch around this register-heavy section,
+    // DESIGN.md section 9) and keeps it: Ep[b][q] = E[16 b + 4 q + lg][16 c + li] = E[16 c + li][16 b + 4 q + lg].
+    d4 Ep[NT];
     if (FULL) {
-      // The adjoint of kappa(t, Z) at a node is gk = Linv^T [gm ut + 2 gv (Vt Vt^T - I) kt], kt = Linv kappa(t, Z), i.e.
-      //     gk = gm a + 2 gv E kappa(t, Z)      with the per-item SYMMETRIC matrix  E = Linv^T (Vt Vt^T - I) Linv
-      // one dense M x M x 16 product per tile on the RAW kernel values -- independent of the whitening chain of the same
-      // tile (round 3 multiplied D = Linv^T (Vt Vt^T - I) with kt: the same 16 MFMAs, but behind the 12 of kt).  Rounding:
-      // E kappa and D kt both carry an absolute error of order u cond(Kzz) (kt itself is computed with u sqrt(cond) and then
-      // multiplied by D ~ sqrt(cond)); the MATLAB-fixture parity test (eps = 1e-5, cond 1e6) bounds it either way.
-      // E is built once per item, one 16-column panel per wavefront.
-      // Every wave builds a panel (NWB >= NT in every launch configuration; waves >= NT repeat panel wave % NT and store
-      // the same values again): no wave-uniform branch around this register-heavy section.  ROCm 7.2's compiler was caught
-      // placing a spill of threadIdx.x at the JOIN of such a branch in front of the exec restore (DESIGN.md section 9,
-      // tests/tools/isa_exec_guard.py), where a wave that skipped the branch loses it.
-      d4 Ep[NT];
-      const int c = wave % NT;
-      {
-        d4 P[NT], T1[NT], T2[NT];
+      d4 P[NT], T1[NT], T2[NT];
 #pragma unroll
-        for (int b = 0; b < NT; ++b)
+      for (int b = 0; b < NT; ++b)
 #pragma unroll
-          for (int q = 0; q < 4; ++q) P[b][q] = Li[(16 * b + 4 * q + lg) * LD + 16 * c + li];   // Linv[:, panel c]
-        tri_chain<NT, 1>(T1, Vl, LD, P, li, lg);       // Vt^T Linv[:, c]
-        tri_chain<NT, 0>(T2, Vl, LD, T1, li, lg);      // Vt Vt^T Linv[:, c]
-#pragma unroll
-        for (int a = 0; a < NT; ++a)
-#pragma unroll
-          for (int q = 0; q < 4; ++q) T2[a][q] -= P[a][q];
-        tri_chain<NT, 1>(Ep, Li, LD, T2, li, lg);      // Linv^T (Vt Vt^T - I) Linv[:, c]
-      }
+        for (int q = 0; q < 4; ++q) {
+          const double v = Li[((b >= c) ? (b * (b + 1) / 2 + c) : 0) * TSZ + otr + 4 * q * TS];      // Linv[:, panel c]
+          P[b][q] = (b >= c) ? v : 0.0;
+        }
+      tri_chain_tp<NT, 1>(T1, Vl, P, orm, otr);       // Vt^T Linv[:, c]
+      tri_chain_tp<NT, 0>(T2, Vl, T1, orm, otr);      // Vt Vt^T Linv[:, c]
 #pragma unroll
       for (int a = 0; a < NT; ++a)
 #pragma unroll
-        for (int q = 0; q < 4; ++q) Dl[(16 * a + 4 * q + lg) * LD + 16 * c + li] = Ep[a][q];
+        for (int q = 0; q < 4; ++q) T2[a][q] -= P[a][q];
+      tri_chain_tp<NT, 1>(Ep, Li, T2, orm, otr);      // Linv^T (Vt Vt^T - I) Linv[:, c]
     }
-    __syncthreads();
+    __syncthreads();                   // (the gather's scratch in region X is dead: the exchange tiles take its place)
     SV_CK(3);
-    if (SV_BWD_STOP == 10) return;   // after the D panels
-    d4 dz[NT], GW[NTRI];
-    double gu[NT];                      // lane (li, lg): partial of gu_{16 a + li} over the nodes lg + 4 q of every tile
+    if (SV_BWD_STOP == 10) return;   // after the E panels
+    d4 GW[NT];                          // column c of Gt: tile (a, c), a >= c
+    d4 dz = {0.0, 0.0, 0.0, 0.0};       // lane (li, lg): partial of dz_{16 c + 4 q + lg} over the nodes li of every tile
+    double gu = 0.0;                    // partial of gu_{16 c + li} over the nodes lg + 4 q of every tile
 #pragma unroll
-    for (int a = 0; a < NT; ++a) {
-      gu[a] = 0.0;
-      dz[a] = (d4){0.0, 0.0, 0.0, 0.0};
-    }
-#pragma unroll
-    for (int t = 0; t < NTRI; ++t) GW[t] = (d4){0.0, 0.0, 0.0, 0.0};
+    for (int a = 0; a < NT; ++a) GW[a] = (d4){0.0, 0.0, 0.0, 0.0};
     double th0 = 0.0, th1 = 0.0;
-    double* Sw = wpart + wave * 2 * MP;    // this wave's partial sums of gu / dz (written behind its last tile)
-    // periodic: kappa and its derivative bases follow from the node's own sin / cos and the inducing
-    // points' (szl, czl) by angle addition (no per-pair sincos, no second exp).  Per-j constants are read
-    // from LDS at their use sites (jo is an opaque 0: it keeps them out of long-lived registers).
+    double* Xb = X + (size_t)team * (DB ? 4 : 2) * NT * 256;     // this team's raw kernel tiles: register image of panel b at [b][q][lane]
+    double* Kb = Xb + NT * 256;                                  // ... whitened tiles (DB: the second pair of buffers behind them)
+    const int jb = 16 * c + lg;                       // this lane's inducing points: jb + 4 q
     const double inv_s2 = 1.0 / p.s2;
     // Node lists of the item.  Segment 0: the trial's Q quadrature nodes with the adjoints the ELL kernel left in
     // [r][k][q] (contiguous for this item).  Segment 1 (statistics mode only, mask bit SV_MASK_STATS): the trial's spike
@@ -503,152 +632,174 @@ __device__ __forceinline__ void item_bwd_body(const EngineView& ev, const int r,
     // spike term's backward, for likelihoods whose spike adjoint is not known a priori (svgpfa_latent_stats_backward).
     const int nseg = (mask & SV_MASK_STATS) ? 2 : 1;
     for (int seg = 0; seg < nseg; ++seg) {
-    const long long s0 = seg ? ev.spk_off[r] : 0;
-    const int Qs = seg ? (int)(ev.spk_off[r + 1] - s0) : Q;
-    const double* gmq = seg ? ev.gmuspk + (long long)k * ev.S + s0 : ev.gmuq + ((long long)r * K + k) * Q;
-    const double* gvq = seg ? ev.gvarspk + (long long)k * ev.S + s0 : ev.gvarq + ((long long)r * K + k) * Q;
-    const double* tqr = seg ? ev.spk_t + s0 : ev.tq + (long long)r * Q;
-
-    const int ntiles = (Qs + 15) >> 4;
-    // inputs of the NEXT tile are fetched one iteration ahead (global latency hidden behind the MFMA chain)
-    double tq_n = 0.0, gm_n = 0.0, gv_n = 0.0;
-    if (wave < ntiles) {
-      const int nn = 16 * wave + li;
-      tq_n = tqr[(nn < Qs) ? nn : 0];
-      gm_n = (nn < Qs) ? gmq[nn] : 0.0;
-      gv_n = (nn < Qs) ? gvq[nn] : 0.0;
-    }
-    for (int tile = wave; tile < ntiles; tile += NWB) {
-      const double tq = tq_n, gm = gm_n, gvv = gv_n;
-      if (tile + NWB < ntiles) {
-        const int nn = 16 * (tile + NWB) + li;
-        tq_n = tqr[(nn < Qs) ? nn : 0];
-        gm_n = (nn < Qs) ? gmq[nn] : 0.0;
-        gv_n = (nn < Qs) ? gvq[nn] : 0.0;
+      const long long s0 = seg ? ev.spk_off[r] : 0;
+      const int Qs = seg ? (int)(ev.spk_off[r + 1] - s0) : Q;
+      const double* gmq = seg ? ev.gmuspk + (long long)k * ev.S + s0 : ev.gmuq + ((long long)r * K + k) * Q;
+      const double* gvq = seg ? ev.gvarspk + (long long)k * ev.S + s0 : ev.gvarq + ((long long)r * K + k) * Q;
+      const double* tqr = seg ? ev.spk_t + s0 : ev.tq + (long long)r * Q;
+      const int ntiles = (Qs + 15) >> 4;
+      if (ntiles == 0) continue;       // (block-uniform)
+      const int nsteps = (ntiles + G - 1) / G;
+      // A team without a tile in the last step repeats the segment's last tile with zero adjoints (adds exact zeros):
+      // no wave-uniform branch around the register-heavy step, and every wave meets every barrier.
+      // Inputs of the NEXT tile are fetched one step ahead (global latency hidden behind the MFMA chains).
+      double tq_n, gm_n, gv_n;
+      {
+        const bool live = team < ntiles;
+        const int nn = 16 * (live ? team : ntiles - 1) + li, ni = (nn < Qs) ? nn : 0;
+        const bool ok = live && nn < Qs;
+        tq_n = tqr[ni];
+        const double x = gmq[ni], y = gvq[ni];
+        gm_n = ok ? x : 0.0;
+        gv_n = ok ? y : 0.0;
       }
-      if (tile == wave) SV_CK(4);
-      double stq = 0.0, ctq = 0.0;
-      if (KT == SV_PERIODIC) sv_sincos_quarter(tq * p.q4, stq, ctq);
-      int jo = lg;
-      asm volatile("" : "+v"(jo));
-      d4 X0[NT];
-      d4 csv[(KT == SV_PERIODIC && FULL) ? NT : 1];      // cos of the pair's phase, kept for the adjoint (FULL; round 4: 16 registers
-                                                          // the kernel has to spare since phase 1 lost its transposes, two FMAs per pair)
-#pragma unroll
-      for (int a = 0; a < NT; ++a)
+      // state of the step in flight (stage1 -> stage2 -> stage3)
+      double tq = 0.0, gm = 0.0, gvv = 0.0, stq = 0.0, ctq = 0.0;
+      d4 X0 = {0.0, 0.0, 0.0, 0.0}, csv = {0.0, 0.0, 0.0, 0.0}, gK = {0.0, 0.0, 0.0, 0.0};
+      double gm4[4], gv4[4];
+      // ---- (1) the raw kernel tile of this wave's panel: lane = node li, registers = inducing points jb + 4 q.
+      // periodic: kappa and its derivative bases follow from the node's own sin / cos and the inducing points'
+      // (szl, czl) by angle addition (no per-pair sincos, no second exp)
+      auto stage1 = [&](const int s) {
+        const int tile = s * G + team;
+        const bool live = tile < ntiles;
+        const int tc = live ? tile : ntiles - 1;
+        tq = tq_n;
+        gm = gm_n;
+        gvv = gv_n;
+        if (s + 1 < nsteps) {
+          const bool live2 = tile + G < ntiles;
+          const int nn = 16 * (live2 ? tile + G : ntiles - 1) + li, ni = (nn < Qs) ? nn : 0;
+          const bool ok = live2 && nn < Qs;
+          tq_n = tqr[ni];
+          const double x = gmq[ni], y = gvq[ni];
+          gm_n = ok ? x : 0.0;
+          gv_n = ok ? y : 0.0;
+        }
+        if (KT == SV_PERIODIC) SV_BWD_SINCOS(tq * p.q4, stq, ctq);
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-          const int j = 16 * a + 4 * q + jo;
+          const int j = jb + 4 * q;
           if (KT == SV_RBF) {
             const double dd = tq - zl[j];
-            X0[a][q] = p.s2 * sv_exp2_neg(-(dd * dd) * p.h2);
+            X0[q] = p.s2 * SV_BWD_EXP2(-(dd * dd) * p.h2);
           } else {
             const double cs = fma(stq, szl[j], ctq * czl[j]);
-            if (FULL) csv[a][q] = cs;
-            X0[a][q] = p.s2 * sv_exp2_neg(fma(cs, p.h2, -p.h2));
+            csv[q] = cs;
+            X0[q] = p.s2 * SV_BWD_EXP2(fma(cs, p.h2, -p.h2));
           }
         }
-      // adjoints of the four nodes lg + 4 q of this tile: what this lane's registers of the TRANSPOSED whitened tile
-      // below belong to (L1 / L2 hits: the tile's 16 values are one 128-byte line, fetched by the prefetch above)
-      double gm4[4], gv4[4];
+        double* xw = Xb + (DB ? (s & 1) * 2 * NT * 256 : 0) + c * 256 + lane;
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const int n4 = 16 * tile + lg + 4 * q;
-        gm4[q] = (n4 < Qs) ? gmq[n4] : 0.0;
-        gv4[q] = (n4 < Qs) ? gvq[n4] : 0.0;
-      }
-      if (tile == wave) SV_CK(5);
-      // Whitened tile TRANSPOSED: KwT[t][i] = sum_j kappa(t, z_j) Linv[i][j] -- the raw kernel tile is the A operand as it
-      // stands (lane = node, registers = inducing points), Linv's fragments the B operand; the accumulator then holds
-      // node lg + 4 q of inducing point 16 a + li, which is BOTH operand layouts of the contraction over the nodes
-      //     Gt += KwT^T diag(gv) KwT,
-      // so that product needs no transpose through LDS (round 3: 8 ds_write + 12 ds_read + two fences per tile, and the
-      // kernel's LDS bank conflicts).
-      d4 KwT[NT];
+        for (int q = 0; q < 4; ++q) xw[q * 64] = X0[q];
+        // adjoints of the four nodes lg + 4 q of this tile: what this lane's registers of the TRANSPOSED whitened tile
+        // belong to (L1 / L2 hits: the tile's 16 values are one 128-byte line, fetched by the prefetch above)
 #pragma unroll
-      for (int a = 0; a < NT; ++a) {
-        d4 acc = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-        for (int b = 0; b <= a; ++b)
-#pragma unroll
-          for (int q = 0; q < 4; ++q)
-            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(X0[b][q], lds_frag(&Li[(16 * a + li) * LD + 16 * b + 4 * q + lg]), acc, 0, 0, 0);
-        KwT[a] = acc;
-      }
-      if (tile == wave) SV_CK(6);
-      d4 Gk[NT];
-      if (FULL) {
-#pragma unroll
-        for (int a = 0; a < NT; ++a) {
-          d4 acc = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-          for (int b = 0; b < NT; ++b)
-#pragma unroll
-            for (int q = 0; q < 4; ++q)
-              acc = __builtin_amdgcn_mfma_f64_16x16x4f64(lds_frag(&Dl[(16 * a + li) * LD + 16 * b + 4 * q + lg]), X0[b][q], acc, 0, 0, 0);
-          Gk[a] = acc;                                            // E kappa(t, Z): independent of KwT
+        for (int q = 0; q < 4; ++q) {
+          const int n4 = 16 * tc + lg + 4 * q;
+          const bool ok = live && n4 < Qs;
+          const double x = gmq[ok ? n4 : 0], y = gvq[ok ? n4 : 0];
+          gm4[q] = ok ? x : 0.0;
+          gv4[q] = ok ? y : 0.0;
         }
-      }
-      {
-        d4 gK[NT];
+      };
+      // ---- (2) Gk_c = E[c, :] kappa (A: this wave's E panel, B: every panel's raw tile) and the whitened tile TRANSPOSED,
+      // KwT_c[t][i] = sum_j kappa(t, z_j) Linv[16 c + i][j] (A: the raw tiles b <= c as they stand, B: row block c of Linv):
+      // the accumulator holds node lg + 4 q of inducing point 16 c + li, which is BOTH operand layouts of the
+      // contraction over the nodes Gt += KwT^T diag(gv) KwT -- no transpose anywhere
+      auto stage2 = [&](const int s) {
+        const double* xr = Xb + (DB ? (s & 1) * 2 * NT * 256 : 0) + lane;
+        d4 Gk = {0.0, 0.0, 0.0, 0.0}, KwT = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-        for (int a = 0; a < NT; ++a)
+        for (int b = 0; b < NT; ++b) {
+          d4 xb;
+#pragma unroll
+          for (int q = 0; q < 4; ++q) xb[q] = xr[b * 256 + q * 64];
+          if (FULL) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) Gk = __builtin_amdgcn_mfma_f64_16x16x4f64(Ep[b][q], xb[q], Gk, 0, 0, 0);
+          }
+          if (b <= c) {
+            const double* lt = Li + (c * (c + 1) / 2 + b) * TSZ + orm;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) KwT = __builtin_amdgcn_mfma_f64_16x16x4f64(xb[q], lds_frag(lt + 4 * q), KwT, 0, 0, 0);
+          }
+        }
+        double* kw = Kb + (DB ? (s & 1) * 2 * NT * 256 : 0) + c * 256 + lane;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) kw[q * 64] = KwT[q];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          gu = fma(gm4[q], KwT[q], gu);
+          gK[q] = gv4[q] * KwT[q];
+        }
+        if (FULL) {
+          // adjoint sums of this wave's inducing points (the raw tile and E kappa are complete; nothing here waits for
+          // the other waves, so it sits in front of the barrier)
 #pragma unroll
           for (int q = 0; q < 4; ++q) {
-            gu[a] = fma(gm4[q], KwT[a][q], gu[a]);
-            gK[a][q] = gv4[q] * KwT[a][q];
-          }
-        int t = 0;
-#pragma unroll
-        for (int a = 0; a < NT; ++a)
-#pragma unroll
-          for (int b = 0; b <= a; ++b) {
-#pragma unroll
-            for (int q = 0; q < 4; ++q) GW[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(KwT[a][q], gK[b][q], GW[t], 0, 0, 0);
-            ++t;
-          }
-      }
-      if (tile == wave) SV_CK(7);
-      if (FULL) {
-#pragma unroll
-        for (int a = 0; a < NT; ++a)
-#pragma unroll
-          for (int q = 0; q < 4; ++q) Gk[a][q] = fma(2.0 * gvv, Gk[a][q], gm * al[16 * a + 4 * q + jo]);
-        asm volatile("" : "+v"(jo));
-#pragma unroll
-        for (int a = 0; a < NT; ++a)
-#pragma unroll
-          for (int q = 0; q < 4; ++q) {
-            const int j = 16 * a + 4 * q + jo;
-            const double gkk = Gk[a][q] * X0[a][q];               // gk * kappa: the factor 1 / s2 (kappa -> ktil) goes onto the sums
+            const int j = jb + 4 * q;
+            const double gk = fma(2.0 * gvv, Gk[q], gm * al[j]);
+            const double gkk = gk * X0[q];                        // gk * kappa: the factor 1 / s2 (kappa -> ktil) goes onto the sums
             const double dd = tq - zl[j];
             if (KT == SV_RBF) {
               const double gd = gkk * dd;
-              dz[a][q] += gd;                                    // bz = delta
-              th0 = fma(gd, dd, th0);                            // b0 = delta^2
+              dz[q] += gd;                                        // bz = delta
+              th0 = fma(gd, dd, th0);                             // b0 = delta^2
             } else {
-              const double cs = csv[a][q];
+              const double cs = csv[q];
               const double sn = fma(stq, czl[j], -(ctq * szl[j]));
               const double gsn = gkk * sn;
-              dz[a][q] += gsn;                                   // bz = sin(2 pi delta / p)
-              th0 = fma(gkk, 0.5 - 0.5 * cs, th0);               // b0 = sin^2(pi delta / p)
-              th1 = fma(gsn, dd, th1);                           // b1 = delta sin(2 pi delta / p)
+              dz[q] += gsn;                                       // bz = sin(2 pi delta / p)
+              th0 = fma(gkk, 0.5 - 0.5 * cs, th0);                // b0 = sin^2(pi delta / p)
+              th1 = fma(gsn, dd, th1);                            // b1 = delta sin(2 pi delta / p)
             }
           }
+        }
+      };
+      // ---- (3) column c of Gt: tiles (a, c), a >= c: A = KwT_a (from its owner), B = diag(gv) KwT_c (own)
+      auto stage3 = [&](const int s) {
+        const double* kr = Kb + (DB ? (s & 1) * 2 * NT * 256 : 0) + lane;
+#pragma unroll
+        for (int a = 0; a < NT; ++a) {
+          if (a >= c) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+              GW[a] = __builtin_amdgcn_mfma_f64_16x16x4f64(kr[a * 256 + q * 64], gK[q], GW[a], 0, 0, 0);
+          }
+        }
+      };
+      if (DB) {
+        // one barrier per node tile: the exchange tiles alternate between two buffers, and the next tile's kernel values
+        // are computed in front of the barrier that publishes this tile's whitened values
+        stage1(0);
+        __syncthreads();
+        for (int s = 0; s < nsteps; ++s) {
+          stage2(s);
+          if (s + 1 < nsteps) stage1(s + 1);
+          __syncthreads();
+          stage3(s);
+        }
+      } else {
+        for (int s = 0; s < nsteps; ++s) {
+          stage1(s);
+          __syncthreads();
+          stage2(s);
+          __syncthreads();
+          stage3(s);
+        }
       }
-      if (tile == wave) SV_CK(8);
-    }
     }   // node segments
     SV_CK(9);
-    // ---- reductions: gu over the four node groups (lg), dz over the 16 node lanes; then over the wavefronts (fixed order)
-#pragma unroll
-    for (int a = 0; a < NT; ++a) {
-      const double g = grp4_sum(gu[a]);
-      if (lg == 0) Sw[16 * a + li] = g;
+    // ---- reductions: gu over the four node groups (lg), dz over the 16 node lanes; then over the teams (fixed order)
+    {
+      double* Sw = wpart + team * 2 * MP;
+      const double g = grp4_sum(gu);
+      if (lg == 0) Sw[16 * c + li] = g;
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
-        const double z = FULL ? row16_sum(dz[a][q]) : 0.0;
-        if (li == 0) Sw[MP + 16 * a + 4 * q + lg] = z;
+        const double z = FULL ? row16_sum(dz[q]) : 0.0;
+        if (li == 0) Sw[MP + jb + 4 * q] = z;
       }
     }
     th0 = wave_sum(th0);
@@ -657,35 +808,30 @@ __device__ __forceinline__ void item_bwd_body(const EngineView& ev, const int r,
       tred[wave * 2 + 0] = th0;
       tred[wave * 2 + 1] = th1;
     }
-    // Gt: the waves' accumulator tiles added in wave order into the (idle) scratch region, both triangles (tile (a, b),
-    // a > b, is mirrored into (b, a)), rows padded to LD; wave 0 writes ahead of the barrier.  Gt's padding rows / columns
-    // are exact zeros: sums of products with zero-padded rows of Linv
-    auto gt_tiles = [&](const bool first) {
-      int t = 0;
+    __syncthreads();   // every wave is done with the exchange tiles: region X becomes Gt
+    // Gt: every tile on or below the diagonal has one owner per team; the teams' tiles are added in team order.  Gt's
+    // padding rows / columns are exact zeros: sums of products with zero-padded rows of Linv
+    for (int t = 0; t < G; ++t) {
+      if (team == t) {
 #pragma unroll
-      for (int a = 0; a < NT; ++a)
+        for (int a = 0; a < NT; ++a) {
+          if (a >= c) {
+            double* gtile = Gl + (a * (a + 1) / 2 + c) * TSZ + otr;       // element (16 a + lg + 4 q, 16 c + li)
 #pragma unroll
-        for (int b = 0; b <= a; ++b) {
-#pragma unroll
-          for (int q = 0; q < 4; ++q) {
-            const int row = 16 * a + lg + 4 * q, col = 16 * b + li;
-            const double v = first ? GW[t][q] : Gl[row * LD + col] + GW[t][q];
-            Gl[row * LD + col] = v;
-            if (a != b) Gl[col * LD + row] = v;
+            for (int q = 0; q < 4; ++q) gtile[4 * q * TS] = (t == 0) ? GW[a][q] : gtile[4 * q * TS] + GW[a][q];
           }
-          ++t;
         }
-    };
-    if (wave == 0) gt_tiles(true);
-    __syncthreads();   // all waves done with their tiles; wave 0's Gt tiles and every wave's partials are in LDS
-    if (tid < MP) {    // gu / dz: the waves' partials, in order
+      }
+      __syncthreads();
+    }
+    if (tid < MP) {    // gu / dz: the teams' partials, in order
       double g = 0.0, z = 0.0;
       if (tid < M) {
         g = wpart[tid];
-        for (int w = 1; w < NWB; ++w) g += wpart[w * 2 * MP + tid];
+        for (int w = 1; w < G; ++w) g += wpart[w * 2 * MP + tid];
         if (FULL) {
           z = wpart[MP + tid];
-          for (int w = 1; w < NWB; ++w) z += wpart[w * 2 * MP + MP + tid];
+          for (int w = 1; w < G; ++w) z += wpart[w * 2 * MP + MP + tid];
           z *= p.cz * inv_s2;
         }
       }
@@ -704,10 +850,6 @@ __device__ __forceinline__ void item_bwd_body(const EngineView& ev, const int r,
       }
       thq[0] = p.c0 * inv_s2 * t0s;
       thq[1] = p.c1 * inv_s2 * t1s;
-    }
-    for (int w = 1; w < NWB; ++w) {
-      if (wave == w) gt_tiles(false);
-      __syncthreads();
     }
   }
 
@@ -736,30 +878,32 @@ __device__ __forceinline__ void item_bwd_body(const EngineView& ev, const int r,
   {   // gt = gq + Linv gs
     double s = 0.0;
     if (mrow < M)
-      for (int q = msub; q <= mrow; q += LPR) s = fma(Li[mrow * LD + q], gs[q], s);
+      for (int q = msub; q <= mrow; q += LPR) s = fma(Li[sv_tp(mrow, q)], gs[q], s);
     for (int o = 1; o < LPR; o <<= 1) s += __shfl_xor(s, o, 64);
     if (msub == 0 && mrow < M) gt[mrow] = gq[mrow] + s;
   }
   __syncthreads();
 
-  const int c = wave;                     // panel index of this wavefront (waves >= NT idle through the panel work)
-  const bool pan = c < NT;
+  const bool pan = team == 0;             // the panel work of phase 2: wave c of the first team (the others idle through it)
   if (mask & 1u) {
     {   // dm = Linv^T (gt - ut)
       double s = 0.0;
       if (mrow < M)
-        for (int q = mrow + msub; q < M; q += LPR) s = fma(Li[q * LD + mrow], gt[q] - ul[q], s);
+        for (int q = mrow + msub; q < M; q += LPR) s = fma(Li[sv_tp(q, mrow)], gt[q] - ul[q], s);
       for (int o = 1; o < LPR; o <<= 1) s += __shfl_xor(s, o, 64);
       if (msub == 0 && mrow < M) pt.g_mean[(long long)r * M + mrow] = s;
     }
     if (pan) {
       // dL_S = tril(Linv^T (2 Gt - I) Vt) + diag(1 / L_S,ii): this wave's 16-column panel
       double* gcv = pt.g_cholvec + (long long)r * m.P;
-      d4 P[NT], X[NT];
+      d4 P[NT], Xm[NT];
 #pragma unroll
       for (int b = 0; b < NT; ++b)
 #pragma unroll
-        for (int q = 0; q < 4; ++q) P[b][q] = Vl[(16 * b + 4 * q + lg) * LD + 16 * c + li];
+        for (int q = 0; q < 4; ++q) {
+          const double v = Vl[((b >= c) ? (b * (b + 1) / 2 + c) : 0) * TSZ + otr + 4 * q * TS];      // Vt[:, panel c]
+          P[b][q] = (b >= c) ? v : 0.0;
+        }
 #pragma unroll
       for (int a = 0; a < NT; ++a) {
         d4 acc = {0.0, 0.0, 0.0, 0.0};
@@ -769,14 +913,13 @@ __device__ __forceinline__ void item_bwd_body(const EngineView& ev, const int r,
             if (b >= c) {   // Vt lower triangular: panel c has zero tiles above the diagonal
 #pragma unroll
               for (int q = 0; q < 4; ++q) {
-                int row = 16 * a + li, col = 16 * b + 4 * q + lg;
-                double av = 2.0 * Gl[row * LD + col] - (row == col ? 1.0 : 0.0);
+                const double av = 2.0 * SV_SYMFRAG(Gl, a, b, q) - ((a == b && li == 4 * q + lg) ? 1.0 : 0.0);
                 acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, P[b][q], acc, 0, 0, 0);
               }
             }
           }
         }
-        X[a] = acc;
+        Xm[a] = acc;
       }
 #pragma unroll
       for (int a = 0; a < NT; ++a) {
@@ -786,7 +929,7 @@ __device__ __forceinline__ void item_bwd_body(const EngineView& ev, const int r,
           for (int b = a; b < NT; ++b)
 #pragma unroll
             for (int q = 0; q < 4; ++q)
-              acc = __builtin_amdgcn_mfma_f64_16x16x4f64(Li[(16 * b + 4 * q + lg) * LD + 16 * a + li], X[b][q], acc, 0, 0, 0);
+              acc = __builtin_amdgcn_mfma_f64_16x16x4f64(lds_frag(&Li[sv_tidx(b, a) * TSZ + otr + 4 * q * TS]), Xm[b][q], acc, 0, 0, 0);
 #pragma unroll
           for (int q = 0; q < 4; ++q) {
             int i = 16 * a + 4 * q + lg, j = 16 * c + li;
@@ -810,37 +953,50 @@ __device__ __forceinline__ void item_bwd_body(const EngineView& ev, const int r,
 #pragma unroll
     for (int b = 0; b < NT; ++b)
 #pragma unroll
-      for (int q = 0; q < 4; ++q) P[b][q] = Gl[(16 * b + 4 * q + lg) * LD + 16 * c + li];
-    tri_chain<NT, 1>(Bm, Vl, LD, P, li, lg);
-    tri_chain<NT, 0>(Cm, Vl, LD, Bm, li, lg);
+      for (int q = 0; q < 4; ++q)      // Gt[:, panel c] (symmetric: tile (b, c) transposed-read, or tile (c, b) row-major)
+        P[b][q] = Gl[(b >= c) ? (b * (b + 1) / 2 + c) * TSZ + otr + 4 * q * TS : (c * (c + 1) / 2 + b) * TSZ + orm + 4 * q];
+    tri_chain_tp<NT, 1>(Bm, Vl, P, orm, otr);
+    tri_chain_tp<NT, 0>(Cm, Vl, Bm, orm, otr);
 #pragma unroll
     for (int b = 0; b < NT; ++b)
 #pragma unroll
-      for (int q = 0; q < 4; ++q) P[b][q] = Vl[(16 * c + li) * LD + 16 * b + 4 * q + lg];   // Vt^T panel
-    tri_chain<NT, 0>(VV, Vl, LD, P, li, lg);
+      for (int q = 0; q < 4; ++q) {      // Vt^T panel: Vt[16 c + li][16 b + 4 q + lg], b <= c
+        const double v = Vl[((b <= c) ? (c * (c + 1) / 2 + b) : 0) * TSZ + orm + 4 * q];
+        P[b][q] = (b <= c) ? v : 0.0;
+      }
+    tri_chain_tp<NT, 0>(VV, Vl, P, orm, otr);
   }
   __syncthreads();
+  // At needs C + C^T: the tiles of C on and above the diagonal go through LDS (Vt's place, Vt is dead): tile (a, c), a <= c,
+  // of this wave's panel row-major into slot (c, a); its reader -- the owner of At's tile (c, a) -- reads it transposed
   double* Cs = Vl;
   if (pan) {
 #pragma unroll
-    for (int a = 0; a < NT; ++a)
+    for (int a = 0; a < NT; ++a) {
+      if (a <= c) {
 #pragma unroll
-      for (int q = 0; q < 4; ++q) Cs[(16 * a + 4 * q + lg) * LD + 16 * c + li] = Cm[a][q];
+        for (int q = 0; q < 4; ++q) Cs[(c * (c + 1) / 2 + a) * TSZ + otr + 4 * q * TS] = Cm[a][q];
+      }
+    }
   }
   __syncthreads();
   if (SV_BWD_STOP == 7) return;      // after C, Vt Vt^T
-  // ---- At (in place over Gt): each element is read and written by exactly one lane; the transposed reads of Gt
-  //      itself do not occur (only C is read transposed), so no wave sees a half-updated panel
+  // ---- At, tiles (a, c), a >= c, in place over Gt: each element is read and written by exactly one lane
   if (pan) {
 #pragma unroll
-    for (int a = 0; a < NT; ++a)
+    for (int a = 0; a < NT; ++a) {
+      if (a >= c) {
+        const int tb = (a * (a + 1) / 2 + c) * TSZ;
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        int i = 16 * a + 4 * q + lg, j = 16 * c + li;
-        double v = -0.5 * (gt[i] * ul[j] + ul[i] * gt[j]) + 0.5 * ul[i] * ul[j] + Gl[i * LD + j] +
-                   0.5 * (VV[a][q] - (i == j ? 1.0 : 0.0)) - Cs[i * LD + j] - Cs[j * LD + i];
-        Gl[i * LD + j] = v;
+        for (int q = 0; q < 4; ++q) {
+          const int i = 16 * a + 4 * q + lg, j = 16 * c + li;
+          const double ct = Cs[tb + orm + 4 * q];                  // C[j][i]
+          const double v = -0.5 * (gt[i] * ul[j] + ul[i] * gt[j]) + 0.5 * ul[i] * ul[j] + Gl[tb + otr + 4 * q * TS] +
+                           0.5 * (VV[a][q] - (i == j ? 1.0 : 0.0)) - Cm[a][q] - ct;
+          Gl[tb + otr + 4 * q * TS] = v;
+        }
       }
+    }
   }
   __syncthreads();
   if (SV_BWD_STOP == 8) return;      // after At
@@ -850,7 +1006,10 @@ __device__ __forceinline__ void item_bwd_body(const EngineView& ev, const int r,
 #pragma unroll
     for (int b = 0; b < NT; ++b)
 #pragma unroll
-      for (int q = 0; q < 4; ++q) P[b][q] = Li[(16 * b + 4 * q + lg) * LD + 16 * c + li];
+      for (int q = 0; q < 4; ++q) {
+        const double v = Li[((b >= c) ? (b * (b + 1) / 2 + c) : 0) * TSZ + otr + 4 * q * TS];
+        P[b][q] = (b >= c) ? v : 0.0;
+      }
 #pragma unroll
     for (int a = 0; a < NT; ++a) {
       d4 acc = {0.0, 0.0, 0.0, 0.0};
@@ -859,11 +1018,11 @@ __device__ __forceinline__ void item_bwd_body(const EngineView& ev, const int r,
         if (b >= c) {   // Linv lower triangular
 #pragma unroll
           for (int q = 0; q < 4; ++q)
-            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(Gl[(16 * a + li) * LD + 16 * b + 4 * q + lg], P[b][q], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(SV_SYMFRAG(Gl, a, b, q), P[b][q], acc, 0, 0, 0);
         }
       Dm[a] = acc;
     }
-    tri_chain<NT, 1>(Am, Li, LD, Dm, li, lg);
+    tri_chain_tp<NT, 1>(Am, Li, Dm, orm, otr);
     const double zc = zl[16 * c + li];
     const double szc = (KT == SV_PERIODIC) ? szl[16 * c + li] : 0.0, czc = (KT == SV_PERIODIC) ? czl[16 * c + li] : 0.0;
     double t0 = 0.0, t1 = 0.0;
@@ -931,16 +1090,14 @@ __device__ __forceinline__ void item_bwd_body(const EngineView& ev, const int r,
   }
 }
 
-// grid = R*K blocks of 64 NWB threads (NWB = 2 or 4 >= NT); FULL = gradients wrt Z / theta wanted (mask & 12).
-// M > 32 (cfg5): one block per CU (115 / 151 KB of LDS), one wave per SIMD.  Eight waves per block were measured for the
-// value-only variant (it fits 256 registers): no gain -- 13 node tiles give the busiest SIMD four tiles either way, and the
-// item's serial sections (staging, cross-wave sums) overlap with nothing while a block is alone on its CU.
+// grid = R*K blocks of 64 NT G threads (G = 1, 2 or 4 teams of NT waves; the host picks G, sv_item_bwd_waves).
+// FULL = gradients wrt Z / theta wanted (mask & 12).  M > 32: 78 KB of LDS and <= 256 registers: two blocks per CU.
 #ifndef SV_BWD_WPE
-#define SV_BWD_WPE 2    // waves per SIMD the compiler must leave room for at M <= 32 (experiment builds: 3)
+#define SV_BWD_WPE 2    // waves per SIMD the compiler must leave room for (experiment builds: 3)
 #endif
 template <int NT, bool FULL>
-__global__ __launch_bounds__(256, (NT <= 2 ? SV_BWD_WPE : 1)) void k_item_bwd(EngineView ev, LatentPtrTable ptab, unsigned mask,
-                                                                     const double* C, const double* d, double* shared) {
+__global__ __launch_bounds__(256, SV_BWD_WPE) void k_item_bwd(EngineView ev, LatentPtrTable ptab, unsigned mask,
+                                                              const double* C, const double* d, double* shared) {
   extern __shared__ double sm[];
   const int r = blockIdx.x / ev.K, k = blockIdx.x % ev.K;
   if (ev.meta[k].ktype == SV_RBF)

@@ -34,10 +34,7 @@ struct svgpfa_engine {
   int ell_lc[2] = {0, 0};      // looped tiles resident in LDS per role (fewer than all: streamed in chunks)
   int ell_nw = 4;              // waves per block of the ELL kernels
   int times_nw = 4;            // waves per block of k_times_fwd (SVGPFA_TIMES_NW, up to SV_TIMES_MAXTH / 64)
-  int tile_nw = 4;             // waves per block of k_item_bwd: 2 when R K >= 512 and M <= 32 (13 tiles of Q = 200 split
-                               // 7 + 6 instead of 4 + 3 + 3 + 3, and four blocks instead of two per CU: cfg3 226 -> 203 us,
-                               // its 8-way shard 0.200 -> 0.186 ms per step), else 4 (shorter per-block latency).
-                               // k_times_fwd stays at 4 (2 measured slower: 107 vs 101 us)
+  int tile_nw = 4;             // waves per block of k_item_bwd = NT x teams (a multiple of NT, at most 4)
   long long totM = 0, totMM = 0, totTT = 0;  // R*sum M, R*sum M^2, R*sum M(M+1)/2
   bool have_quad = false, have_spikes = false, have_kernels = false, have_stats = false;
   bool aux_valid = false;   // Kzz / L buffers hold the matrices of the current kernel snapshot (getters only)
@@ -232,11 +229,13 @@ int svgpfa_create(const svgpfa_dims* d, int device, svgpfa_engine** out) {
   // but at ~165 VGPRs only 12 waves fit a CU, i.e. ONE such block instead of three: measured 152 us vs 128 us.
   e->ell_nw = 4;
   if (getenv("SVGPFA_ELL_NW")) e->ell_nw = std::min(8, std::max(1, atoi(getenv("SVGPFA_ELL_NW"))));
-  e->tile_nw = ((long long)v.R * v.K >= 512 && e->NT <= 2) ? 2 : 4;
+  // k_item_bwd: G teams of NT waves (kernels_item_bwd.h).  M <= 32: one team fills a large grid best (more blocks per CU),
+  // two or four teams shorten the chain of node tiles of a block on a grid that is one under-filled round anyway
+  e->tile_nw = (e->NT >= 3) ? e->NT : (((long long)v.R * v.K >= 512) ? 2 : 4);
   if (getenv("SVGPFA_TIMES_NW")) e->times_nw = std::min(SV_TIMES_MAXTH / 64, std::max(1, atoi(getenv("SVGPFA_TIMES_NW"))));
   if (getenv("SVGPFA_TILE_NW")) {
     const int nw = atoi(getenv("SVGPFA_TILE_NW"));
-    e->tile_nw = (nw >= 2 && nw <= 4 && nw >= e->NT) ? nw : 4;
+    if (nw >= 1 && nw <= 4 && nw % e->NT == 0) e->tile_nw = nw;
   }
   e->ell_lc[0] = qell_chunk(e, 0);
   e->ell_lc[1] = qell_chunk(e, 1);
@@ -314,8 +313,8 @@ int svgpfa_create(const svgpfa_dims* d, int device, svgpfa_engine** out) {
   DISPATCH_NT(e->NT, rc = allow_lds(e, (k_prep_mfma<NT_>), lds_prep_mfma(NT_));
               if (!rc) rc = allow_lds(e, (k_front<NT_>), sv_front_lds(NT_));
               if (!rc) rc = allow_lds(e, (k_times_fwd_mfma<NT_>), lds_times_mfma(NT_));
-              if (!rc) rc = allow_lds(e, (k_item_bwd<NT_, true>), lds_item_bwd(NT_, 4, true));
-              if (!rc) rc = allow_lds(e, (k_item_bwd<NT_, false>), lds_item_bwd(NT_, 4, false)));
+              if (!rc) rc = allow_lds(e, (k_item_bwd<NT_, true>), lds_item_bwd(NT_, e->tile_nw, true));
+              if (!rc) rc = allow_lds(e, (k_item_bwd<NT_, false>), lds_item_bwd(NT_, e->tile_nw, false)));
   if (rc) return rc;
   if (e->precision == SVGPFA_PRECISION_MIXED) {
     DISPATCH_KS(e->KKT, rc = allow_lds(e, (k_quad_ell_mfma<KS_, 0, float>), lds_qell_mfma(e, 0));
