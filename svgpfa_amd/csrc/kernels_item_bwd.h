@@ -49,9 +49,16 @@ __device__ __forceinline__ int sv_tp(int i, int j) { return sv_tidx(i >> 4, j >>
 #define SV_BWD_DB 1
 #endif
 __host__ __device__ constexpr bool sv_bwd_db(int NT) { return SV_BWD_DB && NT <= 2; }
+// Phase 1 as panel owners (teams of NT waves, item_bwd_body) from this many tiles per side on; below, a wave owns whole
+// node tiles (no exchange, no barrier inside the loop: with one or two panels the team would be one or two waves, and the
+// per-tile set-up -- node loads, the node's sincos -- would be repeated by every wave of the team)
+#ifndef SV_BWD_PO_MIN
+#define SV_BWD_PO_MIN 3
+#endif
+__host__ __device__ constexpr bool sv_bwd_po(int NT) { return NT >= SV_BWD_PO_MIN; }
 // transcendental kernels of the node-tile loop: polynomial coefficients in SGPR pairs (sv_math.h) or left to the compiler
 #ifndef SV_BWD_SC
-#define SV_BWD_SC 1
+#define SV_BWD_SC 0
 #endif
 #if SV_BWD_SC
 #define SV_BWD_EXP2 sv_exp2_neg_sc
@@ -67,20 +74,21 @@ __host__ __device__ constexpr bool sv_bwd_db(int NT) { return SV_BWD_DB && NT <=
 // scratch, the per-team exchange tiles of phase 1 (kernel tile X0 and whitened tile KwT: 2 NT register images of 256
 // doubles per team), then Gt / At of phase 2.  NT = 4, one team: 9 800 doubles = 78 KB, two blocks per CU.
 struct ItemBwdLayout {
-  size_t Li, Vl, X, ul, al, zl, gt, gs, gq, gzq, szl, czl, wpart, tred, redz, redt, thq, p1l, cvd, tpl, total;
+  size_t Li, Vl, X, El, ul, al, zl, gt, gs, gq, gzq, szl, czl, wpart, tred, redz, redt, thq, p1l, cvd, tpl, total;
 };
 __host__ __device__ constexpr ItemBwdLayout sv_item_bwd_layout(int NT, int NWB, bool full) {
   const size_t MP = 16 * NT, TM = (size_t)(NT * (NT + 1) / 2) * SV_TSZ;
+  const bool po = sv_bwd_po(NT);
   const size_t G = (NWB / NT) > 0 ? (size_t)(NWB / NT) : 1;
   size_t XS = TM;
-  if (XS < G * NT * (sv_bwd_db(NT) ? 4 : 2) * 256) XS = G * NT * (sv_bwd_db(NT) ? 4 : 2) * 256;
+  if (po && XS < G * NT * (sv_bwd_db(NT) ? 4 : 2) * 256) XS = G * NT * (sv_bwd_db(NT) ? 4 : 2) * 256;
   if (XS < SV_GATHER_SCR) XS = SV_GATHER_SCR;
-  (void)full;
   ItemBwdLayout o{};
   size_t p = 0;
   o.Li = p; p += TM;               // Linv
   o.Vl = p; p += TM;               // Vt; later the tiles of C on and above the diagonal
   o.X = p; p += XS;                // gather scratch; exchange tiles of phase 1; Gt, later At
+  o.El = p; p += (!po && full) ? TM : 0;   // whole-tile owners: E (symmetric, tile-packed); panel owners keep it in registers
   o.ul = p; p += MP;               // ut
   o.al = p; p += MP;               // a = Linv^T ut
   o.zl = p; p += MP;               // Z
@@ -90,7 +98,7 @@ __host__ __device__ constexpr ItemBwdLayout sv_item_bwd_layout(int NT, int NWB, 
   o.gzq = p; p += MP;              // quadrature part of dZ (direct)
   o.szl = p; p += MP;              // sin of the inducing-point phases (periodic)
   o.czl = p; p += MP;              // cos
-  o.wpart = p; p += G * 2 * MP;    // per-team partial sums of gu / dz behind the node tiles
+  o.wpart = p; p += (po ? G : (size_t)NWB) * 2 * MP;    // per-team (whole-tile owners: per-wave) partial sums of gu / dz
   o.tred = p; p += (size_t)NWB * 2;
   o.redz = p; p += (size_t)NT * MP;   // per-panel row sums of the dZ contraction
   o.redt = p; p += 2 * (size_t)NT;    // per-panel dtheta partials
@@ -528,7 +536,8 @@ template <int NT, int KT, bool FULL>
 __device__ __forceinline__ void item_bwd_body(const EngineView& ev, const int r, const int k, const LatentPtrs pt, unsigned mask,
                               double* sm) {
   constexpr int MP = 16 * NT, TS = SV_TS, TSZ = SV_TSZ;
-  constexpr bool DB = sv_bwd_db(NT);
+  constexpr bool DB = sv_bwd_db(NT), PO = sv_bwd_po(NT);
+  constexpr int NTRI = NT * (NT + 1) / 2;
   const int tid = threadIdx.x;
   const int lane = tid & 63, li = lane & 15, lg = lane >> 4;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -544,6 +553,7 @@ __device__ __forceinline__ void item_bwd_body(const EngineView& ev, const int r,
   double* Vl = sm + lay.Vl;
   double* X = sm + lay.X;
   double* Gl = X;                     // (symmetric, tile-packed: phase 2's Gt, later At)
+  double* El = sm + lay.El;
   double* ul = sm + lay.ul;
   double* al = sm + lay.al;
   double* zl = sm + lay.zl;
@@ -612,10 +622,228 @@ __device__ __forceinline__ void item_bwd_body(const EngineView& ev, const int r,
 #pragma unroll
         for (int q = 0; q < 4; ++q) T2[a][q] -= P[a][q];
       tri_chain_tp<NT, 1>(Ep, Li, T2, orm, otr);      // Linv^T (Vt Vt^T - I) Linv[:, c]
+      if (!PO) {                                      // whole-tile owners read E from LDS: the panel's tiles on and below the diagonal
+#pragma unroll
+        for (int a = 0; a < NT; ++a) {
+          if (a >= c) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) El[(a * (a + 1) / 2 + c) * TSZ + otr + 4 * q * TS] = Ep[a][q];
+          }
+        }
+      }
     }
     __syncthreads();                   // (the gather's scratch in region X is dead: the exchange tiles take its place)
     SV_CK(3);
     if (SV_BWD_STOP == 10) return;   // after the E panels
+    const double inv_s2 = 1.0 / p.s2;
+    const int nseg = (mask & SV_MASK_STATS) ? 2 : 1;
+    if constexpr (!PO) {
+    // ------------------------------------------------------------ whole-tile owners (M <= 32): wave w takes node tiles
+    // w, w + NWB, ...; all NT (NT + 1) / 2 accumulator tiles of Gt per wave, added over the waves behind the loop
+    d4 dz[NT], GW[NTRI];
+    double gu[NT];                      // lane (li, lg): partial of gu_{16 a + li} over the nodes lg + 4 q of every tile
+#pragma unroll
+    for (int a = 0; a < NT; ++a) {
+      gu[a] = 0.0;
+      dz[a] = (d4){0.0, 0.0, 0.0, 0.0};
+    }
+#pragma unroll
+    for (int t = 0; t < NTRI; ++t) GW[t] = (d4){0.0, 0.0, 0.0, 0.0};
+    double th0 = 0.0, th1 = 0.0;
+    double* Sw = wpart + wave * 2 * MP;    // this wave's partial sums of gu / dz (written behind its last tile)
+    for (int seg = 0; seg < nseg; ++seg) {
+      const long long s0 = seg ? ev.spk_off[r] : 0;
+      const int Qs = seg ? (int)(ev.spk_off[r + 1] - s0) : Q;
+      const double* gmq = seg ? ev.gmuspk + (long long)k * ev.S + s0 : ev.gmuq + ((long long)r * K + k) * Q;
+      const double* gvq = seg ? ev.gvarspk + (long long)k * ev.S + s0 : ev.gvarq + ((long long)r * K + k) * Q;
+      const double* tqr = seg ? ev.spk_t + s0 : ev.tq + (long long)r * Q;
+      const int ntiles = (Qs + 15) >> 4;
+      // inputs of the NEXT tile are fetched one iteration ahead (global latency hidden behind the MFMA chain)
+      double tq_n = 0.0, gm_n = 0.0, gv_n = 0.0;
+      if (wave < ntiles) {
+        const int nn = 16 * wave + li;
+        tq_n = tqr[(nn < Qs) ? nn : 0];
+        gm_n = (nn < Qs) ? gmq[nn] : 0.0;
+        gv_n = (nn < Qs) ? gvq[nn] : 0.0;
+      }
+      for (int tile = wave; tile < ntiles; tile += NWB) {
+        const double tq = tq_n, gm = gm_n, gvv = gv_n;
+        if (tile + NWB < ntiles) {
+          const int nn = 16 * (tile + NWB) + li;
+          tq_n = tqr[(nn < Qs) ? nn : 0];
+          gm_n = (nn < Qs) ? gmq[nn] : 0.0;
+          gv_n = (nn < Qs) ? gvq[nn] : 0.0;
+        }
+        double stq = 0.0, ctq = 0.0;
+        if (KT == SV_PERIODIC) SV_BWD_SINCOS(tq * p.q4, stq, ctq);
+        int jo = lg;
+        asm volatile("" : "+v"(jo));      // (opaque: keeps the per-j constants out of long-lived registers)
+        d4 X0[NT];
+        d4 csv[(KT == SV_PERIODIC && FULL) ? NT : 1];
+#pragma unroll
+        for (int a = 0; a < NT; ++a)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const int j = 16 * a + 4 * q + jo;
+            if (KT == SV_RBF) {
+              const double dd = tq - zl[j];
+              X0[a][q] = p.s2 * SV_BWD_EXP2(-(dd * dd) * p.h2);
+            } else {
+              const double cs = fma(stq, szl[j], ctq * czl[j]);
+              if (FULL) csv[a][q] = cs;
+              X0[a][q] = p.s2 * SV_BWD_EXP2(fma(cs, p.h2, -p.h2));
+            }
+          }
+        // adjoints of the four nodes lg + 4 q of this tile (L1 / L2 hits: one 128-byte line, fetched by the prefetch above)
+        double gm4[4], gv4[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int n4 = 16 * tile + lg + 4 * q;
+          gm4[q] = (n4 < Qs) ? gmq[n4] : 0.0;
+          gv4[q] = (n4 < Qs) ? gvq[n4] : 0.0;
+        }
+        // Whitened tile TRANSPOSED: KwT[t][i] = sum_j kappa(t, z_j) Linv[i][j] -- the raw kernel tile is the A operand as it
+        // stands, Linv's fragments the B operand; the accumulator holds node lg + 4 q of inducing point 16 a + li, which is
+        // BOTH operand layouts of the contraction over the nodes Gt += KwT^T diag(gv) KwT
+        d4 KwT[NT];
+#pragma unroll
+        for (int a = 0; a < NT; ++a) {
+          d4 acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+          for (int b = 0; b <= a; ++b)
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+              acc = __builtin_amdgcn_mfma_f64_16x16x4f64(X0[b][q], lds_frag(&Li[sv_tidx(a, b) * TSZ + orm + 4 * q]), acc, 0, 0, 0);
+          KwT[a] = acc;
+        }
+        d4 Gk[NT];
+        if (FULL) {
+#pragma unroll
+          for (int a = 0; a < NT; ++a) {
+            d4 acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int b = 0; b < NT; ++b)
+#pragma unroll
+              for (int q = 0; q < 4; ++q)
+                acc = __builtin_amdgcn_mfma_f64_16x16x4f64(SV_SYMFRAG(El, a, b, q), X0[b][q], acc, 0, 0, 0);
+            Gk[a] = acc;                                            // E kappa(t, Z): independent of KwT
+          }
+        }
+        {
+          d4 gK[NT];
+#pragma unroll
+          for (int a = 0; a < NT; ++a)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+              gu[a] = fma(gm4[q], KwT[a][q], gu[a]);
+              gK[a][q] = gv4[q] * KwT[a][q];
+            }
+          int t = 0;
+#pragma unroll
+          for (int a = 0; a < NT; ++a)
+#pragma unroll
+            for (int b = 0; b <= a; ++b) {
+#pragma unroll
+              for (int q = 0; q < 4; ++q) GW[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(KwT[a][q], gK[b][q], GW[t], 0, 0, 0);
+              ++t;
+            }
+        }
+        if (FULL) {
+#pragma unroll
+          for (int a = 0; a < NT; ++a)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) Gk[a][q] = fma(2.0 * gvv, Gk[a][q], gm * al[16 * a + 4 * q + jo]);
+          asm volatile("" : "+v"(jo));
+#pragma unroll
+          for (int a = 0; a < NT; ++a)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+              const int j = 16 * a + 4 * q + jo;
+              const double gkk = Gk[a][q] * X0[a][q];               // gk * kappa: the factor 1 / s2 (kappa -> ktil) goes onto the sums
+              const double dd = tq - zl[j];
+              if (KT == SV_RBF) {
+                const double gd = gkk * dd;
+                dz[a][q] += gd;                                    // bz = delta
+                th0 = fma(gd, dd, th0);                            // b0 = delta^2
+              } else {
+                const double cs = csv[a][q];
+                const double sn = fma(stq, czl[j], -(ctq * szl[j]));
+                const double gsn = gkk * sn;
+                dz[a][q] += gsn;                                   // bz = sin(2 pi delta / p)
+                th0 = fma(gkk, 0.5 - 0.5 * cs, th0);               // b0 = sin^2(pi delta / p)
+                th1 = fma(gsn, dd, th1);                           // b1 = delta sin(2 pi delta / p)
+              }
+            }
+        }
+      }
+    }   // node segments
+    SV_CK(9);
+    // ---- reductions: gu over the four node groups (lg), dz over the 16 node lanes; then over the wavefronts (fixed order)
+#pragma unroll
+    for (int a = 0; a < NT; ++a) {
+      const double g = grp4_sum(gu[a]);
+      if (lg == 0) Sw[16 * a + li] = g;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const double z = FULL ? row16_sum(dz[a][q]) : 0.0;
+        if (li == 0) Sw[MP + 16 * a + 4 * q + lg] = z;
+      }
+    }
+    th0 = wave_sum(th0);
+    th1 = wave_sum(th1);
+    if (lane == 0) {
+      tred[wave * 2 + 0] = th0;
+      tred[wave * 2 + 1] = th1;
+    }
+    // Gt: the waves' accumulator tiles added in wave order into region X (the gather's scratch is dead since the barrier
+    // behind the E panels); wave 0 writes ahead of the barrier
+    auto gt_tiles = [&](const bool first) {
+      int t = 0;
+#pragma unroll
+      for (int a = 0; a < NT; ++a)
+#pragma unroll
+        for (int b = 0; b <= a; ++b) {
+          double* gtile = Gl + sv_tidx(a, b) * TSZ + otr;          // element (16 a + lg + 4 q, 16 b + li)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) gtile[4 * q * TS] = first ? GW[t][q] : gtile[4 * q * TS] + GW[t][q];
+          ++t;
+        }
+    };
+    if (wave == 0) gt_tiles(true);
+    __syncthreads();   // all waves done with their tiles; wave 0's Gt tiles and every wave's partials are in LDS
+    if (tid < MP) {    // gu / dz: the waves' partials, in order
+      double g = 0.0, z = 0.0;
+      if (tid < M) {
+        g = wpart[tid];
+        for (int w = 1; w < NWB; ++w) g += wpart[w * 2 * MP + tid];
+        if (FULL) {
+          z = wpart[MP + tid];
+          for (int w = 1; w < NWB; ++w) z += wpart[w * 2 * MP + MP + tid];
+          z *= p.cz * inv_s2;
+        }
+      }
+      gq[tid] = g;
+      gzq[tid] = z;
+    }
+    if (tid == 0) {
+      double t0s = 0.0, t1s = 0.0;
+      if (FULL) {
+        t0s = tred[0];
+        t1s = tred[1];
+        for (int w = 1; w < NWB; ++w) {
+          t0s += tred[2 * w];
+          t1s += tred[2 * w + 1];
+        }
+      }
+      thq[0] = p.c0 * inv_s2 * t0s;
+      thq[1] = p.c1 * inv_s2 * t1s;
+    }
+    for (int w = 1; w < NWB; ++w) {
+      if (wave == w) gt_tiles(false);
+      __syncthreads();
+    }
+    } else {
+    // ------------------------------------------------------------ panel owners (M > 32)
     d4 GW[NT];                          // column c of Gt: tile (a, c), a >= c
     d4 dz = {0.0, 0.0, 0.0, 0.0};       // lane (li, lg): partial of dz_{16 c + 4 q + lg} over the nodes li of every tile
     double gu = 0.0;                    // partial of gu_{16 c + li} over the nodes lg + 4 q of every tile
@@ -625,12 +853,10 @@ __device__ __forceinline__ void item_bwd_body(const EngineView& ev, const int r,
     double* Xb = X + (size_t)team * (DB ? 4 : 2) * NT * 256;     // this team's raw kernel tiles: register image of panel b at [b][q][lane]
     double* Kb = Xb + NT * 256;                                  // ... whitened tiles (DB: the second pair of buffers behind them)
     const int jb = 16 * c + lg;                       // this lane's inducing points: jb + 4 q
-    const double inv_s2 = 1.0 / p.s2;
     // Node lists of the item.  Segment 0: the trial's Q quadrature nodes with the adjoints the ELL kernel left in
     // [r][k][q] (contiguous for this item).  Segment 1 (statistics mode only, mask bit SV_MASK_STATS): the trial's spike
     // times with caller-given adjoints of the posterior mean / variance at the spikes, [k][S] -- the general form of the
     // spike term's backward, for likelihoods whose spike adjoint is not known a priori (svgpfa_latent_stats_backward).
-    const int nseg = (mask & SV_MASK_STATS) ? 2 : 1;
     for (int seg = 0; seg < nseg; ++seg) {
       const long long s0 = seg ? ev.spk_off[r] : 0;
       const int Qs = seg ? (int)(ev.spk_off[r + 1] - s0) : Q;
@@ -851,6 +1077,7 @@ __device__ __forceinline__ void item_bwd_body(const EngineView& ev, const int r,
       thq[0] = p.c0 * inv_s2 * t0s;
       thq[1] = p.c1 * inv_s2 * t1s;
     }
+    }   // whole-tile / panel owners
   }
 
   SV_CK(10);
