@@ -68,13 +68,18 @@ __host__ __device__ constexpr bool sv_bwd_po(int NT) { return NT >= SV_BWD_PO_MI
 #define SV_BWD_SINCOS sv_sincos_quarter
 #endif
 
+// Nodes of an item's list staged in LDS at a time (times + the two adjoints, 24 bytes per node): the tile loops read them
+// with immediate offsets instead of eleven predicated global loads, their 64-bit address arithmetic and their selects per
+// tile and wave.  256 covers the quadrature nodes of every BASELINE config in one chunk; M = 64 has 3 KB to spare.
+__host__ __device__ constexpr int sv_bwd_qc(int NT) { return NT >= 4 ? 128 : 256; }
+
 // LDS layout of one block (offsets in doubles) -- ONE constexpr function shared by the kernel (which places its buffers with
 // it) and the host (which sizes the launch with it), so the two cannot disagree.  A block is G = NWB / NT teams of NT
 // waves; wave c of a team owns column panel c of everything (see item_bwd_body).  Region X is, in turn: the gather's
 // scratch, the per-team exchange tiles of phase 1 (kernel tile X0 and whitened tile KwT: 2 NT register images of 256
 // doubles per team), then Gt / At of phase 2.  NT = 4, one team: 9 800 doubles = 78 KB, two blocks per CU.
 struct ItemBwdLayout {
-  size_t Li, Vl, X, El, ul, al, zl, gt, gs, gq, gzq, szl, czl, wpart, tred, redz, redt, thq, p1l, cvd, tpl, total;
+  size_t Li, Vl, X, El, tql, gml, gvl, ul, al, zl, gt, gs, gq, gzq, szl, czl, wpart, tred, redz, redt, thq, p1l, cvd, tpl, total;
 };
 __host__ __device__ constexpr ItemBwdLayout sv_item_bwd_layout(int NT, int NWB, bool full) {
   const size_t MP = 16 * NT, TM = (size_t)(NT * (NT + 1) / 2) * SV_TSZ;
@@ -89,6 +94,10 @@ __host__ __device__ constexpr ItemBwdLayout sv_item_bwd_layout(int NT, int NWB, 
   o.Vl = p; p += TM;               // Vt; later the tiles of C on and above the diagonal
   o.X = p; p += XS;                // gather scratch; exchange tiles of phase 1; Gt, later At
   o.El = p; p += (!po && full) ? TM : 0;   // whole-tile owners: E (symmetric, tile-packed); panel owners keep it in registers
+  const size_t QP = sv_bwd_qc(NT) + (po ? 16 * (G - 1) : 0);   // (panel owners pad a chunk to a whole step of the G teams)
+  o.tql = p; p += QP;              // the node chunk in flight: times and the two adjoints, padded to whole tiles
+  o.gml = p; p += QP;
+  o.gvl = p; p += QP;
   o.ul = p; p += MP;               // ut
   o.al = p; p += MP;               // a = Linv^T ut
   o.zl = p; p += MP;               // Z
@@ -532,6 +541,21 @@ __device__ __forceinline__ void load_factors_tp(const EngineView& ev, const Late
   if (NT >= 3) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the DMA pieces have landed (a barrier follows in the caller)
 }
 
+// Nodes [n0, n0 + cnt) of a node list -> LDS, padded to a multiple of `quant` nodes: a padded node repeats the chunk's first
+// time with zero adjoints (it adds exact zeros to every sum).
+__device__ __forceinline__ void stage_nodes(double* tql, double* gml, double* gvl, const double* tqr, const double* gmq,
+                                            const double* gvq, int n0, int cnt, int quant, int tid, int nth) {
+  const int np = (cnt + quant - 1) / quant * quant;
+  for (int i = tid; i < np; i += nth) {
+    const bool ok = i < cnt;
+    const int src = n0 + (ok ? i : 0);
+    const double t = tqr[src], x = gmq[src], y = gvq[src];
+    tql[i] = t;
+    gml[i] = ok ? x : 0.0;
+    gvl[i] = ok ? y : 0.0;
+  }
+}
+
 template <int NT, int KT, bool FULL>
 __device__ __forceinline__ void item_bwd_body(const EngineView& ev, const int r, const int k, const LatentPtrs pt, unsigned mask,
                               double* sm) {
@@ -554,6 +578,11 @@ __device__ __forceinline__ void item_bwd_body(const EngineView& ev, const int r,
   double* X = sm + lay.X;
   double* Gl = X;                     // (symmetric, tile-packed: phase 2's Gt, later At)
   double* El = sm + lay.El;
+  double* tql = sm + lay.tql;
+  double* gml = sm + lay.gml;
+  double* gvl = sm + lay.gvl;
+  constexpr int QC = sv_bwd_qc(NT);
+  const int nquant = 16 * (PO ? G : 1);     // a chunk is padded to whole tiles (panel owners: to whole steps of the G teams)
   double* ul = sm + lay.ul;
   double* al = sm + lay.al;
   double* zl = sm + lay.zl;
@@ -581,6 +610,9 @@ __device__ __forceinline__ void item_bwd_body(const EngineView& ev, const int r,
 
   if (want_lat) {
     load_factors_tp<NT>(ev, m, r, Li, Vl, ul, zl);
+    // the first chunk of the quadrature nodes, requested with the factors (the barrier in front of phase 1 publishes it)
+    stage_nodes(tql, gml, gvl, ev.tq + (long long)r * Q, ev.gmuq + ((long long)r * K + k) * Q,
+                ev.gvarq + ((long long)r * K + k) * Q, 0, Q < QC ? Q : QC, nquant, tid, NTHB);
   } else if (tid < MP) {
     ul[tid] = 0.0;
     zl[tid] = 0.0;
@@ -657,23 +689,16 @@ __device__ __forceinline__ void item_bwd_body(const EngineView& ev, const int r,
       const double* gmq = seg ? ev.gmuspk + (long long)k * ev.S + s0 : ev.gmuq + ((long long)r * K + k) * Q;
       const double* gvq = seg ? ev.gvarspk + (long long)k * ev.S + s0 : ev.gvarq + ((long long)r * K + k) * Q;
       const double* tqr = seg ? ev.spk_t + s0 : ev.tq + (long long)r * Q;
-      const int ntiles = (Qs + 15) >> 4;
-      // inputs of the NEXT tile are fetched one iteration ahead (global latency hidden behind the MFMA chain)
-      double tq_n = 0.0, gm_n = 0.0, gv_n = 0.0;
-      if (wave < ntiles) {
-        const int nn = 16 * wave + li;
-        tq_n = tqr[(nn < Qs) ? nn : 0];
-        gm_n = (nn < Qs) ? gmq[nn] : 0.0;
-        gv_n = (nn < Qs) ? gvq[nn] : 0.0;
+      for (int n0 = 0; n0 < Qs; n0 += QC) {      // chunks of the node list (block-uniform)
+      const int cnt = (Qs - n0 < QC) ? Qs - n0 : QC;
+      if (seg | n0) {                            // (the first chunk of the quadrature nodes was staged at the top)
+        __syncthreads();
+        stage_nodes(tql, gml, gvl, tqr, gmq, gvq, n0, cnt, nquant, tid, NTHB);
+        __syncthreads();
       }
+      const int ntiles = (cnt + 15) >> 4;
       for (int tile = wave; tile < ntiles; tile += NWB) {
-        const double tq = tq_n, gm = gm_n, gvv = gv_n;
-        if (tile + NWB < ntiles) {
-          const int nn = 16 * (tile + NWB) + li;
-          tq_n = tqr[(nn < Qs) ? nn : 0];
-          gm_n = (nn < Qs) ? gmq[nn] : 0.0;
-          gv_n = (nn < Qs) ? gvq[nn] : 0.0;
-        }
+        const double tq = tql[16 * tile + li], gm = gml[16 * tile + li], gvv = gvl[16 * tile + li];
         double stq = 0.0, ctq = 0.0;
         if (KT == SV_PERIODIC) SV_BWD_SINCOS(tq * p.q4, stq, ctq);
         int jo = lg;
@@ -694,13 +719,12 @@ __device__ __forceinline__ void item_bwd_body(const EngineView& ev, const int r,
               X0[a][q] = p.s2 * SV_BWD_EXP2(fma(cs, p.h2, -p.h2));
             }
           }
-        // adjoints of the four nodes lg + 4 q of this tile (L1 / L2 hits: one 128-byte line, fetched by the prefetch above)
+        // adjoints of the four nodes lg + 4 q of this tile
         double gm4[4], gv4[4];
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-          const int n4 = 16 * tile + lg + 4 * q;
-          gm4[q] = (n4 < Qs) ? gmq[n4] : 0.0;
-          gv4[q] = (n4 < Qs) ? gvq[n4] : 0.0;
+          gm4[q] = gml[16 * tile + lg + 4 * q];
+          gv4[q] = gvl[16 * tile + lg + 4 * q];
         }
         // Whitened tile TRANSPOSED: KwT[t][i] = sum_j kappa(t, z_j) Linv[i][j] -- the raw kernel tile is the A operand as it
         // stands, Linv's fragments the B operand; the accumulator holds node lg + 4 q of inducing point 16 a + li, which is
@@ -776,6 +800,7 @@ __device__ __forceinline__ void item_bwd_body(const EngineView& ev, const int r,
             }
         }
       }
+      }   // chunks
     }   // node segments
     SV_CK(9);
     // ---- reductions: gu over the four node groups (lg), dz over the 16 node lanes; then over the wavefronts (fixed order)
@@ -863,22 +888,16 @@ __device__ __forceinline__ void item_bwd_body(const EngineView& ev, const int r,
       const double* gmq = seg ? ev.gmuspk + (long long)k * ev.S + s0 : ev.gmuq + ((long long)r * K + k) * Q;
       const double* gvq = seg ? ev.gvarspk + (long long)k * ev.S + s0 : ev.gvarq + ((long long)r * K + k) * Q;
       const double* tqr = seg ? ev.spk_t + s0 : ev.tq + (long long)r * Q;
-      const int ntiles = (Qs + 15) >> 4;
-      if (ntiles == 0) continue;       // (block-uniform)
-      const int nsteps = (ntiles + G - 1) / G;
-      // A team without a tile in the last step repeats the segment's last tile with zero adjoints (adds exact zeros):
-      // no wave-uniform branch around the register-heavy step, and every wave meets every barrier.
-      // Inputs of the NEXT tile are fetched one step ahead (global latency hidden behind the MFMA chains).
-      double tq_n, gm_n, gv_n;
-      {
-        const bool live = team < ntiles;
-        const int nn = 16 * (live ? team : ntiles - 1) + li, ni = (nn < Qs) ? nn : 0;
-        const bool ok = live && nn < Qs;
-        tq_n = tqr[ni];
-        const double x = gmq[ni], y = gvq[ni];
-        gm_n = ok ? x : 0.0;
-        gv_n = ok ? y : 0.0;
+      for (int n0 = 0; n0 < Qs; n0 += QC) {      // chunks of the node list (block-uniform)
+      const int cnt = (Qs - n0 < QC) ? Qs - n0 : QC;
+      if (seg | n0) {                            // (the first chunk of the quadrature nodes was staged at the top)
+        __syncthreads();
+        stage_nodes(tql, gml, gvl, tqr, gmq, gvq, n0, cnt, nquant, tid, NTHB);
+        __syncthreads();
       }
+      // A team without a tile in the chunk's last step works on padding: nodes with zero adjoints (stage_nodes) that add
+      // exact zeros -- no wave-uniform branch around the register-heavy step, and every wave meets every barrier.
+      const int nsteps = (cnt + nquant - 1) / nquant;
       // state of the step in flight (stage1 -> stage2 -> stage3)
       double tq = 0.0, gm = 0.0, gvv = 0.0, stq = 0.0, ctq = 0.0;
       d4 X0 = {0.0, 0.0, 0.0, 0.0}, csv = {0.0, 0.0, 0.0, 0.0}, gK = {0.0, 0.0, 0.0, 0.0};
@@ -888,20 +907,9 @@ __device__ __forceinline__ void item_bwd_body(const EngineView& ev, const int r,
       // (szl, czl) by angle addition (no per-pair sincos, no second exp)
       auto stage1 = [&](const int s) {
         const int tile = s * G + team;
-        const bool live = tile < ntiles;
-        const int tc = live ? tile : ntiles - 1;
-        tq = tq_n;
-        gm = gm_n;
-        gvv = gv_n;
-        if (s + 1 < nsteps) {
-          const bool live2 = tile + G < ntiles;
-          const int nn = 16 * (live2 ? tile + G : ntiles - 1) + li, ni = (nn < Qs) ? nn : 0;
-          const bool ok = live2 && nn < Qs;
-          tq_n = tqr[ni];
-          const double x = gmq[ni], y = gvq[ni];
-          gm_n = ok ? x : 0.0;
-          gv_n = ok ? y : 0.0;
-        }
+        tq = tql[16 * tile + li];
+        gm = gml[16 * tile + li];
+        gvv = gvl[16 * tile + li];
         if (KT == SV_PERIODIC) SV_BWD_SINCOS(tq * p.q4, stq, ctq);
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
@@ -919,14 +927,11 @@ __device__ __forceinline__ void item_bwd_body(const EngineView& ev, const int r,
 #pragma unroll
         for (int q = 0; q < 4; ++q) xw[q * 64] = X0[q];
         // adjoints of the four nodes lg + 4 q of this tile: what this lane's registers of the TRANSPOSED whitened tile
-        // belong to (L1 / L2 hits: the tile's 16 values are one 128-byte line, fetched by the prefetch above)
+        // belong to
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-          const int n4 = 16 * tc + lg + 4 * q;
-          const bool ok = live && n4 < Qs;
-          const double x = gmq[ok ? n4 : 0], y = gvq[ok ? n4 : 0];
-          gm4[q] = ok ? x : 0.0;
-          gv4[q] = ok ? y : 0.0;
+          gm4[q] = gml[16 * tile + lg + 4 * q];
+          gv4[q] = gvl[16 * tile + lg + 4 * q];
         }
       };
       // ---- (2) Gk_c = E[c, :] kappa (A: this wave's E panel, B: every panel's raw tile) and the whitened tile TRANSPOSED,
@@ -1015,6 +1020,7 @@ __device__ __forceinline__ void item_bwd_body(const EngineView& ev, const int r,
           stage3(s);
         }
       }
+      }   // chunks
     }   // node segments
     SV_CK(9);
     // ---- reductions: gu over the four node groups (lg), dz over the 16 node lanes; then over the teams (fixed order)
