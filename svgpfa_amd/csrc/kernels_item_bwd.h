@@ -901,7 +901,7 @@ __device__ __forceinline__ void item_bwd_body(const EngineView& ev, const int r,
       // state of the step in flight (stage1 -> stage2 -> stage3)
       double tq = 0.0, gm = 0.0, gvv = 0.0, stq = 0.0, ctq = 0.0;
       d4 X0 = {0.0, 0.0, 0.0, 0.0}, csv = {0.0, 0.0, 0.0, 0.0}, gK = {0.0, 0.0, 0.0, 0.0};
-      double gm4[4], gv4[4];
+      d4 gm4 = {0.0, 0.0, 0.0, 0.0}, gv4 = {0.0, 0.0, 0.0, 0.0};
       // ---- (1) the raw kernel tile of this wave's panel: lane = node li, registers = inducing points jb + 4 q.
       // periodic: kappa and its derivative bases follow from the node's own sin / cos and the inducing points'
       // (szl, czl) by angle addition (no per-pair sincos, no second exp)

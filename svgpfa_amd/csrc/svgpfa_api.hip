@@ -235,7 +235,7 @@ int svgpfa_create(const svgpfa_dims* d, int device, svgpfa_engine** out) {
   if (getenv("SVGPFA_TIMES_NW")) e->times_nw = std::min(SV_TIMES_MAXTH / 64, std::max(1, atoi(getenv("SVGPFA_TIMES_NW"))));
   if (getenv("SVGPFA_TILE_NW")) {
     const int nw = atoi(getenv("SVGPFA_TILE_NW"));
-    if (nw >= 1 && nw <= 4 && nw % e->NT == 0) e->tile_nw = nw;
+    if (nw >= 1 && nw <= 4 && (sv_bwd_po(e->NT) ? nw % e->NT == 0 : nw >= 2)) e->tile_nw = nw;
   }
   e->ell_lc[0] = qell_chunk(e, 0);
   e->ell_lc[1] = qell_chunk(e, 1);

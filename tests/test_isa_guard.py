@@ -92,6 +92,22 @@ def test_last_build_is_clean():
     assert ge.check_isa(files, require=True) == []
 
 
+def _scratch_instructions(ge, kernel):
+    """Number of scratch / private-segment memory instructions in `kernel`'s body in the device assembly build() kept."""
+    n = 0
+    for path in glob.glob(os.path.join(ge.BUILD_DIR, "*amdgcn*.s")):
+        inside = False
+        with open(path) as fh:
+            for line in fh:
+                if line.startswith(kernel + ":"):
+                    inside = True
+                elif inside and "s_endpgm" in line:
+                    return n
+                elif inside and line.lstrip().startswith(("scratch_", "buffer_load", "buffer_store")):
+                    n += 1
+    raise AssertionError("kernel %s not found in the kept assembly" % kernel)
+
+
 def test_no_scratch_outside_the_class_kernels():
     """Private (scratch) memory per kernel from the compiler's resource report of the last build.  Round 3 caught
     k_item_bwd<4, *> with 976 bytes per lane -- the whole EngineView argument copied to the stack because the compiler had
@@ -110,6 +126,10 @@ def test_no_scratch_outside_the_class_kernels():
     assert ru, "build() kept no resource report"
     cls = lambda k: "k_spike_cls" in k or "k_ell_cls" in k          # (k_ell_cls: the class items beside the ELL blocks, small shards)
     few = lambda k, v: "k_build_regILi32ELi3E" in k and v.get("scratch", 0) <= 64
-    bad = {k: v["scratch"] for k, v in ru.items() if v.get("scratch", 0) > 0 and not cls(k) and not few(k, v)}
+    # Round 5: some k_item_bwd instantiations report a 36-byte frame that NO instruction touches (an SGPR-spill slot the
+    # register allocator reserved and then served from VGPR lanes; which instantiations show it changes with any edit).  What
+    # the test is after is stack TRAFFIC, so for this kernel it counts the scratch instructions of the kept assembly instead.
+    dead = lambda k, v: "k_item_bwd" in k and v.get("scratch", 0) <= 64 and _scratch_instructions(ge, k) == 0
+    bad = {k: v["scratch"] for k, v in ru.items() if v.get("scratch", 0) > 0 and not cls(k) and not few(k, v) and not dead(k, v)}
     assert not bad, bad
     assert all(v.get("scratch", 0) <= (512 if ("k_spike_cls_all" in k or "k_ell_cls" in k) else 320) for k, v in ru.items())
