@@ -47,9 +47,14 @@ typedef double d4 __attribute__((ext_vector_type(4)));      // accumulator tile 
 __host__ __device__ constexpr int sv_cls_rows_read(int maxlen) {
   return (maxlen <= 0) ? SV_CLS_PF : ((maxlen + SV_CLS_PF - 1) / SV_CLS_PF) * SV_CLS_PF + SV_CLS_PF;
 }
-static_assert(64 * sv_cls_rows_read(1) <= 64 * 1 + SV_CLS_TT_PAD && 64 * sv_cls_rows_read(2) <= 64 * 2 + SV_CLS_TT_PAD &&
-              64 * sv_cls_rows_read(3) <= 64 * 3 + SV_CLS_TT_PAD && 64 * sv_cls_rows_read(4) <= 64 * 4 + SV_CLS_TT_PAD &&
-              64 * sv_cls_rows_read(5) <= 64 * 5 + SV_CLS_TT_PAD, "tt padding shorter than the class kernel's read-ahead");
+// every row length a tile can have (rows are cut at SV_SPIKE_CHUNK spikes): the read-ahead of a tile ends at most SV_CLS_TT_PAD
+// doubles behind the tile itself, hence -- tiles are contiguous -- inside the next tile or, for the last one, inside the pad
+__host__ __device__ constexpr bool sv_cls_tt_pad_covers_every_length() {
+  for (int m = 0; m <= 64 * 8; ++m)
+    if (64 * sv_cls_rows_read(m) > 64 * m + SV_CLS_TT_PAD) return false;
+  return true;
+}
+static_assert(sv_cls_tt_pad_covers_every_length(), "tt padding shorter than the class kernel's read-ahead");
 
 struct LatentMeta {
   int M, P, ktype, nth;

@@ -6,15 +6,19 @@
 
 #include "kernels_spike_cls.h"
 
-void sv_launch_spike_classes(const EngineView& v, hipStream_t s) {
+// Every wrapper returns the launch status (hipGetLastError right behind the launch): a refused launch -- a grid of zero
+// blocks, an LDS request the device cannot serve -- must reach svgpfa_last_error, not vanish.
+hipError_t sv_launch_spike_classes(const EngineView& v, hipStream_t s) {
   hipLaunchKernelGGL(k_spike_classes, dim3((v.R + 3) / 4), dim3(256), 0, s, v);
+  return hipGetLastError();
 }
 
-void sv_launch_spike_pre(const EngineView& v, hipStream_t s) {
+hipError_t sv_launch_spike_pre(const EngineView& v, hipStream_t s) {
   hipLaunchKernelGGL(k_spike_pre, dim3(v.R * v.K), dim3(64), 0, s, v);
+  return hipGetLastError();
 }
 
-void sv_launch_spike_cls(const EngineView& v, const double* C, int nv, int dc, int full, int pair, unsigned grid, hipStream_t s) {
+hipError_t sv_launch_spike_cls(const EngineView& v, const double* C, int nv, int dc, int full, int pair, unsigned grid, hipStream_t s) {
   const dim3 gc(grid), bs(64);
   if (nv == 0) {
     if (dc) hipLaunchKernelGGL((k_spike_cls_all<1>), gc, bs, 0, s, v, C, full, pair);
@@ -26,32 +30,47 @@ void sv_launch_spike_cls(const EngineView& v, const double* C, int nv, int dc, i
     if (dc) hipLaunchKernelGGL((k_spike_cls<2, 1>), gc, bs, 0, s, v, C, full, pair);
     else hipLaunchKernelGGL((k_spike_cls<2, 0>), gc, bs, 0, s, v, C, full, pair);
   }
+  return hipGetLastError();
 }
 
-void sv_launch_spike_comb(const EngineView& v, bool full, hipStream_t s) {
+hipError_t sv_launch_spike_comb(const EngineView& v, bool full, hipStream_t s) {
   if (full) hipLaunchKernelGGL(k_spike_comb<true>, dim3(v.R * v.K), dim3(64), 0, s, v);
   else hipLaunchKernelGGL(k_spike_comb<false>, dim3(v.R * v.K), dim3(64), 0, s, v);
+  return hipGetLastError();
 }
 
 template <int KS, int DC>
 static hipError_t launch_ell_cls_t(const EngineView& v, const double* C, const double* d, int want_sums, int want_lat, int parts,
                                    int lc0, int lc1, int full, int pair, unsigned workers, size_t lds_ell, hipStream_t s) {
   const size_t lds = std::max(lds_ell, (size_t)4 * SV_CLS_SLICE * sizeof(double));
-  static bool allowed = false;           // (one attribute call per instantiation and process)
-  if (!allowed && lds > 48 * 1024) {
-    hipError_t st = hipFuncSetAttribute((const void*)k_ell_cls<KS, DC>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    if (st != hipSuccess) return st;
-    allowed = true;
-  }
   int nell = v.R * parts * (want_lat ? 2 : 1);
-  {   // diagnosis only (results are wrong): SVGPFA_ELLCLS_DIAG=1 launches the ELL blocks alone, =2 the class workers alone
-    static const int diag = getenv("SVGPFA_ELLCLS_DIAG") ? atoi(getenv("SVGPFA_ELLCLS_DIAG")) : 0;
-    if (diag == 1) workers = 0;
-    if (diag == 2) nell = 0;
-  }
+#ifdef SV_ELLCLS_DIAG     // diagnosis BUILDS only (results are wrong; tests/tools/ellcls_diag.sh): 1 launches the ELL blocks alone, 2 the class workers alone
+  if (SV_ELLCLS_DIAG == 1) workers = 0;
+  if (SV_ELLCLS_DIAG == 2) nell = 0;
+#endif
   const unsigned grid = (unsigned)nell + (workers + 3) / 4;
   hipLaunchKernelGGL((k_ell_cls<KS, DC>), dim3(grid), dim3(256), lds, s, v, C, d, want_sums, want_lat, parts, lc0, lc1, full, nell, pair);
   return hipGetLastError();
+}
+
+// The dynamic-LDS allowance of k_ell_cls<ks, *> on the CURRENT device (svgpfa_create calls this once per engine, as it does
+// for every other kernel above 48 KB: the attribute is per device, and an engine on a second device of the process must
+// set it there too).
+template <int KS>
+static hipError_t allow_ell_cls_t() {
+  hipError_t st = hipFuncSetAttribute((const void*)k_ell_cls<KS, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  if (st != hipSuccess) return st;
+  return hipFuncSetAttribute((const void*)k_ell_cls<KS, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+}
+hipError_t sv_allow_ell_cls(int ks) {
+  switch (ks) {
+    case 1: return allow_ell_cls_t<1>();   case 2: return allow_ell_cls_t<2>();   case 3: return allow_ell_cls_t<3>();
+    case 4: return allow_ell_cls_t<4>();   case 5: return allow_ell_cls_t<5>();   case 6: return allow_ell_cls_t<6>();
+    case 7: return allow_ell_cls_t<7>();   case 8: return allow_ell_cls_t<8>();   case 9: return allow_ell_cls_t<9>();
+    case 10: return allow_ell_cls_t<10>(); case 11: return allow_ell_cls_t<11>(); case 12: return allow_ell_cls_t<12>();
+    case 13: return allow_ell_cls_t<13>(); case 14: return allow_ell_cls_t<14>(); case 15: return allow_ell_cls_t<15>();
+    default: return allow_ell_cls_t<16>();
+  }
 }
 
 hipError_t sv_launch_ell_cls(const EngineView& v, const double* C, const double* d, int ks, int dc, int want_sums, int want_lat,

@@ -324,6 +324,7 @@ int svgpfa_create(const svgpfa_dims* d, int device, svgpfa_engine** out) {
                 if (!rc) rc = allow_lds(e, (k_quad_ell_mfma<KS_, 2, double>), std::max(lds_qell_mfma(e, 0), lds_qell_mfma(e, 1))));
   }
   if (rc) return rc;
+  HIPCHK(e, sv_allow_ell_cls(e->KKT));     // k_ell_cls (small shards) on THIS device
   return SVGPFA_OK;
 }
 
@@ -523,7 +524,8 @@ int svgpfa_set_spikes(svgpfa_engine* e, const int64_t* off, const double* times,
   v.nsplitS = (int)sS_neuron.size();
   // k_spike_cls's pass loads rows 0 .. 3 unconditionally and, in every iteration i0 < maxlen, rows i0 + 4 .. i0 + 7: the
   // highest row read of a tile is 4 ceil(maxlen / 4) + 3 <= maxlen + 6, i.e. up to 7 rows past the tile (maxlen = 1), so
-  // two prefetch groups of padding behind the last tile (sv_cls_tt_pad; checked by tests/test_cpu_host.py)
+  // two prefetch groups of padding behind the last tile (SV_CLS_TT_PAD; engine_common.h proves at compile time, for every
+  // row length, that a tile's read-ahead ends within that many doubles behind the tile)
   std::vector<double> tt((size_t)(tt_len + SV_CLS_TT_PAD), 0.0);
   for (const SpikeTile& tl : tiles)
     for (int l = 0; l < tl.nrows; ++l) {
@@ -651,9 +653,10 @@ static void launch_build(svgpfa_engine* e, int write_aux, const SnapTable* snap,
 
 // Classes of the spike pass's class path for the current kernel snapshot (needs the spikes' windows): they ride in the
 // kernel build's launch (launch_build); this separate kernel serves a build that ran before the spikes were set.
-static void launch_classes(svgpfa_engine* e) {
-  sv_launch_spike_classes(e->v, e->stream);
+static int launch_classes(svgpfa_engine* e) {
+  HIPCHK(e, sv_launch_spike_classes(e->v, e->stream));
   e->cls_valid = true;
+  return SVGPFA_OK;
 }
 
 int svgpfa_build_kernels(svgpfa_engine* e, const double* const* Z, const double* const* theta) {
@@ -838,7 +841,7 @@ static bool pair_rides(const svgpfa_engine* e) {
   return e->pair_ride && e->cls_on && e->v.ntiles > 0 && e->precision == SVGPFA_PRECISION_FP64;
 }
 
-static void launch_spike_pass(svgpfa_engine* e, hipStream_t sk, bool full, bool want_c, const double* C, bool have_w,
+static int launch_spike_pass(svgpfa_engine* e, hipStream_t sk, bool full, bool want_c, const double* C, bool have_w,
                               bool comb_rides = false) {
   EngineView& v = e->v;
   const unsigned gc = (unsigned)std::min<long long>((long long)v.ntiles * v.K, e->grid_cls);
@@ -847,19 +850,23 @@ static void launch_spike_pass(svgpfa_engine* e, hipStream_t sk, bool full, bool 
     const bool fused = cls_one_launch(e);
     const bool tw = !fused && full && v.ntype[SV_PERIODIC] > 0;
     const int dc = (full && want_c) ? 1 : 0;
-    if (dc && !have_w) sv_launch_spike_pre(v, sk);
+    if (dc && !have_w) HIPCHK(e, sv_launch_spike_pre(v, sk));
     // a rider needs workers for the pair items even when the class items are few: the grid of the pair pass's own launch
     const long long npair = (long long)v.nchunks * v.K;
     const unsigned gr = ride ? std::max(gc, (unsigned)std::min<long long>((npair + 7) & ~7LL, e->grid_cls)) : gc;
     if (fused) {
-      sv_launch_spike_cls(v, C, 0, dc, (dc || full) ? 1 : 0, ride ? 1 : 0, gr, sk);
+      HIPCHK(e, sv_launch_spike_cls(v, C, 0, dc, (dc || full) ? 1 : 0, ride ? 1 : 0, gr, sk));
     } else {
-      if (tw) sv_launch_spike_cls(v, C, 4, dc, 1, 0, gc, sk);
-      sv_launch_spike_cls(v, C, 2, dc, (dc || full) ? 1 : 0, ride ? 1 : 0, gr, sk);
+      if (tw) HIPCHK(e, sv_launch_spike_cls(v, C, 4, dc, 1, 0, gc, sk));
+      HIPCHK(e, sv_launch_spike_cls(v, C, 2, dc, (dc || full) ? 1 : 0, ride ? 1 : 0, gr, sk));
     }
   }
-  if (!v.comb_fold && e->cls_on && !comb_rides) sv_launch_spike_comb(v, full, sk);
-  if (!ride) launch_pair_pass(e, sk, full, want_c, C);
+  if (!v.comb_fold && e->cls_on && !comb_rides) HIPCHK(e, sv_launch_spike_comb(v, full, sk));
+  if (!ride) {
+    launch_pair_pass(e, sk, full, want_c, C);
+    HIPCHK(e, hipGetLastError());
+  }
+  return SVGPFA_OK;
 }
 
 static int check_ready(svgpfa_engine* e) {
@@ -879,7 +886,7 @@ static int enqueue_elbo(svgpfa_engine* e, const PtrTable& pt, const ElboPlan& pl
   EngineView& v = e->v;
   const unsigned mask = pl.mask;
   int rc;
-  if (!e->cls_valid) launch_classes(e);   // spikes set after the last kernel build
+  if (!e->cls_valid && (rc = launch_classes(e))) return rc;   // spikes set after the last kernel build
   hipStream_t sm = e->stream;
   // the class path's W rides in k_prep when this evaluation's spike pass wants dC
   const bool have_w = pl.run_spike && pl.full && (mask & 2u) && e->cls_on && v.ntiles > 0;
@@ -890,8 +897,9 @@ static int enqueue_elbo(svgpfa_engine* e, const PtrTable& pt, const ElboPlan& pl
   // ---- spike pass (fp64 VALU bound): needs only a = Kzz^-1 m (and W) from k_prep
   // Small shards (one launch for all classes, fp64, quadrature statistics already made by k_front): the ELL blocks and the
   // class items share ONE launch (k_ell_cls) -- both follow k_front, both precede k_item_bwd, neither fills the chip.
+  // (k_ell_cls runs its ELL blocks with four waves: its dynamic LDS is sized for e->ell_nw, so any other count keeps the launches apart)
   const bool merged = e->ell_cls && e->front && pl.run_spike && e->cls_on && v.ntiles > 0 && cls_one_launch(e) &&
-                      e->precision == SVGPFA_PRECISION_FP64;
+                      e->precision == SVGPFA_PRECISION_FP64 && e->ell_nw == 4;
   // Blocks per trial of the merged launch's ELL part: its blocks and the class workers' blocks hold the same 64 KB of LDS, two
   // per CU, so the ELL part may take at most half of the chip's 2 x CUs slots or the class items queue up behind it (measured
   // with the engine's usual four blocks per trial: 504 ELL blocks, 48.6 us = the two kernels one after the other)
@@ -913,10 +921,10 @@ static int enqueue_elbo(svgpfa_engine* e, const PtrTable& pt, const ElboPlan& pl
       const bool ride = pair_rides(e);
       HIPCHK(e, sv_launch_ell_cls(ve, C, d, e->KKT, dc, want_c ? 1 : 0, pl.want_lat ? 1 : 0, parts_m, e->ell_lc[0], e->ell_lc[1],
                                   full ? 1 : 0, ride ? 1 : 0, workers, lds_ell, sm));
-      if (!v.comb_fold) sv_launch_spike_comb(v, full, sm);
+      if (!v.comb_fold) HIPCHK(e, sv_launch_spike_comb(v, full, sm));
       if (!ride) launch_pair_pass(e, sm, full, want_c, C);
     } else {
-      launch_spike_pass(e, sm, pl.full, (mask & 2u) != 0, C, have_w, comb_rides);
+      if ((rc = launch_spike_pass(e, sm, pl.full, (mask & 2u) != 0, C, have_w, comb_rides))) return rc;
     }
     timing_end(e, evp, sm);
   }
@@ -1007,12 +1015,12 @@ int svgpfa_freeze_stats(svgpfa_engine* e, const double* const* mean, const doubl
   EngineView& v = e->v;
   PtrTable pt;
   if ((rc = fill_ptrs(e, pt, mean, cholvec, nullptr, nullptr, nullptr, 0))) return rc;
-  if (!e->cls_valid) launch_classes(e);
+  if (!e->cls_valid && (rc = launch_classes(e))) return rc;
   launch_prep(e, pt);
   if ((rc = launch_times_quad(e, e->stream))) return rc;
   // the per-neuron sums of the spike means are the spike part of dC, which the spike-time pass makes (cosine series:
   // ~0.3 ms at the north-star size against 2 ms for the posterior mean and variance at every spike)
-  if (v.nchunks > 0) launch_spike_pass(e, e->stream, true, true, C, false);
+  if (v.nchunks > 0 && (rc = launch_spike_pass(e, e->stream, true, true, C, false))) return rc;
   e->p0_token = 0;                     // that pass overwrote the reusable spike sums
   hipLaunchKernelGGL(k_mseg_from_dc, dim3((v.N * v.K + SV_FS_OUT - 1) / SV_FS_OUT), dim3(256), 0, e->stream, v);
   HIPCHK(e, hipGetLastError());

@@ -3,7 +3,7 @@
 Every per-trial quantity is independent across trials, so each rank owns a contiguous block of trials
 (balanced by spike count, svgpfa_amd.utils.synthetic.shard_trials) and runs its own engine.  The only
 exchange per evaluation is ONE all-reduce (sum) of the engine's `shared` vector
-[ELBO, ELL, KL, dC, dd, dtheta] -- 2 219 doubles at the north-star config, latency bound.
+[ELBO, ELL, KL, dC, dd, dtheta] -- 2 218 doubles at the north-star config, latency bound.
 Gradients of per-trial parameters (means, cholVecs, Z) never leave their owner.
 
 Backend: "nccl" (= RCCL over xGMI on ROCm) for device tensors, "gloo" in the CPU tests."""

@@ -179,7 +179,7 @@ def test_not_positive_definite_raises():
 @pytest.mark.parametrize("env", [{"SVGPFA_COMB_FOLD": "0"}, {"SVGPFA_COMB_FOLD": "1"}, {"SVGPFA_TILE_NW": "2"},
                                  {"SVGPFA_TILE_NW": "4"}, {"SVGPFA_CLS_FUSED": "0"}, {"SVGPFA_CLS_FUSED": "1"},
                                  {"SVGPFA_ELL_PARTS": "3"}, {"SVGPFA_FRONT": "0"}, {"SVGPFA_FRONT": "0", "SVGPFA_TIMES_NW": "2"},
-                                 {"SVGPFA_BUILD": "mfma"}, {"SVGPFA_ELL_CLS": "0"},
+                                 {"SVGPFA_BUILD": "mfma"}, {"SVGPFA_ELL_CLS": "0"}, {"SVGPFA_ELL_NW": "2"},
                                  {"SVGPFA_PAIR_RIDE": "0"}, {"SVGPFA_PAIR_RIDE": "0", "SVGPFA_RBF_SERIES": "0"},
                                  {"SVGPFA_PAIR_RIDE": "0", "SVGPFA_ELL_CLS": "0", "SVGPFA_RBF_SERIES": "0"},
                                  {"SVGPFA_CLS_FUSED": "0", "SVGPFA_RBF_SERIES": "0"},
@@ -198,7 +198,7 @@ def test_launch_switches_agree_with_the_default(monkeypatch, env):
         prob["theta"][k] = prob["theta"][k] * np.array([lsc, psc][:len(prob["theta"][k])])
     outs = []
     for e in ({}, env):
-        for var in ("SVGPFA_COMB_FOLD", "SVGPFA_TILE_NW", "SVGPFA_CLS_FUSED", "SVGPFA_ELL_PARTS", "SVGPFA_TIMES_NW", "SVGPFA_FRONT", "SVGPFA_BUILD", "SVGPFA_ELL_CLS", "SVGPFA_PAIR_RIDE", "SVGPFA_RBF_SERIES", "SVGPFA_COMB_RIDE"):
+        for var in ("SVGPFA_COMB_FOLD", "SVGPFA_TILE_NW", "SVGPFA_CLS_FUSED", "SVGPFA_ELL_PARTS", "SVGPFA_TIMES_NW", "SVGPFA_FRONT", "SVGPFA_BUILD", "SVGPFA_ELL_CLS", "SVGPFA_PAIR_RIDE", "SVGPFA_RBF_SERIES", "SVGPFA_COMB_RIDE", "SVGPFA_ELL_NW"):
             monkeypatch.delenv(var, raising=False)
         if "SVGPFA_RBF_SERIES" in env:             # both runs with the RBF latents pair by pair: the rider has work to do
             monkeypatch.setenv("SVGPFA_RBF_SERIES", env["SVGPFA_RBF_SERIES"])
@@ -216,6 +216,32 @@ def test_launch_switches_agree_with_the_default(monkeypatch, env):
         assert rel_err(b, a) < tol
 
 
+@pytest.mark.parametrize("Ms", [[10, 24, 9, 30, 11], [9, 16, 12]], ids=["M<=32", "M<=16"])
+def test_item_bwd_wave_counts_agree(monkeypatch, Ms):
+    """k_item_bwd below M = 33 (whole-tile owners): 2, 3 and 4 waves per block deal the node tiles differently and add the
+    waves' partial sums in wave order -- every count against the oracle and against the default to rounding.  (Above 32 the
+    block is one team of ceil(M / 16) panel owners: test_launch_switches... runs M = 40, the shape classes M = 33 .. 64.)"""
+    from oracle import svgpfa_oracle as orc
+    prob = synthetic.make_problem(R=4, N=9, K=len(Ms), M=Ms, kernels="mix", seed=21, n_quad=70, rate=20.0, jitter=1.0)
+    ref = orc.elbo_and_grads(orc.from_numpy_problem(prob), 15)
+    outs = {}
+    for nw in ("", "2", "3", "4"):
+        monkeypatch.delenv("SVGPFA_TILE_NW", raising=False)
+        if nw:
+            monkeypatch.setenv("SVGPFA_TILE_NW", nw)
+        eng, P = _engine(prob)
+        shared, gm, gc, gz = eng.elbo(P["mean"], P["cholVecs"], P["C"], P["d"], 15)
+        eng.sync()
+        outs[nw] = [shared.cpu().numpy()] + [t.cpu().numpy() for t in gm + gc + gz]
+        eng.close()
+        assert abs(outs[nw][0][0] - float(ref["elbo"])) <= 1e-9 * abs(float(ref["elbo"]))
+        for k in range(prob["K"]):
+            assert rel_err(outs[nw][1 + k], ref["g_mean"][k][:, :, 0].numpy()) < 1e-7
+    for nw in ("2", "3", "4"):
+        for a, b in zip(outs[""], outs[nw]):
+            assert rel_err(b, a) < 1e-12
+
+
 def test_build_reg_three_waves_per_simd_agrees_with_two(monkeypatch):
     """k_build_reg<32> has two instantiations (two / three waves per SIMD; the host picks by grid size, SVGPFA_BUILD_WPE
     forces one): the same arithmetic in the same order -- Kzz, its Cholesky factor, and an evaluation agree to rounding."""
@@ -231,6 +257,20 @@ def test_build_reg_three_waves_per_simd_agrees_with_two(monkeypatch):
         eng.close()
     for a, b in zip(*outs):
         assert rel_err(b, a) < 1e-12
+
+
+def test_kzz_and_its_cholesky_factor_above_32_inducing_points():
+    """svgpfa_get_kzz / svgpfa_get_kzz_chol for the blocked MFMA build (k_build_mfma, M > 32: its L output is written only
+    for this getter, so no gradient test reaches it) against the oracle's Kzz + eps I and torch.linalg.cholesky
+    (reference stats/kernelsMatricesStore.py:107-117, utils/miscUtils.py:209-216)."""
+    from oracle import svgpfa_oracle as orc
+    prob = synthetic.make_problem(R=3, N=5, K=4, M=[33, 48, 64, 40], kernels="mix", seed=29, n_quad=30, rate=10.0, jitter=1.0)
+    eng, P = _engine(prob)
+    Kzz, Kchol = orc.build_kzz(orc.from_numpy_problem(prob))
+    for k in range(prob["K"]):
+        assert rel_err(eng.get_kzz(k).cpu().numpy(), Kzz[k].numpy()) < 1e-12
+        assert rel_err(eng.get_kzz_chol(k).cpu().numpy(), Kchol[k].numpy()) < 1e-9
+    eng.close()
 
 
 def _drop_spikes(prob, keep_trial):

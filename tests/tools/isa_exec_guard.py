@@ -27,7 +27,9 @@ PROLOGUE_OK = re.compile(r"^\s*(v_writelane_b32|v_readlane_b32|v_readfirstlane_b
 # the prologue of a join block ends where EXEC is written by anything but the restore (`s_and_saveexec` opens a nested
 # region: an `s_or_b64 exec` behind it closes THAT region, and what stands in front of it ran under the block's full mask) or
 # where control leaves the block
-PROLOGUE_END = re.compile(r"^\s*(s_\w+_saveexec_b64\b|s_\w+\s+exec\b|s_cbranch_\w+|s_branch\b|s_endpgm\b|s_setpc_b64\b)")
+# (a CONDITIONAL scalar branch does not end it: the fall-through still reaches the restore with the same suspect copies in
+# front of it -- round 5, after review; only an unconditional transfer does)
+PROLOGUE_END = re.compile(r"^\s*(s_\w+_saveexec_b64\b|s_\w+\s+exec\b|s_branch\b|s_endpgm\b|s_setpc_b64\b)")
 # everything else that executes per lane
 EXEC_DEPENDENT = re.compile(r"^\s*(v_|ds_|global_|buffer_|scratch_|flat_|tbuffer_|image_)\w+")
 
@@ -52,6 +54,8 @@ def scan(path):
             name = m.group(1)
             if not name.startswith(".L"):
                 func = name
+            if name.startswith(".L") and block is not None and pending and (func, name) not in join_targets:
+                continue                                   # fall-through of a conditional branch into the next label: same prologue
             block, pending = (name if (func, name) in join_targets else None), []
             continue
         if block is None:
