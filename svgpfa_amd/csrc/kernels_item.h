@@ -313,7 +313,10 @@ __global__ __launch_bounds__(64, (NT <= 2 ? SV_BUILD_WPE2 : 2)) void k_build_mfm
           T[rr * LDT + li] = v;
           if (write_aux && in) {
             ev.Kzz[base + (long long)i * M + j] = v;
-            if (ib != jb) ev.Kzz[base + (long long)j * M + i] = v;
+            if (ib != jb) {
+              ev.Kzz[base + (long long)j * M + i] = v;
+              ev.L[base + (long long)j * M + i] = 0.0;      // L's tiles above the diagonal (the factorisation below writes the rest;
+            }                                               //  round 5: they were left as the allocation held them)
           }
         }
       }
