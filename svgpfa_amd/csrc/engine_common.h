@@ -168,7 +168,10 @@ struct EngineView {
   double* muq; double* varq; double* gmuq; double* gvarq;
   double* P0; double* P1; double* Tpart;           // spike partials
   double* gCspk;                                   // [R][N][K] spike part of dC per trial (segment, or its first part)
-  double* gCspkB;                                  // [R][N][K] second part of segments cut by a chunk boundary (else 0)
+  double* gCspkB;                                  // [R][N][K] second part of segments cut by a chunk boundary / cut to fill a tile: VALID
+                                                   // only where seg_cut says so (sv_dc_spike), whatever it holds elsewhere
+  const unsigned char* seg_cut;                    // [R][N] static: bit 0 the pair pass's chunks cut the (trial, neuron) segment,
+                                                   // bit 1 the class path's rows do (kinds 1 / 2)
   double* splitPart;                               // [nchunks][K] spike part of dC of split chunks
   // class path (kernels_spike_cls.h)
   SpikeClassTab* cls;                              // device copy of the class table
@@ -400,6 +403,17 @@ __device__ __forceinline__ double block_sum(double x, double* red) {
   double s = 0.0;
   for (int i = 0; i < nw; ++i) s += red[i];
   return s;
+}
+
+// Spike part of dC of (trial r, neuron n, latent k): plane A, plus plane B where the pass that served the item (ev.ser) cut the
+// segment in two.  Round 5: the passes used to clear plane B for every uncut segment so that it stayed valid when an item
+// moved between them (8 MB of zeros stored per evaluation at the north-star size, and 8 MB read back here); which
+// segments each pass cuts is static, so a one-byte flag per (trial, neuron) says instead where plane B counts.
+__device__ __forceinline__ double sv_dc_spike(const EngineView& ev, int r, int n, int k) {
+  const long long o = ((long long)r * ev.N + n) * ev.K + k;
+  const double a = ev.gCspk[o];
+  const int bit = ev.ser[r * ev.K + k] ? 2 : 1;
+  return (ev.seg_cut[(long long)r * ev.N + n] & bit) ? a + ev.gCspkB[o] : a;
 }
 
 // dC partials of oversize (trial, neuron) segments (usually none): the pair-by-pair pass leaves them per split chunk, the

@@ -149,8 +149,7 @@ __device__ __forceinline__ void fin_cd_group(const EngineView& ev, const double*
             double t = 0.0;
             if (r < R) {
               const long long o2 = ((long long)r * N + n) * 2 * K + k;      // ncd == R: one partial row per trial
-              t = (ev.gCspk[(long long)r * NK + id] + ev.gCspkB[(long long)r * NK + id]) -
-                  (ev.gCpart[o2] + cnk * ev.gCpart[o2 + K]);               // dC = spikes - (E^T mu + C . E^T var)
+              t = sv_dc_spike(ev, r, n, k) - (ev.gCpart[o2] + cnk * ev.gCpart[o2 + K]);     // dC = spikes - (E^T mu + C . E^T var)
             }
             v[u] = t;
           }

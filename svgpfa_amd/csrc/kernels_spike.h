@@ -70,7 +70,7 @@ __global__ __launch_bounds__(256) void k_mseg(EngineView ev, int gs) {
 }
 
 // The same sums from the spike part of dC that a FULL spike pass has just left per trial (svgpfa_freeze_stats): Mseg[n][k]
-// = sum_r (gCspk + gCspkB)[r][n][k] + the split chunks of neuron n, trials four at a time, fixed order.
+// = sum_r (gCspk [+ gCspkB where the segment is cut: sv_dc_spike])[r][n][k] + the split chunks of neuron n, trials four at a time, fixed order.
 __global__ __launch_bounds__(256) void k_mseg_from_dc(EngineView ev) {
   __shared__ double red[256];
   const int tid = threadIdx.x, o = tid % SV_FS_OUT, pg = tid / SV_FS_OUT, NG = 256 / SV_FS_OUT;
@@ -82,7 +82,7 @@ __global__ __launch_bounds__(256) void k_mseg_from_dc(EngineView ev) {
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
         const int r = r0 + u * NG;
-        v[u] = (r < R) ? ev.gCspk[(long long)r * NK + id] + ev.gCspkB[(long long)r * NK + id] : 0.0;
+        v[u] = (r < R) ? sv_dc_spike(ev, r, id / ev.K, id % ev.K) : 0.0;
       }
       s += (v[0] + v[1]) + (v[2] + v[3]);
     }

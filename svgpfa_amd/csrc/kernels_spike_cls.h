@@ -259,9 +259,9 @@ __device__ __forceinline__ void cls_flush(const EngineView& ev, const double* __
   }
 }
 
-// the rows' dC partials: every (trial, neuron, latent) entry of BOTH planes is written on every pass -- a whole segment
-// writes plane A and clears plane B, the halves of a cut segment write one plane each -- so the planes stay valid when an
-// item changes between this path and the pair loop; pieces of an oversize segment go to their slot
+// the rows' dC partials: a whole segment writes plane A, the halves of a cut segment one plane each (ev.seg_cut, static,
+// tells the reader which segments have a second half: engine_common.h sv_dc_spike); pieces of an oversize segment go to
+// their slot
 __device__ __forceinline__ void cls_emit_rows(const EngineView& ev, const SpikeRow& row, int r, int memk, int nmem,
                                               const double* dcl) {
   const int lane = threadIdx.x & 63, K = ev.K;
@@ -271,8 +271,7 @@ __device__ __forceinline__ void cls_emit_rows(const EngineView& ev, const SpikeR
     const double v = dcl[s * 64 + lane];
     const long long o = ((long long)r * ev.N + row.neuron) * K + k;
     if (row.kind == 0) {
-      ev.gCspk[o] = v;
-      ev.gCspkB[o] = 0.0;
+      ev.gCspk[o] = v;                     // (plane B of an uncut segment is never read: ev.seg_cut)
     } else if (row.kind == 1) {
       ev.gCspk[o] = v;
     } else if (row.kind == 2) {

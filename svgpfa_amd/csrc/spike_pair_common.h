@@ -16,9 +16,9 @@
 // that continue its head segment), then every segment end stores its total -- each neuron has exactly one writer.
 // Two planes per (trial, neuron, latent): outA takes a segment that lies inside the chunk (outB is then cleared) and the
 // first part of a segment cut by the chunk's end (tailcut: the chunk's LAST segment continues in the next chunk, which
-// writes outB); headcont: the chunk's FIRST segment continues one of the previous chunk and goes to outB.  Every entry of
-// both planes that belongs to an existing segment is written on every pass, so the planes stay valid when an item moves
-// between this pass and the class path (which follows the same rule).
+// writes outB); headcont: the chunk's FIRST segment continues one of the previous chunk and goes to outB.  Plane A of every
+// existing segment is written on every pass; plane B only where a chunk boundary cuts the segment -- ev.seg_cut (static)
+// tells the reader where it counts, so the planes stay valid when an item moves between this pass and the class path.
 template <int SPL>
 __device__ __forceinline__ void seg_emit_lane(const int (&key)[SPL], const double (&v)[SPL], double* outA, double* outB,
                                               bool headcont, bool tailcut, int K, int lane) {
@@ -48,8 +48,7 @@ __device__ __forceinline__ void seg_emit_lane(const int (&key)[SPL], const doubl
       if (key[i] == kfirst) {
         outB[o] = tot;                       // continuation: plane A was written by the previous chunk
       } else {
-        outA[o] = tot;
-        if (!(tailcut && kn < 0)) outB[o] = 0.0;   // kn < 0: the chunk's last segment
+        outA[o] = tot;                       // (plane B of a segment no chunk boundary cuts is never read: ev.seg_cut)
       }
     }
   }

@@ -413,6 +413,7 @@ int svgpfa_set_spikes(svgpfa_engine* e, const int64_t* off, const double* times,
   std::vector<long long> seg((size_t)v.R * v.N + 1);
   std::vector<double> cnt(v.N, 0.0);
   std::vector<SpikeChunk> chunks;
+  std::vector<unsigned char> seg_cut((size_t)v.R * v.N, 0);   // bit 0: cut by a chunk boundary; bit 1: cut to fill a tile (below)
   std::vector<int> cfirst(v.R + 1), splits;
   for (int r = 0; r < v.R; ++r) {
     long long s0 = off[r], s1 = off[r + 1];
@@ -450,6 +451,7 @@ int svgpfa_set_spikes(svgpfa_engine* e, const int64_t* off, const double* times,
         } else {
           cur.count += (int)room;
           cur.split |= 4;              // this chunk's last segment continues in the next chunk
+          seg_cut[(size_t)r * v.N + n] |= 1;
           flush();
           cur = SpikeChunk{r, (int)(len - room), b + room, 2, -1};
         }
@@ -503,6 +505,7 @@ int svgpfa_set_spikes(svgpfa_engine* e, const int64_t* off, const double* times,
       const long long b = tr[i].second;
       tr[i] = {SpikeRow{h1, n, 1, 0}, b};
       tr.push_back({SpikeRow{len - h1, n, 2, 0}, b + h1});
+      seg_cut[(size_t)r * v.N + n] |= 2;
     }
     std::stable_sort(tr.begin(), tr.end(), [](const std::pair<SpikeRow, long long>& a, const std::pair<SpikeRow, long long>& b2) {
       return a.first.len > b2.first.len;
@@ -581,6 +584,12 @@ int svgpfa_set_spikes(svgpfa_engine* e, const int64_t* off, const double* times,
     HIPCHK(e, hipMemcpy(dlo, tlo.data(), sizeof(double) * v.R, hipMemcpyHostToDevice));
     HIPCHK(e, hipMemcpy(dhi, thi.data(), sizeof(double) * v.R, hipMemcpyHostToDevice));
     v.spk_lo = dlo; v.spk_hi = dhi;
+  }
+  {
+    unsigned char* dcut;
+    DALLOC(e, dcut, seg_cut.size());
+    if (!seg_cut.empty()) HIPCHK(e, hipMemcpy(dcut, seg_cut.data(), seg_cut.size(), hipMemcpyHostToDevice));
+    v.seg_cut = dcut;
   }
   v.spk_t = st; v.spk_n = sn; v.spk_off = so; v.seg_off = sg; v.spk_cnt = sc; v.chunks = dc; v.chunk_first = cf;
   DALLOC(e, v.P0, (size_t)v.nchunks * v.sumM); DALLOC(e, v.P1, (size_t)v.nchunks * v.sumM);
