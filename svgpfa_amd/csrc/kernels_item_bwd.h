@@ -32,18 +32,6 @@
 // the class's moments + three coefficient rows); it borrows the Gt region, which nothing else uses before the reductions
 #define SV_GATHER_SCR (SV_ACOLS + 3 * (SV_FH + 1))
 
-// ---- M x M matrices of an item in LDS: TILE-PACKED lower triangles (round 5).  A lower-triangular (Linv, Vt) or symmetric
-// (Gt, At, C + C^T's inputs) matrix is kept as its NT (NT + 1) / 2 tiles of 16 x 16 on and below the diagonal, tile (a, b),
-// a >= b, at sv_tidx(a, b) * SV_TSZ, rows of a tile SV_TS = 18 doubles apart (both MFMA fragment patterns of a tile --
-// row-major li * 18 + 4 q + lg and transposed (4 q + lg) * 18 + li -- are conflict-free ds_read_b64).  A symmetric matrix
-// is read through whichever of the two patterns the tile's position asks for.  Against full MP x (MP + 2) images: 23 KB
-// instead of 34 KB per matrix at M = 64, which is what lets two blocks of k_item_bwd<4> share a CU.
-#define SV_TS 18
-#define SV_TSZ (16 * SV_TS)
-__host__ __device__ constexpr int sv_tidx(int a, int b) { return a * (a + 1) / 2 + b; }      // a >= b
-// element (i, j) of a tile-packed lower triangle, block row of i >= block row of j
-__device__ __forceinline__ int sv_tp(int i, int j) { return sv_tidx(i >> 4, j >> 4) * SV_TSZ + (i & 15) * SV_TS + (j & 15); }
-
 // Exchange tiles of phase 1 double-buffered (one block barrier per node tile instead of two): where the LDS is to spare
 #ifndef SV_BWD_DB
 #define SV_BWD_DB 1
@@ -442,55 +430,6 @@ __device__ SV_GATHER_ATTR void gather_item_inputs(const EngineView& ev, const La
 // NT (NT + 1) / 2 accumulator tiles of Gt -- 80 registers at M = 64, which is what kept k_item_bwd<4> at one wave per SIMD).
 // Two block barriers per node tile order the two hand-overs; no exchange tile is double-buffered (a tile's readers finish
 // in front of the barrier its next writer waits behind).
-template <int NT, int MODE>
-__device__ __forceinline__ void tri_chain_tp(d4 (&D)[NT], const double* Mat, const d4 (&B)[NT], const int orm, const int otr) {
-#pragma unroll
-  for (int a = 0; a < NT; ++a) {
-    d4 acc = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-    for (int b = 0; b < NT; ++b) {
-      if (MODE == 0 ? (b <= a) : (b >= a)) {
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const double av = (MODE == 0) ? lds_frag(&Mat[sv_tidx(a, b) * SV_TSZ + orm + 4 * q])
-                                        : lds_frag(&Mat[sv_tidx(b, a) * SV_TSZ + otr + 4 * q * SV_TS]);
-          acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, B[b][q], acc, 0, 0, 0);
-        }
-      }
-    }
-    D[a] = acc;
-  }
-}
-// A-operand fragment (row 16 a + li, column 16 b + 4 q + lg) of a SYMMETRIC tile-packed matrix (a, b compile-time)
-#define SV_SYMFRAG(Mat, a, b, q) \
-  (((a) >= (b)) ? lds_frag(&(Mat)[sv_tidx((a), (b)) * SV_TSZ + orm + 4 * (q)]) : lds_frag(&(Mat)[sv_tidx((b), (a)) * SV_TSZ + otr + 4 * (q) * SV_TS]))
-
-__device__ __forceinline__ void sv_tile_ab(int t, int& a, int& b) {
-  a = (t >= 1) + (t >= 3) + (t >= 6);
-  b = t - a * (a + 1) / 2;
-}
-
-// LDS-DMA staging of a packed lower triangle into the tile-packed image (global_load_lds, 16 bytes per lane: a wave
-// instruction fills 128 consecutive doubles of the image; pairs above the diagonal, beyond M and the tiles' row padding
-// come from a zero pair in global memory; the pair that holds a diagonal element of an odd-length row ends in the pad zero
-// its producer wrote, sv_tri_off).  23 wave instructions per matrix at M = 64.
-template <int NT>
-__device__ __forceinline__ void stage_matrix_dma_tp(double* dst, const double* src, int M, int tid, int nth) {
-  constexpr int TOT2 = NT * (NT + 1) / 2 * SV_TSZ / 2;       // pairs of doubles in the image
-  const int lane = tid & 63, wave = tid >> 6, nw = nth >> 6;
-  for (int cc = wave; cc * 64 < TOT2; cc += nw) {
-    const int e2 = cc * 64 + lane;
-    if (e2 < TOT2) {
-      const int t = e2 / (SV_TSZ / 2), rem = e2 - t * (SV_TSZ / 2), it = rem / (SV_TS / 2), jp = rem - it * (SV_TS / 2);
-      int a, b;
-      sv_tile_ab(t, a, b);
-      const int i = 16 * a + it, j = 16 * b + 2 * jp;
-      const double* g = (jp < 8 && i < M && j <= i) ? src + sv_tri_off(i) + j : sv_zero_pad;
-      __builtin_amdgcn_global_load_lds((const void*)g, (__attribute__((address_space(3))) void*)(dst + cc * 128), 16, 0, 0);
-    }
-  }
-}
-
 // Linv, Vt (tile-packed), ut, Z of the item into LDS.  M <= 32: both factors and the two vectors are requested before
 // anything is stored (one exposed memory latency); above: LDS-DMA.  The caller synchronises.
 template <int NT>
@@ -646,7 +585,7 @@ __device__ __forceinline__ void item_bwd_body(const EngineView& ev, const int r,
           const double v = Li[((b >= c) ? (b * (b + 1) / 2 + c) : 0) * TSZ + otr + 4 * q * TS];      // Linv[:, panel c]
           P[b][q] = (b >= c) ? v : 0.0;
         }
-      tri_chain_tp<NT, 1>(T1, Vl, P, orm, otr);       // Vt^T Linv[:, c]
+      tri_chain_tp<NT, 1>(T1, Vl, P, orm, otr, c);    // Vt^T Linv[:, c]  (the panel's tiles above the diagonal are zero: skipped)
       tri_chain_tp<NT, 0>(T2, Vl, T1, orm, otr);      // Vt Vt^T Linv[:, c]
 #pragma unroll
       for (int a = 0; a < NT; ++a)
@@ -1196,7 +1135,7 @@ __device__ __forceinline__ void item_bwd_body(const EngineView& ev, const int r,
         const double v = Vl[((b <= c) ? (c * (c + 1) / 2 + b) : 0) * TSZ + orm + 4 * q];
         P[b][q] = (b <= c) ? v : 0.0;
       }
-    tri_chain_tp<NT, 0>(VV, Vl, P, orm, otr);
+    tri_chain_tp<NT, 0>(VV, Vl, P, orm, otr, 0, c);      // (Vt^T[:, c] is zero below tile c: skipped)
   }
   __syncthreads();
   // At needs C + C^T: the tiles of C on and above the diagonal go through LDS (Vt's place, Vt is dead): tile (a, c), a <= c,

@@ -96,6 +96,70 @@ __device__ __forceinline__ void stage_matrix_dma(double* dst, const double* src,
   }
 }
 
+// ---- M x M matrices of an item in LDS: TILE-PACKED lower triangles (round 5).  A lower-triangular (Linv, Vt) or symmetric
+// (Gt, At, C + C^T's inputs) matrix is kept as its NT (NT + 1) / 2 tiles of 16 x 16 on and below the diagonal, tile (a, b),
+// a >= b, at sv_tidx(a, b) * SV_TSZ, rows of a tile SV_TS = 18 doubles apart (both MFMA fragment patterns of a tile --
+// row-major li * 18 + 4 q + lg and transposed (4 q + lg) * 18 + li -- are conflict-free ds_read_b64).  A symmetric matrix
+// is read through whichever of the two patterns the tile's position asks for.  Against full MP x (MP + 2) images: 23 KB
+// instead of 34 KB per matrix at M = 64, which is what lets two blocks of k_item_bwd<4> share a CU.
+#define SV_TS 18
+#define SV_TSZ (16 * SV_TS)
+__host__ __device__ constexpr int sv_tidx(int a, int b) { return a * (a + 1) / 2 + b; }      // a >= b
+// element (i, j) of a tile-packed lower triangle, block row of i >= block row of j
+__device__ __forceinline__ int sv_tp(int i, int j) { return sv_tidx(i >> 4, j >> 4) * SV_TSZ + (i & 15) * SV_TS + (j & 15); }
+
+// blo / bhi (wave-uniform): B[b] is known to be zero outside blo <= b <= bhi (a panel of a triangular matrix): those tile
+// products are skipped.
+template <int NT, int MODE>
+__device__ __forceinline__ void tri_chain_tp(d4 (&D)[NT], const double* Mat, const d4 (&B)[NT], const int orm, const int otr,
+                                             const int blo = 0, const int bhi = NT - 1) {
+#pragma unroll
+  for (int a = 0; a < NT; ++a) {
+    d4 acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int b = 0; b < NT; ++b) {
+      if ((MODE == 0 ? (b <= a) : (b >= a)) && b >= blo && b <= bhi) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const double av = (MODE == 0) ? lds_frag(&Mat[sv_tidx(a, b) * SV_TSZ + orm + 4 * q])
+                                        : lds_frag(&Mat[sv_tidx(b, a) * SV_TSZ + otr + 4 * q * SV_TS]);
+          acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, B[b][q], acc, 0, 0, 0);
+        }
+      }
+    }
+    D[a] = acc;
+  }
+}
+// A-operand fragment (row 16 a + li, column 16 b + 4 q + lg) of a SYMMETRIC tile-packed matrix (a, b compile-time)
+#define SV_SYMFRAG(Mat, a, b, q) \
+  (((a) >= (b)) ? lds_frag(&(Mat)[sv_tidx((a), (b)) * SV_TSZ + orm + 4 * (q)]) : lds_frag(&(Mat)[sv_tidx((b), (a)) * SV_TSZ + otr + 4 * (q) * SV_TS]))
+
+__device__ __forceinline__ void sv_tile_ab(int t, int& a, int& b) {
+  a = (t >= 1) + (t >= 3) + (t >= 6);
+  b = t - a * (a + 1) / 2;
+}
+
+// LDS-DMA staging of a packed lower triangle into the tile-packed image (global_load_lds, 16 bytes per lane: a wave
+// instruction fills 128 consecutive doubles of the image; pairs above the diagonal, beyond M and the tiles' row padding
+// come from a zero pair in global memory; the pair that holds a diagonal element of an odd-length row ends in the pad zero
+// its producer wrote, sv_tri_off).  23 wave instructions per matrix at M = 64.
+template <int NT>
+__device__ __forceinline__ void stage_matrix_dma_tp(double* dst, const double* src, int M, int tid, int nth) {
+  constexpr int TOT2 = NT * (NT + 1) / 2 * SV_TSZ / 2;       // pairs of doubles in the image
+  const int lane = tid & 63, wave = tid >> 6, nw = nth >> 6;
+  for (int cc = wave; cc * 64 < TOT2; cc += nw) {
+    const int e2 = cc * 64 + lane;
+    if (e2 < TOT2) {
+      const int t = e2 / (SV_TSZ / 2), rem = e2 - t * (SV_TSZ / 2), it = rem / (SV_TS / 2), jp = rem - it * (SV_TS / 2);
+      int a, b;
+      sv_tile_ab(t, a, b);
+      const int i = 16 * a + it, j = 16 * b + 2 * jp;
+      const double* g = (jp < 8 && i < M && j <= i) ? src + sv_tri_off(i) + j : sv_zero_pad;
+      __builtin_amdgcn_global_load_lds((const void*)g, (__attribute__((address_space(3))) void*)(dst + cc * 128), 16, 0, 0);
+    }
+  }
+}
+
 template <int NT>
 __device__ __forceinline__ void load_factors(const EngineView& ev, const LatentMeta& m, int r, double* Li,
                                              double* Vl, double* ul, double* zl, bool want_v) {
@@ -169,7 +233,8 @@ __device__ __forceinline__ void load_factors(const EngineView& ev, const LatentM
 // the inducing points' phases are in LDS and synchronised by the caller.  DYN = false: wave w takes tiles w, w + NWB, ...;
 // DYN = true: the block's waves draw tiles from the LDS counter `next` (zeroed by the caller in front of its barrier) --
 // for blocks whose waves do not start the loop together (k_front: one wave carries a rider).
-template <int NT, int KT, bool DYN>
+// TP: Li / Vl are tile-packed lower triangles (sv_tidx) instead of MP x LD images.
+template <int NT, int KT, bool DYN, bool TP = false>
 __device__ __forceinline__ void times_tiles(const KPar& p, const double* Li, const double* Vl, const double* ul,
                                             const double* zl, const double* szl, const double* czl, const double* times,
                                             long long t0, int nt, double* mu_out, double* var_out, long long obase,
@@ -223,7 +288,8 @@ __device__ __forceinline__ void times_tiles(const KPar& p, const double* Li, con
         }
       }
     d4 Kw[NT];
-    tri_chain<NT, 0>(Kw, Li, LD, X0, li, lg);
+    if (TP) tri_chain_tp<NT, 0>(Kw, Li, X0, li * SV_TS + lg, lg * SV_TS + li);
+    else tri_chain<NT, 0>(Kw, Li, LD, X0, li, lg);
     double pm = 0.0, n2 = 0.0, tt = 0.0;
 #pragma unroll
     for (int a = 0; a < NT; ++a)
@@ -234,7 +300,8 @@ __device__ __forceinline__ void times_tiles(const KPar& p, const double* Li, con
       }
     if (want_var) {
       d4 T[NT];
-      tri_chain<NT, 1>(T, Vl, LD, Kw, li, lg);
+      if (TP) tri_chain_tp<NT, 1>(T, Vl, Kw, li * SV_TS + lg, lg * SV_TS + li);
+      else tri_chain<NT, 1>(T, Vl, LD, Kw, li, lg);
 #pragma unroll
       for (int a = 0; a < NT; ++a)
 #pragma unroll
@@ -406,9 +473,13 @@ __global__ __launch_bounds__(64 * NT) void k_prep_mfma(EngineView ev, LatentPtrT
 // per SIMD that are in their tile loops: the kernel is issue-bound, and the item loop only added registers (the compiler
 // hoists every fp64 polynomial constant of the body out of such a loop: 94 -> 177 VGPRs).
 // grid = R K blocks of 256 threads; dynamic LDS sv_front_lds(NT).
+// M > 32: the two factors as tile-packed lower triangles (46 KB instead of 68 at M = 64: three blocks per CU, what the kernel's
+// registers allow, instead of two -- round 5)
+__host__ __device__ constexpr bool sv_front_tp(int NT) { return NT >= 3; }
 __host__ __device__ constexpr size_t sv_front_lds(int NT) {
   const size_t MP = 16 * (size_t)NT, LD = MP + 2;
-  return (2 * MP * LD + 5 * MP + 6 + 64 + SV_PRE_LDS) * 8;
+  const size_t mat = sv_front_tp(NT) ? (size_t)(NT * (NT + 1) / 2) * SV_TSZ : MP * LD;
+  return (2 * mat + 5 * MP + 6 + 64 + SV_PRE_LDS) * 8;
 }
 #ifndef SV_FRONT_CLK
 #define SV_FRONT_CLK 0    // diagnosis builds only: 1 = two threads of two blocks print cycle stamps of the phases (device printf)
@@ -419,14 +490,17 @@ template <int NT, int KT>
 __device__ __forceinline__ void front_body(const EngineView& ev, const LatentPtrTable& ptab, const LatentMeta& m, int r, int k,
                                            int want_w, double* sm) {
   constexpr int MP = 16 * NT, LD = MP + 2, NTH = 256;
+  constexpr bool TP = sv_front_tp(NT);
+  constexpr int MAT = TP ? NT * (NT + 1) / 2 * SV_TSZ : MP * LD, TS = SV_TS, TSZ = SV_TSZ;
   constexpr int PW = (NT < 4) ? NT : 0;            // the wave that carries the mean chain
   const int tid = threadIdx.x;
   const int item = r * ev.K + k, lane = tid & 63, wave = tid >> 6, li = lane & 15, lg = lane >> 4;
+  const int orm = li * TS + lg, otr = lg * TS + li;
   const int M = m.M;
   const LatentPtrs& pt = ptab.p[k];
-  double* Li = sm;               // MP*LD
-  double* Ls = Li + MP * LD;     // MP*LD: L_S, then Vt
-  double* ul = Ls + MP * LD;
+  double* Li = sm;               // MAT
+  double* Ls = Li + MAT;         // MAT: L_S, then Vt
+  double* ul = Ls + MAT;
   double* zl = ul + MP;
   double* szl = zl + MP;
   double* czl = szl + MP;
@@ -463,18 +537,22 @@ __device__ __forceinline__ void front_body(const EngineView& ev, const LatentPtr
       }
     }
   } else {
-    stage_matrix_dma<NT>(Li, ev.Linv + base, M, tid, NTH);     // (lands behind the loads below; the barrier waits)
-    for (int e0 = tid; e0 < MP * MP; e0 += 4 * NTH) {      // L_S from the row-major tril vector, four loads in flight
+    stage_matrix_dma_tp<NT>(Li, ev.Linv + base, M, tid, NTH);     // (lands behind the loads below; the barrier waits)
+    constexpr int NE = NT * (NT + 1) / 2 * 256;
+    for (int e0 = tid; e0 < NE; e0 += 4 * NTH) {           // L_S from the row-major tril vector, four loads in flight
       double v[4];
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
-        const int e = e0 + u * NTH, i = e / MP, j = e % MP;
-        v[u] = (e < MP * MP && i < M && j <= i) ? cv[i * (i + 1) / 2 + j] : 0.0;
+        const int e = e0 + u * NTH, t = e >> 8, it = (e >> 4) & 15, jt = e & 15;
+        int a, b;
+        sv_tile_ab(t, a, b);
+        const int i = 16 * a + it, j = 16 * b + jt;
+        v[u] = (e < NE && i < M && j <= i) ? cv[i * (i + 1) / 2 + j] : 0.0;
       }
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
-        const int e = e0 + u * NTH, i = e / MP, j = e % MP;
-        if (e < MP * MP) Ls[i * LD + j] = v[u];
+        const int e = e0 + u * NTH, t = e >> 8, it = (e >> 4) & 15, jt = e & 15;
+        if (e < NE) Ls[t * TSZ + it * TS + jt] = v[u];
       }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the DMA pieces of Linv have landed
@@ -498,8 +576,16 @@ __device__ __forceinline__ void front_body(const EngineView& ev, const LatentPtr
 #pragma unroll
     for (int b = 0; b < NT; ++b)
 #pragma unroll
-      for (int q = 0; q < 4; ++q) P[b][q] = Ls[(16 * b + 4 * q + lg) * LD + 16 * c + li];
-    tri_chain<NT, 0>(V, Li, LD, P, li, lg);
+      for (int q = 0; q < 4; ++q) {
+        if (TP) {                // L_S[:, panel c]: tiles (b, c), b >= c
+          const double v = Ls[((b >= c) ? (b * (b + 1) / 2 + c) : 0) * TSZ + otr + 4 * q * TS];
+          P[b][q] = (b >= c) ? v : 0.0;
+        } else {
+          P[b][q] = Ls[(16 * b + 4 * q + lg) * LD + 16 * c + li];
+        }
+      }
+    if (TP) tri_chain_tp<NT, 0>(V, Li, P, orm, otr);
+    else tri_chain<NT, 0>(V, Li, LD, P, li, lg);
     if (wave < NT) {
 #pragma unroll
       for (int a = 0; a < NT; ++a)
@@ -514,9 +600,15 @@ __device__ __forceinline__ void front_body(const EngineView& ev, const LatentPtr
     for (int b = 0; b < NT; ++b)
 #pragma unroll
       for (int q = 0; q < 4; ++q) Pm[b][q] = (li == 0) ? ml[16 * b + 4 * q + lg] : 0.0;
-    tri_chain<NT, 0>(U, Li, LD, Pm, li, lg);
-    tri_chain<NT, 1>(A, Li, LD, U, li, lg);
-    if (lane < M) part += -2.0 * log(Li[lane * LD + lane]) - 2.0 * log(fabs(Ls[lane * LD + lane]));
+    if (TP) {
+      tri_chain_tp<NT, 0>(U, Li, Pm, orm, otr);
+      tri_chain_tp<NT, 1>(A, Li, U, orm, otr);
+    } else {
+      tri_chain<NT, 0>(U, Li, LD, Pm, li, lg);
+      tri_chain<NT, 1>(A, Li, LD, U, li, lg);
+    }
+    const int dgo = TP ? sv_tp(lane < MP ? lane : 0, lane < MP ? lane : 0) : lane * LD + lane;
+    if (lane < M) part += -2.0 * log(Li[dgo]) - 2.0 * log(fabs(Ls[dgo]));
   }
   SV_FCK(3);
   __syncthreads();               // every wave is done reading L_S: its buffer becomes Vt
@@ -527,7 +619,11 @@ __device__ __forceinline__ void front_body(const EngineView& ev, const LatentPtr
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         const int i = 16 * a + 4 * q + lg, j = 16 * c + li;
-        Ls[i * LD + j] = V[a][q];                                               // (exact zeros above the diagonal and in the padding)
+        if (TP) {
+          if (a >= c) Ls[sv_tidx(a, c) * TSZ + otr + 4 * q * TS] = V[a][q];      // (tiles on and below the diagonal; the rest of Vt is zero)
+        } else {
+          Ls[i * LD + j] = V[a][q];                                             // (exact zeros above the diagonal and in the padding)
+        }
         if (i < M && j <= i) ev.Vt[base + sv_tri_off(i) + j] = V[a][q];
         if (i < M && j == i && !(i & 1)) ev.Vt[base + sv_tri_off(i) + i + 1] = 0.0;   // the pad of an odd-length row
       }
@@ -558,7 +654,7 @@ __device__ __forceinline__ void front_body(const EngineView& ev, const LatentPtr
   // ---- the class path's W on the last wave, ahead of its share of the tiles
   if (want_w && wave == 3) spike_pre_item(ev, item, r, k, m, (lane < M) ? wsc[lane] : 0.0, wsc + 64);
   // ---- quadrature statistics [r][k][q]
-  times_tiles<NT, KT, true>(p, Li, Ls, ul, zl, szl, czl, ev.tq, (long long)r * ev.Q, ev.Q, ev.muq, ev.varq,
+  times_tiles<NT, KT, true, TP>(p, Li, Ls, ul, zl, szl, czl, ev.tq, (long long)r * ev.Q, ev.Q, ev.muq, ev.varq,
                             ((long long)r * ev.K + k) * ev.Q, 1LL, 1, next, tid);
   if (SV_FRONT_CLK) {
     SV_FCK(6);
