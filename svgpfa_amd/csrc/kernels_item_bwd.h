@@ -318,7 +318,7 @@ __device__ SV_GATHER_ATTR void gather_item_inputs(const EngineView& ev, const La
   } else if (cls) {
     const SpikeItem it = ev.sitem[r * ev.K + k];
     const int H = it.H;
-    const bool TW = (mask & 14u) != 0 && m.ktype == SV_PERIODIC;      // what the class kernels produced for this mask
+    const bool TW = (mask & 4u) != 0 && m.ktype == SV_PERIODIC;       // what the class kernels produced for this mask (time-weighted moments: kernel-parameter gradient only)
     const int NV = TW ? 4 : 2, ncol = NV * (H + 1);
     double* Fs = scr;                         // SV_ACOLS moments
     double* cf = scr + SV_ACOLS;              // 3 x (SV_FH + 1) coefficients c_n | g_n | e_n

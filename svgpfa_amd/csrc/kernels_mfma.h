@@ -942,8 +942,8 @@ __global__ __launch_bounds__(512) void k_quad_ell_mfma(EngineView ev, const doub
     const int item = ((int)blockIdx.x - nell) * nwb + wave;
     if (item < ncomb) {
       double* lds = sm + wave * SV_COMB_LDS;
-      if (comb_full) spike_comb_item<true>(ev, item, lds);
-      else spike_comb_item<false>(ev, item, lds);
+      if (comb_full & 1) spike_comb_item<true>(ev, item, lds, (comb_full >> 1) & 1);      // (bit 0: full, bit 1: time-weighted moments)
+      else spike_comb_item<false>(ev, item, lds, 0);
     }
     return;
   }

@@ -44,6 +44,7 @@
 template <int DC>
 __device__ __forceinline__ void cls_pair_rider(const EngineView& ev, const double* __restrict__ C, int full, double* lds,
                                                int worker, int nworkers) {
+  full &= 1;
   if (DC == 1) pair_pass<true, double, true>(ev, C, lds, worker, nworkers);        // (DC == 1 implies full and dC wanted)
   else if (full) pair_pass<true, double, false>(ev, C, lds, worker, nworkers);
   else pair_pass<false, double, true>(ev, C, lds, worker, nworkers);
@@ -333,12 +334,15 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 8))) void
   const SpikeClassTab* cls = ev.cls;
   const int ncls = cls->ncls;
   int mine = 0;                                  // classes this kernel serves (scalar loop, ncls <= 32)
-  for (int g = 0; g < ncls; ++g) mine += ((full && cls->type[g] == SV_PERIODIC) == (NV == 4)) ? 1 : 0;
+  // full: bit 0 = Z / theta / C gradient sums wanted, bit 1 = time-weighted moments wanted (kernel-parameter gradient): only
+  // then do periodic classes take the NV = 4 pass
+  const int tw = (full >> 1) & 1;
+  for (int g = 0; g < ncls; ++g) mine += ((tw && cls->type[g] == SV_PERIODIC) == (NV == 4)) ? 1 : 0;
   const int nitems = ev.ntiles * mine;           // ntiles K < 2^31 is checked by the host
   for (int w = blockIdx.x; w < nitems; w += gridDim.x) {
     int j = w % mine, g = 0;
     for (;; ++g) {
-      if ((full && cls->type[g] == SV_PERIODIC) == (NV == 4)) {
+      if ((tw && cls->type[g] == SV_PERIODIC) == (NV == 4)) {
         if (j == 0) break;
         --j;
       }
@@ -365,7 +369,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 8))) void
   const int nitems = ev.ntiles * ncls;
   for (int w = blockIdx.x; w < nitems; w += gridDim.x) {
     const int g = w % ncls;
-    if (full && cls->type[g] == SV_PERIODIC) cls_item<4, DC>(ev, C, cls, g, w / ncls, Ut, dcl);
+    if ((full & 2) && cls->type[g] == SV_PERIODIC) cls_item<4, DC>(ev, C, cls, g, w / ncls, Ut, dcl);
     else cls_item<2, DC>(ev, C, cls, g, w / ncls, Ut, dcl);
   }
   if (pair) {
@@ -408,7 +412,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   const int nwork = nwb * 4;
   for (int w = bid * 4 + wave; w < nitems; w += nwork) {
     const int g = w % ncls;
-    if (full && cls->type[g] == SV_PERIODIC) cls_item<4, DC>(ev, C, cls, g, w / ncls, Ut, dcl);
+    if ((full & 2) && cls->type[g] == SV_PERIODIC) cls_item<4, DC>(ev, C, cls, g, w / ncls, Ut, dcl);
     else cls_item<2, DC>(ev, C, cls, g, w / ncls, Ut, dcl);
   }
   if (pair) {                  // (the worker's slice holds sv_pair_lds_doubles(true) doubles: static_assert below)
@@ -426,7 +430,7 @@ static_assert(SV_CLS_SLICE >= sv_pair_lds_doubles(true), "a class worker's LDS s
 //   T1 (periodic) = sum_j a_j sum_n e_n [cos(n phi_j) Bt_n - sin(n phi_j) At_n - z_j Ss]
 // -> P0t / P1t [r][sum M], Tt [r][k][2]: what k_item_bwd's gather reads for this item.  grid = R K blocks of 64 threads.
 template <bool FULL>
-__global__ __launch_bounds__(64) void k_spike_comb(EngineView ev) {
+__global__ __launch_bounds__(64) void k_spike_comb(EngineView ev, int tw) {
   __shared__ double lds[SV_COMB_LDS];
-  spike_comb_item<FULL>(ev, blockIdx.x, lds);
+  spike_comb_item<FULL>(ev, blockIdx.x, lds, tw);
 }

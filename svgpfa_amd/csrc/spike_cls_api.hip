@@ -33,9 +33,9 @@ hipError_t sv_launch_spike_cls(const EngineView& v, const double* C, int nv, int
   return hipGetLastError();
 }
 
-hipError_t sv_launch_spike_comb(const EngineView& v, bool full, hipStream_t s) {
-  if (full) hipLaunchKernelGGL(k_spike_comb<true>, dim3(v.R * v.K), dim3(64), 0, s, v);
-  else hipLaunchKernelGGL(k_spike_comb<false>, dim3(v.R * v.K), dim3(64), 0, s, v);
+hipError_t sv_launch_spike_comb(const EngineView& v, int full, hipStream_t s) {      // full: bit 0 full, bit 1 time-weighted moments
+  if (full & 1) hipLaunchKernelGGL(k_spike_comb<true>, dim3(v.R * v.K), dim3(64), 0, s, v, (full >> 1) & 1);
+  else hipLaunchKernelGGL(k_spike_comb<false>, dim3(v.R * v.K), dim3(64), 0, s, v, 0);
   return hipGetLastError();
 }
 

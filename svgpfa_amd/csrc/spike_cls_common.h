@@ -309,8 +309,11 @@ __device__ inline void spike_pre_item(const EngineView& ev, int item, int r, int
 // body of k_spike_comb (kernels_spike_cls.h), and of the rider blocks of k_quad_ell_mfma that do the same work inside the
 // ELL kernel's launch at full size (kernels_mfma.h).
 #define SV_COMB_LDS (SV_ACOLS + 3 * (SV_FH + 1))
+// tw: the class kernels carried the time-weighted moments of periodic classes (four values per harmonic instead of two):
+// only when the gradient wrt the kernel parameters is wanted -- the period's is their one consumer (T1); round 5: until
+// then every pass with any gradient carried them, at half again the price per spike and harmonic.
 template <bool FULL>
-__device__ __forceinline__ void spike_comb_item(const EngineView& ev, const int item, double* lds) {
+__device__ __forceinline__ void spike_comb_item(const EngineView& ev, const int item, double* lds, const int tw) {
   double* Fs = lds;                        // SV_ACOLS moments
   double* cf = lds + SV_ACOLS;             // 3 x (SV_FH + 1) coefficients
   const int lane = threadIdx.x & 63, K = ev.K;
@@ -322,7 +325,7 @@ __device__ __forceinline__ void spike_comb_item(const EngineView& ev, const int 
   const int H = it.H;
   const double sc = it.sc, t0 = it.t0;
   const KPar p = make_kpar(m, ev.theta + 2 * k);
-  const bool TW = FULL && m.ktype == SV_PERIODIC;
+  const bool TW = FULL && tw && m.ktype == SV_PERIODIC;
   const int NV = TW ? 4 : 2, ncol = NV * (H + 1);
   const int tl0 = ev.tile_first[r], tl1 = ev.tile_first[r + 1];
   double zj = t0, aj = 0.0;

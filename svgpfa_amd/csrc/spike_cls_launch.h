@@ -15,7 +15,9 @@ hipError_t sv_launch_spike_pre(const EngineView& v, hipStream_t s);
 // nv: 4 / 2 = the kernel of the classes with / without time-weighted moments, 0 = both kinds in one launch; dc: the rows'
 // dC partials wanted (needs W); pair: the pair-by-pair pass (fp64) rides behind the class items (nv = 2 or 0 only)
 hipError_t sv_launch_spike_cls(const EngineView& v, const double* C, int nv, int dc, int full, int pair, unsigned grid, hipStream_t s);
-hipError_t sv_launch_spike_comb(const EngineView& v, bool full, hipStream_t s);
+hipError_t sv_launch_spike_comb(const EngineView& v, int full, hipStream_t s);
+// `full` of the class kernels and the combine is a bit set: bit 0 = gradient sums wanted (Z / theta / C), bit 1 = the
+// time-weighted moments of periodic classes wanted (kernel-parameter gradient: the period's T1 is their only consumer)
 // k_ell_cls: the quadrature ELL blocks and the class items in one launch (small shards, fp64); ks = k-steps of the ELL
 // product (1 .. 16), lds_ell = dynamic LDS the ELL roles need.  Returns hipSuccess or the launch / attribute error.
 hipError_t sv_launch_ell_cls(const EngineView& v, const double* C, const double* d, int ks, int dc, int want_sums, int want_lat,

@@ -851,26 +851,27 @@ static bool pair_rides(const svgpfa_engine* e) {
 }
 
 static int launch_spike_pass(svgpfa_engine* e, hipStream_t sk, bool full, bool want_c, const double* C, bool have_w,
-                              bool comb_rides = false) {
+                              bool comb_rides = false, bool want_tw = true) {
+  const int fl = (full ? 1 : 0) | ((full && want_tw) ? 2 : 0);       // the class kernels' / combine's `full` bit set
   EngineView& v = e->v;
   const unsigned gc = (unsigned)std::min<long long>((long long)v.ntiles * v.K, e->grid_cls);
   const bool ride = pair_rides(e);
   if (v.ntiles > 0 && e->cls_on) {
     const bool fused = cls_one_launch(e);
-    const bool tw = !fused && full && v.ntype[SV_PERIODIC] > 0;
+    const bool tw = !fused && (fl & 2) && v.ntype[SV_PERIODIC] > 0;      // a launch for the classes with time-weighted moments
     const int dc = (full && want_c) ? 1 : 0;
     if (dc && !have_w) HIPCHK(e, sv_launch_spike_pre(v, sk));
     // a rider needs workers for the pair items even when the class items are few: the grid of the pair pass's own launch
     const long long npair = (long long)v.nchunks * v.K;
     const unsigned gr = ride ? std::max(gc, (unsigned)std::min<long long>((npair + 7) & ~7LL, e->grid_cls)) : gc;
     if (fused) {
-      HIPCHK(e, sv_launch_spike_cls(v, C, 0, dc, (dc || full) ? 1 : 0, ride ? 1 : 0, gr, sk));
+      HIPCHK(e, sv_launch_spike_cls(v, C, 0, dc, (dc || full) ? fl : 0, ride ? 1 : 0, gr, sk));
     } else {
-      if (tw) HIPCHK(e, sv_launch_spike_cls(v, C, 4, dc, 1, 0, gc, sk));
-      HIPCHK(e, sv_launch_spike_cls(v, C, 2, dc, (dc || full) ? 1 : 0, ride ? 1 : 0, gr, sk));
+      if (tw) HIPCHK(e, sv_launch_spike_cls(v, C, 4, dc, fl, 0, gc, sk));
+      HIPCHK(e, sv_launch_spike_cls(v, C, 2, dc, (dc || full) ? fl : 0, ride ? 1 : 0, gr, sk));
     }
   }
-  if (!v.comb_fold && e->cls_on && !comb_rides) HIPCHK(e, sv_launch_spike_comb(v, full, sk));
+  if (!v.comb_fold && e->cls_on && !comb_rides) HIPCHK(e, sv_launch_spike_comb(v, fl, sk));
   if (!ride) {
     launch_pair_pass(e, sk, full, want_c, C);
     HIPCHK(e, hipGetLastError());
@@ -924,23 +925,24 @@ static int enqueue_elbo(svgpfa_engine* e, const PtrTable& pt, const ElboPlan& pl
     const int evp = timing_begin(e, 0, sm);
     if (merged) {
       const bool full = pl.full, want_c = (mask & 2u) != 0;
+      const int fl = (full ? 1 : 0) | ((full && (mask & 4u)) ? 2 : 0);      // bit 1: time-weighted moments (kernel-parameter gradient)
       const int dc = (full && want_c) ? 1 : 0;          // (have_w holds whenever dc does: k_front made W)
       const unsigned workers = (unsigned)std::min<long long>((long long)v.ntiles * v.K, e->grid_cls);
       const size_t lds_ell = pl.want_lat ? std::max(lds_qell_mfma(e, 0), lds_qell_mfma(e, 1)) : lds_qell_mfma(e, 0);
       const bool ride = pair_rides(e);
       HIPCHK(e, sv_launch_ell_cls(ve, C, d, e->KKT, dc, want_c ? 1 : 0, pl.want_lat ? 1 : 0, parts_m, e->ell_lc[0], e->ell_lc[1],
-                                  full ? 1 : 0, ride ? 1 : 0, workers, lds_ell, sm));
-      if (!v.comb_fold) HIPCHK(e, sv_launch_spike_comb(v, full, sm));
+                                  fl, ride ? 1 : 0, workers, lds_ell, sm));
+      if (!v.comb_fold) HIPCHK(e, sv_launch_spike_comb(v, fl, sm));
       if (!ride) launch_pair_pass(e, sm, full, want_c, C);
     } else {
-      if ((rc = launch_spike_pass(e, sm, pl.full, (mask & 2u) != 0, C, have_w, comb_rides))) return rc;
+      if ((rc = launch_spike_pass(e, sm, pl.full, (mask & 2u) != 0, C, have_w, comb_rides, (mask & 4u) != 0))) return rc;
     }
     timing_end(e, evp, sm);
   }
   // ---- quadrature chain (f64 MFMA): posterior statistics at the nodes -> ELL term and its adjoints
   if (!e->front && (rc = launch_times_quad(e, sm))) return rc;
   if (!merged && (rc = launch_quad_ell(e, sm, C, d, (mask & 2u) ? 1 : 0, pl.want_lat ? 1 : 0, comb_rides ? v.R * v.K : 0,
-                                       pl.full ? 1 : 0))) return rc;
+                                       (pl.full ? 1 : 0) | ((pl.full && (mask & 4u)) ? 2 : 0)))) return rc;
   // ---- per-item adjoints + backward + the fixed-order cross-trial reductions in one kernel
   const int evb = timing_begin(e, 1, sm);
   if (mask & (4u | 8u)) {
@@ -1029,7 +1031,7 @@ int svgpfa_freeze_stats(svgpfa_engine* e, const double* const* mean, const doubl
   if ((rc = launch_times_quad(e, e->stream))) return rc;
   // the per-neuron sums of the spike means are the spike part of dC, which the spike-time pass makes (cosine series:
   // ~0.3 ms at the north-star size against 2 ms for the posterior mean and variance at every spike)
-  if (v.nchunks > 0 && (rc = launch_spike_pass(e, e->stream, true, true, C, false))) return rc;
+  if (v.nchunks > 0 && (rc = launch_spike_pass(e, e->stream, true, true, C, false, false, false))) return rc;     // (dC rows only: no time-weighted moments)
   e->p0_token = 0;                     // that pass overwrote the reusable spike sums
   hipLaunchKernelGGL(k_mseg_from_dc, dim3((v.N * v.K + SV_FS_OUT - 1) / SV_FS_OUT), dim3(256), 0, e->stream, v);
   HIPCHK(e, hipGetLastError());
