@@ -485,15 +485,20 @@ def test_cfg3_shape_golden(golden_dir):
     assert rel_err(out["g_d"], ref["g_d"]) < TOL_A
 
 
-def test_cfg3_full_size_against_oracle_blocks():
+@pytest.mark.parametrize("spread", [False, True], ids=["survey-theta", "theta-spread"])
+def test_cfg3_full_size_against_oracle_blocks(spread):
     """BASELINE config 3 at FULL size (500 x 200 x 10 x 32, 2.0e6 spikes): one engine evaluation against the oracle run
     in 100-trial blocks (the bound and the shared gradients add over trials, per-trial gradients concatenate).
     north_star asks for 1e-6 on the ELBO; asserted here: TOL_S = 1e-9 on ELBO / ELL / KL, TOL_A = 1e-7 on every
-    gradient array."""
+    gradient array.  theta-spread: the kernel parameters a kernel M-step leaves (synthetic.spread_theta) -- seven classes
+    in the spike pass, i.e. the full-size class kernels (k_spike_cls<4, 1> / <2, 1>, the combine's riders in the ELL launch)
+    with five single-member periodic classes and two RBF classes, against the oracle at the size they run at."""
     from oracle import svgpfa_oracle as orc
     torch.set_num_threads(max(1, min(16, len(__import__("os").sched_getaffinity(0)))))
-    prob = synthetic.make_config("cfg3")
+    prob = synthetic.make_config("cfg3", theta_spread=spread)
     eng, P = _engine(prob)
+    if spread:
+        assert all(h != -1 for h in eng.series_harmonics())       # every latent on the class path
     out = _eval(eng, P, 15)
     eng.close()
     K, R = prob["K"], prob["R"]

@@ -5,5 +5,5 @@ for c in "$@"; do
   IFS=: read lib envs worlds <<< "$c"
   ( [ "$lib" != "-" ] && export SVGPFA_LIB="$PWD/$lib"
     if [ "$envs" != "-" ]; then for kv in ${envs//,/ }; do export "$kv"; done; fi
-    python tests/tools/shard_floor.py $worlds 2>/dev/null | grep "^world" | sed "s|^|$c  |" )
+    python tests/tools/shard_floor.py $worlds 2>/dev/null | grep " world " | sed "s|^|$c  |" )
 done
