@@ -902,16 +902,6 @@ __device__ __forceinline__ void item_bwd_body(const EngineView& ev, const int r,
           gu = fma(gm4[q], KwT[q], gu);
           gK[q] = gv4[q] * KwT[q];
         }
-        // the diagonal tile of this wave's column of Gt needs no other wave's values: here, in front of the barrier, for every
-        // wave but the last -- whose whitened tile is the longest chain of this stage (c + 1 products) while its column is
-        // the shortest of the next (stage 2 / stage 3 tile products per wave at NT = 4: 6 7 8 8 / 3 2 1 1 instead of 5 6 7 8 / 4 3 2 1)
-#pragma unroll
-        for (int a = 0; a < NT - 1; ++a) {
-          if (a == c) {
-#pragma unroll
-            for (int q = 0; q < 4; ++q) GW[a] = __builtin_amdgcn_mfma_f64_16x16x4f64(KwT[q], gK[q], GW[a], 0, 0, 0);
-          }
-        }
         if (FULL) {
           // adjoint sums of this wave's inducing points (the raw tile and E kappa are complete; nothing here waits for
           // the other waves, so it sits in front of the barrier)
@@ -941,7 +931,7 @@ __device__ __forceinline__ void item_bwd_body(const EngineView& ev, const int r,
         const double* kr = Kb + (DB ? (s & 1) * 2 * NT * 256 : 0) + lane;
 #pragma unroll
         for (int a = 0; a < NT; ++a) {
-          if (a > c || (a == NT - 1 && c == NT - 1)) {
+          if (a >= c) {
 #pragma unroll
             for (int q = 0; q < 4; ++q)
               GW[a] = __builtin_amdgcn_mfma_f64_16x16x4f64(kr[a * 256 + q * 64], gK[q], GW[a], 0, 0, 0);
