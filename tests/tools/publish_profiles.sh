@@ -14,4 +14,5 @@ grep '^{' $e/bench_spread.json > profiles/${v}_bench_theta_spread.json
 cp $e/timeline8.txt profiles/${v}_shard8_timeline.txt
 cp $e/timeline4.txt profiles/${v}_shard4_timeline.txt
 cp $e/spread_trace/*/*kernel_stats.csv profiles/${v}_theta_spread_kernel_stats.csv
+[ -d $e/cfg5_trace ] && cp $e/cfg5_trace/*/*kernel_stats.csv profiles/${v}_cfg5_mixed_kernel_stats.csv
 ls profiles | grep -c "^${v}_"
