@@ -936,7 +936,11 @@ __global__ __launch_bounds__(512) void k_quad_ell_mfma(EngineView ev, const doub
                                                        int want_sums, int write_ell, int parts, int lc0, int lc1,
                                                        int ncomb, int comb_full) {
   extern __shared__ double sm[];
-  const int nell = ev.R * parts * (ROLE == 2 ? 2 : 1);
+  // ROLE 2 without dC / dd (the E-step closure): no role-0 blocks at all -- role 1 evaluates every E[q, n] as well, so it
+  // writes the ELL value itself (round 5: until then role 0 ran its h products and exponentials for the sake of that one sum,
+  // a third of the launch)
+  const int nb0 = (ROLE == 2 && !want_sums) ? 0 : ev.R * parts;
+  const int nell = nb0 + (ROLE == 2 ? ev.R * parts : 0);
   if ((int)blockIdx.x >= nell) {                       // rider blocks (only launched with ncomb > 0)
     const int nwb = (int)blockDim.x >> 6, wave = (int)threadIdx.x >> 6;
     const int item = ((int)blockIdx.x - nell) * nwb + wave;
@@ -948,11 +952,10 @@ __global__ __launch_bounds__(512) void k_quad_ell_mfma(EngineView ev, const doub
     return;
   }
   if (ROLE == 2) {
-    const int nb = ev.R * parts;
-    if ((int)blockIdx.x < nb)
+    if ((int)blockIdx.x < nb0)
       quad_ell_mfma_body<KS, 0, T>(ev, C, d, want_sums, 1, parts, lc0, blockIdx.x, sm);
     else
-      quad_ell_mfma_body<KS, 1, T>(ev, C, d, 1, 0, parts, lc1, blockIdx.x - nb, sm);
+      quad_ell_mfma_body<KS, 1, T>(ev, C, d, 1, want_sums ? 0 : 1, parts, lc1, blockIdx.x - nb0, sm);
   } else {
     quad_ell_mfma_body<KS, (ROLE == 2 ? 0 : ROLE), T>(ev, C, d, want_sums, write_ell, parts, ROLE == 0 ? lc0 : lc1,
                                                        blockIdx.x, sm);

@@ -398,9 +398,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   // 42.4 against 43.7 us, 4-way 68 against 55: the ELL blocks then start behind the workers on the same SIMDs.)
   const int nwb = (int)gridDim.x - nell, bid = (int)blockIdx.x - nell;
   if (bid < 0) {
-    const int nb = ev.R * parts, blk = (int)blockIdx.x;
+    // (latent adjoints without dC / dd -- the E-step closure: role-1 blocks only, they write the ELL value: kernels_mfma.h)
+    const int nb = (want_lat && !want_sums) ? 0 : ev.R * parts, blk = (int)blockIdx.x;
     if (blk < nb) quad_ell_mfma_body<KS, 0, double>(ev, C, d, want_sums, 1, parts, lc0, blk, sm);
-    else quad_ell_mfma_body<KS, 1, double>(ev, C, d, 1, 0, parts, lc1, blk - nb, sm);
+    else quad_ell_mfma_body<KS, 1, double>(ev, C, d, 1, want_sums ? 0 : 1, parts, lc1, blk - nb, sm);
     return;
   }
   const int wave = threadIdx.x >> 6;

@@ -43,7 +43,7 @@ template <int KS, int DC>
 static hipError_t launch_ell_cls_t(const EngineView& v, const double* C, const double* d, int want_sums, int want_lat, int parts,
                                    int lc0, int lc1, int full, int pair, unsigned workers, size_t lds_ell, hipStream_t s) {
   const size_t lds = std::max(lds_ell, (size_t)4 * SV_CLS_SLICE * sizeof(double));
-  int nell = v.R * parts * (want_lat ? 2 : 1);
+  int nell = v.R * parts * ((want_lat && want_sums) ? 2 : 1);      // (latent adjoints alone: role-1 blocks only)
 #ifdef SV_ELLCLS_DIAG     // diagnosis BUILDS only (results are wrong; tests/tools/ellcls_diag.sh): 1 launches the ELL blocks alone, 2 the class workers alone
   if (SV_ELLCLS_DIAG == 1) workers = 0;
   if (SV_ELLCLS_DIAG == 2) nell = 0;

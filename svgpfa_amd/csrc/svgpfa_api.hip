@@ -722,8 +722,8 @@ static int fill_ptrs(svgpfa_engine* e, PtrTable& pt, const double* const* mean, 
 static int launch_quad_ell(svgpfa_engine* e, hipStream_t st, const double* C, const double* d, int want_cd, int want_lat,
                            int ncomb = 0, int comb_full = 0) {
   EngineView& v = e->v;
-  // role 0 (dC, dd and the ELL value) always runs: its column sums give sum E; role 1 (latent adjoints) rides in the
-  // same launch when some latent-side gradient is wanted
+  // role 0 (dC, dd and the ELL value; its column sums give sum E) and role 1 (latent adjoints) share a launch when both are
+  // wanted; the latent adjoints alone (E-step closure) are role-1 blocks only, which then write the ELL value themselves
   dim3 gm(v.R * e->ell_parts), bm(64 * e->ell_nw);
   const unsigned nrb = ncomb > 0 ? (unsigned)((ncomb + e->ell_nw - 1) / e->ell_nw) : 0u;      // rider blocks
   const size_t lrid = ncomb > 0 ? (size_t)e->ell_nw * SV_COMB_LDS * sizeof(double) : 0;
@@ -731,10 +731,10 @@ static int launch_quad_ell(svgpfa_engine* e, hipStream_t st, const double* C, co
   if (want_lat) {
     const size_t l2 = std::max(std::max(lds_qell_mfma(e, 0), lds_qell_mfma(e, 1)), lrid);
     if (f32) {
-      DISPATCH_KS(e->KKT, hipLaunchKernelGGL((k_quad_ell_mfma<KS_, 2, float>), dim3(2 * gm.x + nrb), bm, l2, st, v, C, d,
+      DISPATCH_KS(e->KKT, hipLaunchKernelGGL((k_quad_ell_mfma<KS_, 2, float>), dim3((want_cd ? 2 : 1) * gm.x + nrb), bm, l2, st, v, C, d,
                                              want_cd, 1, e->ell_parts, e->ell_lc[0], e->ell_lc[1], ncomb, comb_full));
     } else {
-      DISPATCH_KS(e->KKT, hipLaunchKernelGGL((k_quad_ell_mfma<KS_, 2, double>), dim3(2 * gm.x + nrb), bm, l2, st, v, C, d,
+      DISPATCH_KS(e->KKT, hipLaunchKernelGGL((k_quad_ell_mfma<KS_, 2, double>), dim3((want_cd ? 2 : 1) * gm.x + nrb), bm, l2, st, v, C, d,
                                              want_cd, 1, e->ell_parts, e->ell_lc[0], e->ell_lc[1], ncomb, comb_full));
     }
   } else {
@@ -914,7 +914,8 @@ static int enqueue_elbo(svgpfa_engine* e, const PtrTable& pt, const ElboPlan& pl
   // per CU, so the ELL part may take at most half of the chip's 2 x CUs slots or the class items queue up behind it (measured
   // with the engine's usual four blocks per trial: 504 ELL blocks, 48.6 us = the two kernels one after the other)
   int parts_m = e->ell_parts;
-  while (merged && parts_m > 1 && (long long)v.R * parts_m * 2 > e->n_cu) parts_m >>= 1;
+  const int ell_roles = (pl.want_lat && (mask & 2u)) ? 2 : 1;       // (latent adjoints alone or dC / dd alone: one role's blocks)
+  while (merged && parts_m > 1 && (long long)v.R * parts_m * ell_roles > e->n_cu) parts_m >>= 1;
   if (merged && getenv("SVGPFA_ELLCLS_PARTS")) parts_m = std::max(1, std::min(e->ell_parts, atoi(getenv("SVGPFA_ELLCLS_PARTS"))));   // (experiments)
   // Full size (two class kernels, the combine not folded into k_item_bwd): the combine rides behind the ELL blocks of
   // k_quad_ell_mfma, which follows the class kernels on this stream anyway (SVGPFA_COMB_RIDE=0: a launch of its own)
