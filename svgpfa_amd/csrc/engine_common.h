@@ -197,6 +197,16 @@ struct EngineView {
   double* gCpart; double* gdpart; double* ellq;    // [ncd][N][2K] raw sums (E^T mu | E^T var), [ncd][N], [nell]
   double* ells; double* gthitem;                   // [R*K], [R*K*2]
   double* Mseg;                                    // [N][K] sum over spikes of mu_spk per neuron (stats path)
+  // Whitened kernel tiles at the quadrature nodes, Kw = Linv kappa(t_q, Z), kept across evaluations while the kernels
+  // stand (the E-step closure: reference stats/svEM.py:218-223 runs on the Ktz its KernelsMatricesStore cached).  One
+  // register image of k_front's accumulator per (item, node tile, panel): [R K][ceil(Q / 16)][NT][4][64] doubles
+  // (Kw[a][q] of lane (li, lg) = Ktil[inducing 16 a + 4 q + lg][node li]), and behind it (+ kw_half doubles) the same tiles as
+  // the register images k_item_bwd wants (KwT[a][q] of lane (li, lg) = Ktil[inducing 16 a + li][node lg + 4 q]): both kernels
+  // then load 512 contiguous bytes per wave instruction.  kw_mode: 0 off, 1 k_front stores both, 2 k_front loads its image
+  // instead of evaluating the kernel and whitening; kw_use: k_item_bwd<*, false> loads its image.
+  double* Kwc;
+  long long kw_half;
+  int kw_mode, kw_use, kw_nt;
   int* status;
   unsigned* fin_ticket;       // k_fin_items: scalar blocks that have finished (zero at rest)
   double* fin_part;           // [0] ELL terms known before k_item_bwd, [1] KL, [2 + b] spike-ELL partial of scalar block b

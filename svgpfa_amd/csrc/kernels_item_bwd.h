@@ -521,6 +521,11 @@ __device__ __forceinline__ void item_bwd_body(const EngineView& ev, const int r,
   double* gvl = sm + lay.gvl;
   constexpr int QC = sv_bwd_qc(NT);
   const int nquant = 16 * (PO ? G : 1);     // a chunk is padded to whole tiles (panel owners: to whole steps of the G teams)
+  // Value-only variant with the whitened tiles of the quadrature nodes cached by k_front (EngineView::Kwc, the E-step closure):
+  // the tile loop loads its whitened tile -- KwT[a][q] of lane (li, lg) = Ktil[inducing 16 a + li][node lg + 4 q], the second
+  // image of the cache, in this kernel's register layout -- instead of evaluating the kernel and whitening it
+  const bool kwl = !FULL && ev.kw_use != 0;
+  const double* kwi = ev.Kwc + ev.kw_half + (long long)(r * ev.K + k) * ((ev.Q + 15) >> 4) * NT * 256 + lane;
   double* ul = sm + lay.ul;
   double* al = sm + lay.al;
   double* zl = sm + lay.zl;
@@ -638,11 +643,12 @@ __device__ __forceinline__ void item_bwd_body(const EngineView& ev, const int r,
       for (int tile = wave; tile < ntiles; tile += NWB) {
         const double tq = tql[16 * tile + li], gm = gml[16 * tile + li], gvv = gvl[16 * tile + li];
         double stq = 0.0, ctq = 0.0;
-        if (KT == SV_PERIODIC) SV_BWD_SINCOS(tq * p.q4, stq, ctq);
         int jo = lg;
         asm volatile("" : "+v"(jo));      // (opaque: keeps the per-j constants out of long-lived registers)
         d4 X0[NT];
         d4 csv[(KT == SV_PERIODIC && FULL) ? NT : 1];
+        if (!kwl) {
+        if (KT == SV_PERIODIC) SV_BWD_SINCOS(tq * p.q4, stq, ctq);
 #pragma unroll
         for (int a = 0; a < NT; ++a)
 #pragma unroll
@@ -657,6 +663,7 @@ __device__ __forceinline__ void item_bwd_body(const EngineView& ev, const int r,
               X0[a][q] = p.s2 * SV_BWD_EXP2(fma(cs, p.h2, -p.h2));
             }
           }
+        }
         // adjoints of the four nodes lg + 4 q of this tile
         double gm4[4], gv4[4];
 #pragma unroll
@@ -668,6 +675,13 @@ __device__ __forceinline__ void item_bwd_body(const EngineView& ev, const int r,
         // stands, Linv's fragments the B operand; the accumulator holds node lg + 4 q of inducing point 16 a + li, which is
         // BOTH operand layouts of the contraction over the nodes Gt += KwT^T diag(gv) KwT
         d4 KwT[NT];
+        if (kwl) {
+          const double* kt = kwi + (long long)((n0 >> 4) + tile) * NT * 256;
+#pragma unroll
+          for (int a = 0; a < NT; ++a)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) KwT[a][q] = kt[a * 256 + 64 * q];
+        } else {
 #pragma unroll
         for (int a = 0; a < NT; ++a) {
           d4 acc = {0.0, 0.0, 0.0, 0.0};
@@ -677,6 +691,7 @@ __device__ __forceinline__ void item_bwd_body(const EngineView& ev, const int r,
             for (int q = 0; q < 4; ++q)
               acc = __builtin_amdgcn_mfma_f64_16x16x4f64(X0[b][q], lds_frag(&Li[sv_tidx(a, b) * TSZ + orm + 4 * q]), acc, 0, 0, 0);
           KwT[a] = acc;
+        }
         }
         d4 Gk[NT];
         if (FULL) {
@@ -938,7 +953,40 @@ __device__ __forceinline__ void item_bwd_body(const EngineView& ev, const int r,
           }
         }
       };
-      if (DB) {
+      if (kwl) {
+        // whitened tiles cached by k_front: a wave loads its own panel's tile (512 contiguous bytes per load instruction) and
+        // hands it to the team through LDS as in the computing form -- no kernel evaluation, no whitening, and ONE barrier per
+        // node tile: the hand-over alternates between the two exchange buffers (the raw tiles' one is idle here)
+        for (int s = 0; s < nsteps; ++s) {
+          const int tile = s * G + team;
+          const double* kt = kwi + (long long)((n0 >> 4) + tile) * NT * 256;
+          const bool live = 16 * tile < cnt;             // (a team beyond the chunk's last tile: padded nodes, zero adjoints)
+          double* kb = (s & 1) ? Xb : Kb;
+          d4 KwT;
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            gm4[q] = gml[16 * tile + lg + 4 * q];
+            gv4[q] = gvl[16 * tile + lg + 4 * q];
+            KwT[q] = live ? kt[c * 256 + 64 * q] : 0.0;
+          }
+#pragma unroll
+          for (int q = 0; q < 4; ++q) kb[c * 256 + q * 64 + lane] = KwT[q];
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            gu = fma(gm4[q], KwT[q], gu);
+            gK[q] = gv4[q] * KwT[q];
+          }
+          __syncthreads();
+#pragma unroll
+          for (int a = 0; a < NT; ++a) {
+            if (a >= c) {
+#pragma unroll
+              for (int q = 0; q < 4; ++q)
+                GW[a] = __builtin_amdgcn_mfma_f64_16x16x4f64(kb[a * 256 + q * 64 + lane], gK[q], GW[a], 0, 0, 0);
+            }
+          }
+        }
+      } else if (DB) {
         // one barrier per node tile: the exchange tiles alternate between two buffers, and the next tile's kernel values
         // are computed in front of the barrier that publishes this tile's whitened values
         stage1(0);

@@ -238,7 +238,10 @@ template <int NT, int KT, bool DYN, bool TP = false>
 __device__ __forceinline__ void times_tiles(const KPar& p, const double* Li, const double* Vl, const double* ul,
                                             const double* zl, const double* szl, const double* czl, const double* times,
                                             long long t0, int nt, double* mu_out, double* var_out, long long obase,
-                                            long long os_t, int want_var, int* next, const int tid) {
+                                            long long os_t, int want_var, int* next, const int tid, double* kwc = nullptr,
+                                            const int kw_mode = 0, const long long kw_half = 0) {
+  // kwc / kw_mode (k_front only): the item's cached whitened tiles (EngineView::Kwc): 1 store them, 2 load them instead of
+  // evaluating the kernel and whitening
   constexpr int MP = 16 * NT, LD = MP + 2;
   const int lane = tid & 63, wave = tid >> 6, li = lane & 15, lg = lane >> 4;
   // per-lane constants: ut and (RBF) Z of this lane's inducing points
@@ -270,6 +273,14 @@ __device__ __forceinline__ void times_tiles(const KPar& p, const double* Li, con
       const int nn = 16 * tile_n + li;
       tq_next = times[t0 + ((nn < nt) ? nn : 0)];
     }
+    d4 Kw[NT];
+    double* kwt = kwc + (long long)tile * NT * 256 + lane;          // this tile's images (kw_mode != 0 only)
+    if (kw_mode == 2) {
+#pragma unroll
+      for (int a = 0; a < NT; ++a)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) Kw[a][q] = kwt[a * 256 + q * 64];
+    } else {
     d4 X0[NT];
     double stq = 0.0, ctq = 0.0;
     if (KT == SV_PERIODIC) sv_sincos_quarter(tq * p.q4, stq, ctq);
@@ -287,9 +298,21 @@ __device__ __forceinline__ void times_tiles(const KPar& p, const double* Li, con
           X0[a][q] = p.s2 * sv_exp2_neg(fma(cs, p.h2, -p.h2));     // (cs may exceed 1 by a rounding: 2^(+1e-16 h2) is harmless; k_item_bwd evaluates the same expression)
         }
       }
-    d4 Kw[NT];
     if (TP) tri_chain_tp<NT, 0>(Kw, Li, X0, li * SV_TS + lg, lg * SV_TS + li);
     else tri_chain<NT, 0>(Kw, Li, LD, X0, li, lg);
+    if (kw_mode == 1) {
+      // both images: this kernel's own (linear), and k_item_bwd's transposed one -- register (a, q) of lane (li, lg) is its
+      // register (a, li >> 2) of lane (4 q + lg, li & 3): a scattered store, once per kernel build
+      double* kw2 = kwc + kw_half + (long long)tile * NT * 256 + (li >> 2) * 64 + (li & 3) * 16 + lg;
+#pragma unroll
+      for (int a = 0; a < NT; ++a)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          kwt[a * 256 + q * 64] = Kw[a][q];
+          kw2[a * 256 + 4 * q] = Kw[a][q];
+        }
+    }
+    }
     double pm = 0.0, n2 = 0.0, tt = 0.0;
 #pragma unroll
     for (int a = 0; a < NT; ++a)
@@ -655,7 +678,9 @@ __device__ __forceinline__ void front_body(const EngineView& ev, const LatentPtr
   if (want_w && wave == 3) spike_pre_item(ev, item, r, k, m, (lane < M) ? wsc[lane] : 0.0, wsc + 64);
   // ---- quadrature statistics [r][k][q]
   times_tiles<NT, KT, true, TP>(p, Li, Ls, ul, zl, szl, czl, ev.tq, (long long)r * ev.Q, ev.Q, ev.muq, ev.varq,
-                            ((long long)r * ev.K + k) * ev.Q, 1LL, 1, next, tid);
+                                ((long long)r * ev.K + k) * ev.Q, 1LL, 1, next, tid,
+                                ev.kw_mode ? ev.Kwc + (long long)item * ((ev.Q + 15) >> 4) * NT * 256 : nullptr, ev.kw_mode,
+                                ev.kw_half);
   if (SV_FRONT_CLK) {
     SV_FCK(6);
     if ((blockIdx.x == 101 || blockIdx.x == 202) && (tid == 0 || tid == 192)) {

@@ -38,6 +38,8 @@ struct svgpfa_engine {
   long long totM = 0, totMM = 0, totTT = 0;  // R*sum M, R*sum M^2, R*sum M(M+1)/2
   bool have_quad = false, have_spikes = false, have_kernels = false, have_stats = false;
   bool aux_valid = false;   // Kzz / L buffers hold the matrices of the current kernel snapshot (getters only)
+  bool kw_valid = false;    // EngineView::Kwc holds the whitened quadrature tiles of the current kernels and nodes
+  bool kw_cache = true;     // keep them across E-step evaluations (SVGPFA_KW_CACHE=0: off)
   bool timing = false;
   uint64_t emb_token = 0, p0_token = 0;   // svgpfa_set_embedding_token: content id of C now / when P0 was computed
   std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool;  // event pairs, reused
@@ -290,6 +292,8 @@ int svgpfa_create(const svgpfa_dims* d, int device, svgpfa_engine** out) {
     if (bw) e->build_wpe = (atoi(bw) == 3) ? 3 : 2;
     const char* fr = getenv("SVGPFA_FRONT");
     e->front = !(fr && atoi(fr) == 0);
+    const char* kc = getenv("SVGPFA_KW_CACHE");
+    e->kw_cache = !(kc && atoi(kc) == 0);
     const char* ps = getenv("SVGPFA_PERIODIC_SERIES");
     v.per_series = (ps && atoi(ps) == 0) ? 0 : 1;
   }
@@ -380,6 +384,7 @@ int svgpfa_set_quad(svgpfa_engine* e, const double* t, const double* w) {
   size_t n = sizeof(double) * e->v.R * e->v.Q;
   HIPCHK(e, hipMemcpyAsync((void*)e->v.tq, t, n, hipMemcpyDeviceToDevice, e->stream));
   HIPCHK(e, hipMemcpyAsync((void*)e->v.wq, w, n, hipMemcpyDeviceToDevice, e->stream));
+  e->kw_valid = false;
   e->have_quad = true;
   e->have_stats = false;
   return SVGPFA_OK;
@@ -682,6 +687,7 @@ int svgpfa_build_kernels(svgpfa_engine* e, const double* const* Z, const double*
   const bool cls = e->have_spikes && e->cls_on;
   launch_build(e, 0, &st, cls);
   e->aux_valid = false;
+  e->kw_valid = false;
   e->p0_token = 0;
   e->cls_valid = cls || !e->cls_on;
   HIPCHK(e, hipGetLastError());
@@ -902,6 +908,21 @@ static int enqueue_elbo(svgpfa_engine* e, const PtrTable& pt, const ElboPlan& pl
   const bool have_w = pl.run_spike && pl.full && (mask & 2u) && e->cls_on && v.ntiles > 0;
   // whitened parameters (ut, a, Vt, KL), the class path's W and the quadrature statistics: one launch (k_front);
   // SVGPFA_FRONT=0 keeps k_prep_mfma and k_times_fwd_mfma as launches of their own
+  // E-step evaluations (variational gradients only, or the value alone) keep the whitened kernel tiles of the quadrature
+  // nodes across evaluations while the kernels and the nodes stand: the first one behind a kernel build stores them (k_front),
+  // every one loads them in k_item_bwd, later ones in k_front too -- the reference's E-step closure runs on cached Ktz as well
+  // (stats/svEM.py:218-223).  2 x 266 MB at the north-star size (2 x 4.3 GB at cfg5), allocated at the first such evaluation.
+  int kw_mode = 0;
+  if (e->front && e->kw_cache && !pl.full && !(mask & SV_MASK_STATS)) {
+    if (e->kw_valid) kw_mode = 2;
+    else if (mask & 1u) kw_mode = 1;
+    v.kw_half = (long long)v.R * v.K * ((v.Q + 15) / 16) * e->NT * 256;      // two images of the tiles: k_front's and k_item_bwd's
+    if (kw_mode && !v.Kwc) DALLOC(e, v.Kwc, (size_t)2 * v.kw_half);
+    if (kw_mode == 1) e->kw_valid = true;
+  }
+  v.kw_mode = kw_mode;
+  v.kw_use = (kw_mode != 0 && (mask & 1u)) ? 1 : 0;
+  v.kw_nt = e->NT;
   if (e->front) launch_front(e, pt, have_w);
   else launch_prep(e, pt, have_w);
   // ---- spike pass (fp64 VALU bound): needs only a = Kzz^-1 m (and W) from k_prep
@@ -1078,6 +1099,7 @@ int svgpfa_latent_stats_backward(svgpfa_engine* e, const double* const* mean, co
       hipLaunchKernelGGL(k_transpose_b, dim3(gs), dim3(256), 0, e->stream, g_var_spk, v.gvarspk, 1LL, (long long)v.S, (long long)v.K);
     }
   }
+  v.kw_mode = v.kw_use = 0;            // (the whitened-tile cache serves svgpfa_elbo's E-step evaluations only)
   const unsigned m2 = mask | SV_MASK_STATS;
   if (mask & (4u | 8u)) {
     DISPATCH_NT(e->NT, hipLaunchKernelGGL((k_item_bwd<NT_, true>), dim3(v.R * v.K), dim3(64 * e->tile_nw),
