@@ -242,6 +242,54 @@ def test_item_bwd_wave_counts_agree(monkeypatch, Ms):
             assert rel_err(b, a) < 1e-12
 
 
+@pytest.mark.parametrize("Ms", [[10, 24, 9], [40, 33, 64]], ids=["M<=32", "M>32"])
+def test_estep_evaluations_reuse_the_whitened_tiles(monkeypatch, Ms):
+    """E-step evaluations (variational gradients only) keep the whitened kernel tiles of the quadrature nodes while the
+    kernels stand (the reference's E-step closure runs on its cached Ktz, stats/svEM.py:218-223): the first evaluation behind a
+    kernel build stores them, later ones load them -- every one bit-identical to the first and, to rounding, to an engine
+    without the cache and to the oracle; a kernel build with other inducing points starts over."""
+    from oracle import svgpfa_oracle as orc
+    prob = synthetic.make_problem(R=4, N=9, K=len(Ms), M=Ms, kernels="mix", seed=33, n_quad=70, rate=20.0, jitter=1.0)
+    ref = orc.elbo_and_grads(orc.from_numpy_problem(prob), 1)
+    monkeypatch.delenv("SVGPFA_KW_CACHE", raising=False)
+    eng, P = _engine(prob)
+    outs = [_eval(eng, P, 1) for _ in range(3)]
+    val = _eval(eng, P, 0)                                   # the value alone: loads the tiles too
+    assert val["elbo"] == outs[0]["elbo"]
+    for o in outs[1:]:
+        assert o["elbo"] == outs[0]["elbo"]
+        for k in range(prob["K"]):
+            assert np.array_equal(o["g_mean"][k], outs[0]["g_mean"][k]) and np.array_equal(o["g_cholVecs"][k], outs[0]["g_cholVecs"][k])
+    assert _close(outs[0]["elbo"], float(ref["elbo"]), TOL_S)
+    for k in range(prob["K"]):
+        assert rel_err(outs[0]["g_mean"][k], ref["g_mean"][k].numpy()[:, :, 0]) < TOL_A
+        assert rel_err(outs[0]["g_cholVecs"][k], ref["g_cholVecs"][k].numpy()[:, :, 0]) < TOL_A
+    # a full evaluation in between does not disturb it; a kernel build with moved inducing points invalidates it
+    _eval(eng, P, 15)
+    again = _eval(eng, P, 1)
+    assert again["elbo"] == outs[0]["elbo"]
+    Z2 = [z + 0.01 * torch.sin(17.0 * z) for z in P["Z"]]
+    eng.build_kernels(Z2, P["theta"])
+    moved = _eval(eng, P, 1)
+    eng.close()
+    prob2 = dict(prob)
+    prob2["Z"] = [z.cpu().numpy() for z in Z2]
+    eng2, P2 = _engine(prob2)
+    fresh = _eval(eng2, P2, 1)
+    eng2.close()
+    assert moved["elbo"] == fresh["elbo"] and moved["elbo"] != outs[0]["elbo"]
+    for k in range(prob["K"]):
+        assert np.array_equal(moved["g_mean"][k], fresh["g_mean"][k])
+    monkeypatch.setenv("SVGPFA_KW_CACHE", "0")
+    eng3, P3 = _engine(prob)
+    plain = _eval(eng3, P3, 1)
+    eng3.close()
+    assert _close(plain["elbo"], outs[0]["elbo"], 1e-13)
+    for k in range(prob["K"]):
+        assert rel_err(plain["g_mean"][k], outs[0]["g_mean"][k]) < 1e-11
+        assert rel_err(plain["g_cholVecs"][k], outs[0]["g_cholVecs"][k]) < 1e-11
+
+
 def test_build_reg_three_waves_per_simd_agrees_with_two(monkeypatch):
     """k_build_reg<32> has two instantiations (two / three waves per SIMD; the host picks by grid size, SVGPFA_BUILD_WPE
     forces one): the same arithmetic in the same order -- Kzz, its Cholesky factor, and an evaluation agree to rounding."""
