@@ -32,11 +32,6 @@
 // the class's moments + three coefficient rows); it borrows the Gt region, which nothing else uses before the reductions
 #define SV_GATHER_SCR (SV_ACOLS + 3 * (SV_FH + 1))
 
-// Exchange tiles of phase 1 double-buffered (one block barrier per node tile instead of two): where the LDS is to spare
-#ifndef SV_BWD_DB
-#define SV_BWD_DB 1
-#endif
-__host__ __device__ constexpr bool sv_bwd_db(int NT) { return SV_BWD_DB && NT <= 2; }
 // Phase 1 as panel owners (teams of NT waves, item_bwd_body) from this many tiles per side on; below, a wave owns whole
 // node tiles (no exchange, no barrier inside the loop: with one or two panels the team would be one or two waves, and the
 // per-tile set-up -- node loads, the node's sincos -- would be repeated by every wave of the team)
@@ -74,7 +69,7 @@ __host__ __device__ constexpr ItemBwdLayout sv_item_bwd_layout(int NT, int NWB, 
   const bool po = sv_bwd_po(NT);
   const size_t G = (NWB / NT) > 0 ? (size_t)(NWB / NT) : 1;
   size_t XS = TM;
-  if (po && XS < G * NT * (sv_bwd_db(NT) ? 4 : 2) * 256) XS = G * NT * (sv_bwd_db(NT) ? 4 : 2) * 256;
+  if (po && XS < G * NT * 2 * 256) XS = G * NT * 2 * 256;
   if (XS < SV_GATHER_SCR) XS = SV_GATHER_SCR;
   ItemBwdLayout o{};
   size_t p = 0;
@@ -498,7 +493,7 @@ template <int NT, int KT, bool FULL>
 __device__ __forceinline__ void item_bwd_body(const EngineView& ev, const int r, const int k, const LatentPtrs pt, unsigned mask,
                               double* sm) {
   constexpr int MP = 16 * NT, TS = SV_TS, TSZ = SV_TSZ;
-  constexpr bool DB = sv_bwd_db(NT), PO = sv_bwd_po(NT);
+  constexpr bool PO = sv_bwd_po(NT);
   constexpr int NTRI = NT * (NT + 1) / 2;
   const int tid = threadIdx.x;
   const int lane = tid & 63, li = lane & 15, lg = lane >> 4;
@@ -828,8 +823,8 @@ __device__ __forceinline__ void item_bwd_body(const EngineView& ev, const int r,
 #pragma unroll
     for (int a = 0; a < NT; ++a) GW[a] = (d4){0.0, 0.0, 0.0, 0.0};
     double th0 = 0.0, th1 = 0.0;
-    double* Xb = X + (size_t)team * (DB ? 4 : 2) * NT * 256;     // this team's raw kernel tiles: register image of panel b at [b][q][lane]
-    double* Kb = Xb + NT * 256;                                  // ... whitened tiles (DB: the second pair of buffers behind them)
+    double* Xb = X + (size_t)team * 2 * NT * 256;     // this team's raw kernel tiles: register image of panel b at [b][q][lane]
+    double* Kb = Xb + NT * 256;                       // ... whitened tiles
     const int jb = 16 * c + lg;                       // this lane's inducing points: jb + 4 q
     // Node lists of the item.  Segment 0: the trial's Q quadrature nodes with the adjoints the ELL kernel left in
     // [r][k][q] (contiguous for this item).  Segment 1 (statistics mode only, mask bit SV_MASK_STATS): the trial's spike
@@ -876,7 +871,7 @@ __device__ __forceinline__ void item_bwd_body(const EngineView& ev, const int r,
             X0[q] = p.s2 * SV_BWD_EXP2(fma(cs, p.h2, -p.h2));
           }
         }
-        double* xw = Xb + (DB ? (s & 1) * 2 * NT * 256 : 0) + c * 256 + lane;
+        double* xw = Xb + c * 256 + lane;
 #pragma unroll
         for (int q = 0; q < 4; ++q) xw[q * 64] = X0[q];
         // adjoints of the four nodes lg + 4 q of this tile: what this lane's registers of the TRANSPOSED whitened tile
@@ -892,7 +887,7 @@ __device__ __forceinline__ void item_bwd_body(const EngineView& ev, const int r,
       // the accumulator holds node lg + 4 q of inducing point 16 c + li, which is BOTH operand layouts of the
       // contraction over the nodes Gt += KwT^T diag(gv) KwT -- no transpose anywhere
       auto stage2 = [&](const int s) {
-        const double* xr = Xb + (DB ? (s & 1) * 2 * NT * 256 : 0) + lane;
+        const double* xr = Xb + lane;
         d4 Gk = {0.0, 0.0, 0.0, 0.0}, KwT = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
         for (int b = 0; b < NT; ++b) {
@@ -909,7 +904,7 @@ __device__ __forceinline__ void item_bwd_body(const EngineView& ev, const int r,
             for (int q = 0; q < 4; ++q) KwT = __builtin_amdgcn_mfma_f64_16x16x4f64(xb[q], lds_frag(lt + 4 * q), KwT, 0, 0, 0);
           }
         }
-        double* kw = Kb + (DB ? (s & 1) * 2 * NT * 256 : 0) + c * 256 + lane;
+        double* kw = Kb + c * 256 + lane;
 #pragma unroll
         for (int q = 0; q < 4; ++q) kw[q * 64] = KwT[q];
 #pragma unroll
@@ -943,7 +938,7 @@ __device__ __forceinline__ void item_bwd_body(const EngineView& ev, const int r,
       };
       // ---- (3) column c of Gt: tiles (a, c), a >= c: A = KwT_a (from its owner), B = diag(gv) KwT_c (own)
       auto stage3 = [&](const int s) {
-        const double* kr = Kb + (DB ? (s & 1) * 2 * NT * 256 : 0) + lane;
+        const double* kr = Kb + lane;
 #pragma unroll
         for (int a = 0; a < NT; ++a) {
           if (a >= c) {
@@ -985,17 +980,6 @@ __device__ __forceinline__ void item_bwd_body(const EngineView& ev, const int r,
                 GW[a] = __builtin_amdgcn_mfma_f64_16x16x4f64(kb[a * 256 + q * 64 + lane], gK[q], GW[a], 0, 0, 0);
             }
           }
-        }
-      } else if (DB) {
-        // one barrier per node tile: the exchange tiles alternate between two buffers, and the next tile's kernel values
-        // are computed in front of the barrier that publishes this tile's whitened values
-        stage1(0);
-        __syncthreads();
-        for (int s = 0; s < nsteps; ++s) {
-          stage2(s);
-          if (s + 1 < nsteps) stage1(s + 1);
-          __syncthreads();
-          stage3(s);
         }
       } else {
         for (int s = 0; s < nsteps; ++s) {

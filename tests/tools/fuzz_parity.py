@@ -19,7 +19,7 @@ worst = {"scalar": 0.0, "array": 0.0}
 for c in range(n_cases):
     K = int(rng.integers(1, 7))
     case = dict(R=int(rng.integers(1, 6)), N=int(rng.integers(1, 41)), K=K,
-                M=[int(rng.integers(1, 49)) for _ in range(K)],
+                M=[int(rng.integers(1, 65)) for _ in range(K)],
                 kernels=[synthetic.RBF if rng.random() < 0.5 else synthetic.PERIODIC for _ in range(K)],
                 n_quad=int(rng.integers(8, 120)), rate=float(np.exp(rng.uniform(np.log(0.5), np.log(400.0)))),
                 trial_len=float(rng.uniform(0.5, 8.0)), seed=int(rng.integers(0, 1 << 30)), jitter=1.0, reg=1e-3)
@@ -30,6 +30,10 @@ for c in range(n_cases):
     eng, P = engine_from_problem(prob, precision=precision)
     shared, gm, gc, gz = eng.elbo(P["mean"], P["cholVecs"], P["C"], P["d"], mask)
     eng.sync()
+    if mask == 1:     # E-step evaluation: the second one loads the whitened tiles the first one stored -- bit-identical
+        sh2, gm2, gc2, _ = eng.elbo(P["mean"], P["cholVecs"], P["C"], P["d"], mask)
+        eng.sync()
+        assert torch.equal(sh2, shared) and all(torch.equal(a, b) for a, b in zip(gm2 + gc2, gm + gc)), "cached E-step evaluation differs"
     elbo, ell, kl, gC, gd, gth = eng.split_shared(shared)
     ref = orc.elbo_and_grads(orc.from_numpy_problem(prob), mask)
     scale = max(1.0, abs(float(ref["elbo"]))) if precision == "fp64" else max(1.0, abs(float(ref["elbo"])), abs(float(ref["ell"])),
