@@ -222,8 +222,16 @@ int svgpfa_spike_kernel_ms(svgpfa_engine* e, double* total_ms, int32_t* launches
  *   the accepted pairs, oldest first); out[0..5) = [y.s, y.y, g.g, s.g, y.g], out[5 + j m + i] for i < m =
  *   S_i.y (j = 0), Y_i.s (1), Y_i.y (2), S_i.g (3), Y_i.g (4).
  * svgpfa_lbfgs_direction: d = -H g + sum_i cY_i Y_i + sum_i cS_i S_i with coef = [cY (m), cS (m), H] on the device;
- *   x0 = x when both are given (the line search's restart point); out_dmax[0] = max|d|. */
+ *   x0 = x when both are given (the line search's restart point); out_dmax[0] = max|d|.
+ * svgpfa_lbfgs_coef: the coefficient step between the two, on the device (one wavefront): dots = pair_dots' 5 m + 5 sums;
+ *   gram = [history_rows^2] s_i.y_j | [history_rows^2] y_i.y_j | H, state kept on the device (history_rows <= 128 rows each way,
+ *   > m); accepts the candidate pair when y.s > 1e-10 (its row and column join the matrices, H = y.s / y.y), runs the
+ *   two-loop recursion in coefficient space and leaves coef = [cY (m + 1), cS (m + 1), H] for svgpfa_lbfgs_direction over
+ *   m + 1 rows (zeros for a rejected candidate) and out4 = [g.d, new number of pairs, accepted (0 / 1), H] -- so that the host
+ *   can enqueue the direction and the next evaluation without waiting for the sums. */
 int64_t svgpfa_lbfgs_workspace_doubles(int64_t n, int32_t max_history);
+int svgpfa_lbfgs_coef(void* stream, int32_t m, int32_t history_rows, const double* dots, double* gram, double* coef,
+                      double* out4);
 int svgpfa_lbfgs_grad_stats(void* stream, int64_t n, const double* g_raw, double sign, const double* d, double* g,
                             int64_t n_weighted, double weight, const double* value, const double* carry, double* work,
                             double* out6);

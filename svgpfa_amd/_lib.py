@@ -61,6 +61,7 @@ SIGNATURES = {
     "svgpfa_kernel_ms": (ctypes.c_int, [_vp, _i32, ctypes.POINTER(_f64), ctypes.POINTER(_i32)]),
     "svgpfa_spike_kernel_ms": (ctypes.c_int, [_vp, ctypes.POINTER(_f64), ctypes.POINTER(_i32)]),
     "svgpfa_lbfgs_workspace_doubles": (_i64, [_i64, _i32]),
+    "svgpfa_lbfgs_coef": (ctypes.c_int, [_vp, _i32, _i32, _vp, _vp, _vp, _vp]),
     "svgpfa_lbfgs_grad_stats": (ctypes.c_int, [_vp, _i64, _vp, _f64, _vp, _vp, _i64, _f64, _vp, _vp, _vp, _vp]),
     "svgpfa_lbfgs_pair_dots": (ctypes.c_int, [_vp, _i64, _vp, _vp, _vp, _f64, _vp, _vp, _i64, _i32, _i64, _f64, _vp, _vp]),
     "svgpfa_lbfgs_direction": (ctypes.c_int, [_vp, _i64, _vp, _vp, _vp, _i64, _i32, _vp, _vp, _vp, _vp, _vp, _vp]),

@@ -241,6 +241,95 @@ __global__ __launch_bounds__(256) void k_lbfgs_final(const double* __restrict__ 
   }
 }
 
+// The coefficient step of the vector-free two-loop recursion ON THE DEVICE (round 5): what shardedLBFGS.py's _step_flat did
+// on the host between pair_dots and direction -- accept the candidate pair when y.s > 1e-10, extend the Gram matrices
+// SY[i][j] = s_i.y_j and YY[i][j] = y_i.y_j by its row and column, H = y.s / y.y, then
+//     al_i = (-S_i.g - sum_{j > i} al_j SY[i][j]) / SY[i][i]                          i = m1 - 1 .. 0
+//     yq_i = -Y_i.g - sum_j YY[i][j] al_j
+//     be_i = (H yq_i + sum_{j < i} (al_j - be_j) SY[j][i]) / SY[i][i]                  i = 0 .. m1 - 1
+//     g.d  = -H g.g - H sum al_i Y_i.g + sum (al_i - be_i) S_i.g
+// and the coefficients of  d = -H g + sum cY_i y_i + cS_i s_i :  cY = -H al, cS = al - be  -- so that the host need not
+// wait for the inner products before it can enqueue the direction, the trial point and the next evaluation: ONE read-back
+// per iteration (with the evaluation's) instead of two.  One wavefront; the sums over j run over the lanes and are added in
+// a fixed order.  The direction is launched over m + 1 rows: a rejected candidate gets coefficients 0.
+// gram: [hs1 hs1] SY | [hs1 hs1] YY | H (state that lives on the device from one iteration to the next).
+__global__ __launch_bounds__(64) void k_lbfgs_coef(int m, int hs1, const double* __restrict__ tot, double* gram, double* coef,
+                                                  double* out4) {
+  __shared__ double Sg[128], Yg[128], al[128], be[128], yq[128];
+  const int lane = threadIdx.x;
+  double* SY = gram;
+  double* YY = gram + (long long)hs1 * hs1;
+  double* Hs = gram + 2LL * hs1 * hs1;
+  const double ys = tot[0], yy = tot[1], gg = tot[2], sg = tot[3], yg = tot[4];
+  const double* S_y = tot + 5;
+  const double* s_Y = tot + 5 + m;
+  const double* Y_y = tot + 5 + 2 * m;
+  const double* S_g = tot + 5 + 3 * m;
+  const double* Y_g = tot + 5 + 4 * m;
+  const bool acc = ys > 1e-10;
+  for (int i = lane; i < m; i += 64) {
+    Sg[i] = S_g[i];
+    Yg[i] = Y_g[i];
+    if (acc) {
+      SY[(long long)i * hs1 + m] = S_y[i];
+      SY[(long long)m * hs1 + i] = s_Y[i];
+      YY[(long long)i * hs1 + m] = Y_y[i];
+      YY[(long long)m * hs1 + i] = Y_y[i];
+    }
+  }
+  if (acc && lane == 0) {
+    SY[(long long)m * hs1 + m] = ys;
+    YY[(long long)m * hs1 + m] = yy;
+    Hs[0] = ys / yy;
+    Sg[m] = sg;
+    Yg[m] = yg;
+  }
+  __syncthreads();
+  __threadfence_block();
+  const int m1 = acc ? m + 1 : m;
+  const double H = Hs[0];                      // (the caller seeds it; an accepted pair has just replaced it)
+  for (int i = m1 - 1; i >= 0; --i) {
+    double s = 0.0;
+    for (int j = i + 1 + lane; j < m1; j += 64) s = fma(al[j], SY[(long long)i * hs1 + j], s);
+    s = wave_sum(s);
+    if (lane == 0) al[i] = (-Sg[i] - s) / SY[(long long)i * hs1 + i];
+    __syncthreads();
+  }
+  for (int i = lane; i < m1; i += 64) {
+    double s = 0.0;
+    for (int j = 0; j < m1; ++j) s = fma(YY[(long long)i * hs1 + j], al[j], s);
+    yq[i] = -Yg[i] - s;
+  }
+  __syncthreads();
+  for (int i = 0; i < m1; ++i) {
+    double s = 0.0;
+    for (int j = lane; j < i; j += 64) s = fma(al[j] - be[j], SY[(long long)j * hs1 + i], s);
+    s = wave_sum(s);
+    if (lane == 0) be[i] = (H * yq[i] + s) / SY[(long long)i * hs1 + i];
+    __syncthreads();
+  }
+  double a = 0.0, b = 0.0;
+  for (int i = lane; i < m1; i += 64) {
+    a = fma(al[i], Yg[i], a);
+    b = fma(al[i] - be[i], Sg[i], b);
+  }
+  a = wave_sum(a);
+  b = wave_sum(b);
+  // coefficients over m + 1 rows (the candidate's row m is part of the direction's launch whether accepted or not)
+  for (int i = lane; i <= m; i += 64) {
+    const bool in = i < m1;
+    coef[i] = in ? -H * al[i] : 0.0;
+    coef[(m + 1) + i] = in ? al[i] - be[i] : 0.0;
+  }
+  if (lane == 0) {
+    coef[2 * (m + 1)] = H;
+    out4[0] = -H * gg + (-H * a + b);
+    out4[1] = (double)m1;
+    out4[2] = acc ? 1.0 : 0.0;
+    out4[3] = H;
+  }
+}
+
 inline int lb_blocks(long long n) { return (int)((n + (long long)SV_LB_T * SV_LB_E - 1) / ((long long)SV_LB_T * SV_LB_E)); }
 
 inline int lb_status() { return hipGetLastError() == hipSuccess ? SVGPFA_OK : SVGPFA_ERR_HIP; }
@@ -292,6 +381,13 @@ int svgpfa_lbfgs_direction(void* stream, int64_t n, const double* g, const doubl
                      (int)m, coef, d, x, x0, work, nb);
   hipLaunchKernelGGL(k_lbfgs_final, dim3(1), dim3(256), 0, st, (const double*)work, nb, 0, 1, out_dmax,
                      (const double*)nullptr, 1.0, (const double*)nullptr);
+  return lb_status();
+}
+
+int svgpfa_lbfgs_coef(void* stream, int32_t m, int32_t history_rows, const double* dots, double* gram, double* coef,
+                      double* out4) {
+  if (m < 0 || history_rows <= m || history_rows > 128 || !dots || !gram || !coef || !out4) return SVGPFA_ERR_INVALID;
+  hipLaunchKernelGGL(k_lbfgs_coef, dim3(1), dim3(64), 0, (hipStream_t)stream, (int)m, (int)history_rows, dots, gram, coef, out4);
   return lb_status();
 }
 

@@ -157,8 +157,49 @@ class _HipVec:
                     "svgpfa_lbfgs_pair_dots")
         return out
 
+    # ---- the coefficient step on the device (svgpfa_lbfgs_coef): Gram matrices, H and the coefficients never visit the host
+    HS1_MAX = 128
+
+    def coef_ready(self, history_size, m):
+        """The device-side coefficient step can serve a history of m pairs + the candidate (no pair has to be dropped)."""
+        return m + 1 < min(history_size + 1, self.HS1_MAX)
+
+    def coef(self, m, part, history_size):
+        """-> (coef [2 (m + 1) + 1] on the device, laid out for a direction over m + 1 rows, out4 = [g.d, pairs, accepted, H])."""
+        hs1 = min(history_size + 1, self.HS1_MAX)
+        if getattr(self, "_gram", None) is None:
+            self._hs1 = hs1
+            self._gram = torch.zeros(2 * hs1 * hs1 + 8, dtype=torch.float64, device=self._dev)
+            self._coefd = torch.empty(2 * hs1 + 1, dtype=torch.float64, device=self._dev)
+            self._out4 = torch.empty(4, dtype=torch.float64, device=self._dev)
+        self._check(self._lib.svgpfa_lbfgs_coef(self._stream(), int(m), int(self._hs1), self._ptr(part), self._ptr(self._gram),
+                                                self._ptr(self._coefd), self._ptr(self._out4)), "svgpfa_lbfgs_coef")
+        return self._coefd, self._out4
+
+    def gram_to_host(self, m):
+        """(SY, YY, H) of the m accepted pairs as the host path keeps them (when the device path hands over)."""
+        g = self._gram.cpu().numpy()
+        hs1 = self._hs1
+        SY = g[:hs1 * hs1].reshape(hs1, hs1)[:m, :m].copy()
+        YY = g[hs1 * hs1:2 * hs1 * hs1].reshape(hs1, hs1)[:m, :m].copy()
+        return SY, YY, float(g[2 * hs1 * hs1])
+
+    def gram_from_host(self, SY, YY, H, history_size):
+        """Seed the device state from the host's matrices (the device path takes over an optimiser the host path started)."""
+        hs1 = min(history_size + 1, self.HS1_MAX)
+        g = np.zeros(2 * hs1 * hs1 + 8)
+        m = SY.shape[0]
+        a = g[:hs1 * hs1].reshape(hs1, hs1)
+        b = g[hs1 * hs1:2 * hs1 * hs1].reshape(hs1, hs1)
+        a[:m, :m], b[:m, :m] = SY, YY
+        g[2 * hs1 * hs1] = H
+        self._hs1 = hs1
+        self._gram = torch.from_numpy(g).to(self._dev)
+        self._coefd = torch.empty(2 * hs1 + 1, dtype=torch.float64, device=self._dev)
+        self._out4 = torch.empty(4, dtype=torch.float64, device=self._dev)
+
     def direction(self, g, S, Y, m, coef, d, x, x0):
-        c = torch.from_numpy(np.ascontiguousarray(coef, dtype=np.float64)).to(self._dev)
+        c = coef if torch.is_tensor(coef) else torch.from_numpy(np.ascontiguousarray(coef, dtype=np.float64)).to(self._dev)
         self._check(self._lib.svgpfa_lbfgs_direction(self._stream(), self._n, self._ptr(g),
                                                      S.data_ptr() if m else None, Y.data_ptr() if m else None,
                                                      S.stride(0) if m else self._n, int(m), self._ptr(c), self._ptr(d),
@@ -486,6 +527,9 @@ class ShardedLBFGS:
         x0 = st.get("x0")
         if d is None:
             d, x0 = torch.empty_like(x), torch.empty_like(x)
+        # The coefficient step on the device (one host read-back per iteration instead of two): fp64 vectors on one GPU, one
+        # rank (across ranks the inner products are summed over the ranks on the way: the host path), SVGPFA_LBFGS_DEVCOEF=0: off
+        devcoef = isinstance(vec, _HipVec) and self._world == 1 and os.environ.get("SVGPFA_LBFGS_DEVCOEF", "1") != "0"
         n_iter = 0
         while n_iter < self.max_iter:
             n_iter += 1
@@ -496,6 +540,7 @@ class ShardedLBFGS:
                 H = 1.0
                 gtd = -gg
                 coef = np.array([H])
+                st["gram_on_device"] = False
             else:
                 if Sb is None or w0 + m + 1 > Sb.shape[0]:
                     full = 2 * self.history_size + 1
@@ -510,6 +555,56 @@ class ShardedLBFGS:
                     w0 = 0
                 Sw, Yw = Sb[w0:], Yb[w0:]
                 part = vec.pair_dots(g, prev_g, d, t, Sw, Yw, m)      # writes the candidate pair into the window's row m
+                dev_it = (devcoef and self.line_search_fn == "strong_wolfe" and vec.coef_ready(self.history_size, m))
+                if devcoef and not dev_it and st.get("gram_on_device"):      # the device path hands over (history full)
+                    SY, YY, H = vec.gram_to_host(m)
+                    st["gram_on_device"] = False
+                if dev_it:
+                    # The coefficient step on the device: nothing is read back here.  g.d, the number of pairs and H come
+                    # with the read-back of the first trial evaluation below.
+                    if not st.get("gram_on_device"):
+                        vec.gram_from_host(SY if SY is not None else np.zeros((0, 0)), YY if YY is not None else np.zeros((0, 0)),
+                                           H, self.history_size)
+                        st["gram_on_device"] = True
+                    coef, pend = vec.coef(m, part, self.history_size)
+                    dmax_t = vec.direction(g, Sw, Yw, m + 1, coef, d, x, x0)
+                    prev_g, prev_loss = g, loss
+                    t = self.lr
+                    torch.add(x0, d, alpha=t, out=x)
+                    f, graw = closure()
+                    gn, o6 = vec.grad_stats(graw, sign, d, f, dmax_t)
+                    v = self._read(torch.cat([o6, pend]), 3, maxes=(3, 5))
+                    gtd, m, H = float(v[6]), int(round(float(v[7]))), float(v[9])
+                    if gtd > -tc:                  # torch stops in front of the line search: the trial evaluation is dropped
+                        x.copy_(x0)
+                        break
+                    first = (float(v[4]), gn, float(v[0]), float(v[3]), float(v[5]))
+                    step0, used, last = t, [False], [t]
+
+                    def phi(step):    # the first trial has been evaluated already; further ones as in the host path
+                        if not used[0] and step == step0:
+                            used[0] = True
+                            return first
+                        torch.add(x0, d, alpha=step, out=x)
+                        last[0] = step
+                        fv, gr = closure()
+                        gnew, o = vec.grad_stats(gr, sign, d, fv, dmax_t)
+                        w = self._read(o, 3, maxes=(3, 5))
+                        return float(w[4]), gnew, float(w[0]), float(w[3]), float(w[5])
+                    loss, g, t, ls_evals, gmax, dmax = self._strong_wolfe(phi, t, d, loss, g, gtd, gm0=gmax)
+                    if last[0] != t:
+                        torch.add(x0, d, alpha=t, out=x)
+                    evals += ls_evals
+                    st["func_evals"] += ls_evals
+                    if n_iter == self.max_iter or evals >= self.max_eval:
+                        break
+                    if gmax <= tg:
+                        break
+                    if dmax * abs(t) <= tc:
+                        break
+                    if abs(loss - prev_loss) < tc:
+                        break
+                    continue
                 tot = self._read(part, part.numel())                  # the one host sync of the iteration
                 ys, yy, gg, sg, yg = (float(v) for v in tot[:5])
                 S_y, s_Y, Y_y, S_g, Y_g = (tot[5 + i * m:5 + (i + 1) * m] for i in range(5))
