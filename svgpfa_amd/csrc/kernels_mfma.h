@@ -741,6 +741,16 @@ __device__ __forceinline__ void quad_ell_mfma_body(const EngineView& ev, const d
   typedef EllT<T> X;
   typedef typename X::acc accT;
   constexpr int KKP = 4 * KS, LDK = KKP + 2, KKT = (KKP + 15) / 16;
+  // Output rows of the sum products (the 2K columns of [mu | var] or [C | C^2/2]): fp64 takes whole 16-row tiles with
+  // v_mfma_f64_16x16x4_f64 and the rows left over, four at a time, with v_mfma_f64_4x4x4_4b_f64 -- four independent 4x4x4
+  // products whose operand and result lanes (lane = x + 4 block + 16 k; result lane = j + 4 block + 16 i, probed on the chip:
+  // tests/tools/probes/mfma_f64_4x4x4_probe.hip) are exactly the 16x16x4 layouts restricted to four output rows, at a quarter
+  // of the issue time (7.3 against 29 ns per SIMD).  At 2K = 20 the second 16-row tile carried 4 useful rows: 8 -> 4 + 4
+  // quarter-cost instructions per tile pair (round 5).  fp32 keeps whole tiles (its 4x4 instruction has k = 1).
+  constexpr bool SPL = sizeof(T) == 8;
+  constexpr int FT = SPL ? KS / 4 : KKT;          // whole 16-row tiles
+  constexpr int LG = SPL ? KS % 4 : 0;            // groups of four left-over rows
+  constexpr int FTA = FT > 0 ? FT : 1, LGA = LG > 0 ? LG : 1;
   const double L2E = 1.4426950408889634074, LN2 = 0.69314718055994530942;
   const int K = ev.K, N = ev.N, Q = ev.Q, K2 = 2 * K;
   const int QT = (Q + 15) >> 4, NTl = (N + 15) >> 4;
@@ -873,9 +883,12 @@ __device__ __forceinline__ void quad_ell_mfma_body(const EngineView& ev, const d
     T bfrag[KS];                              // own rows as the B operand of the h product
 #pragma unroll
     for (int c = 0; c < KS; ++c) bfrag[c] = ow[li * LDK + 4 * c + lg];
-    accT acc[KKT];
+    accT acc[FTA];
+    double accl[LGA];
 #pragma unroll
-    for (int t = 0; t < KKT; ++t) acc[t] = (accT){0, 0, 0, 0};
+    for (int t = 0; t < FTA; ++t) acc[t] = (accT){0, 0, 0, 0};
+#pragma unroll
+    for (int g = 0; g < LGA; ++g) accl[g] = 0.0;
     T colsum = 0;
     for (int lt0 = 0; lt0 < LT; lt0 += LC) {
       if (LC < LT) fill_lm(lt0 * 16);         // block-uniform: every wave takes part, active or not
@@ -887,17 +900,23 @@ __device__ __forceinline__ void quad_ell_mfma_body(const EngineView& ev, const d
         const T* pA = LM + li * LDK + lg;                       // row lr + li, column 4 c + lg
         const T* pT = LM + X::row(lg, 0) * LDK + li;            // row lr + row(lg, c), column 16 t + li
         const T* pv = lv + lt0 * 16 + X::row(lg, 0);            // element lt 16 + row(lg, q)
+        const T* pL = LM + X::row(lg, 0) * LDK + 16 * FT + (li & 3);   // row lr + lg + 4 c, column 16 FT + 4 g + (li & 3)
         constexpr int RS = (sizeof(T) == 8) ? 4 : 1;            // row(lg, c) = row(lg, 0) + RS c  (f64: lg + 4 c; f32: 4 lg + c)
-        for (int lt = lt0; lt < lt1; ++lt, pA += 16 * LDK, pT += 16 * LDK, pv += 16) {
+        for (int lt = lt0; lt < lt1; ++lt, pA += 16 * LDK, pT += 16 * LDK, pL += 16 * LDK, pv += 16) {
           accT h = {0, 0, 0, 0};
 #pragma unroll
           for (int c = 0; c < KS; ++c) h = X::mfma(lds_frag(pA + 4 * c), bfrag[c], h);
-          T afrag[KKT][4];                    // looped rows, transposed, for the sum product (independent of E)
+          T afrag[FTA][4];                    // looped rows, transposed, for the sum product (independent of E)
+          T afl[LGA][4];                      // (left-over rows: i = lane & 3 of each of the four blocks)
           if (want_sums) {
 #pragma unroll
-            for (int t = 0; t < KKT; ++t)
+            for (int t = 0; t < FT; ++t)
 #pragma unroll
               for (int c = 0; c < 4; ++c) afrag[t][c] = pT[RS * c * LDK + 16 * t];
+#pragma unroll
+            for (int g = 0; g < LG; ++g)
+#pragma unroll
+              for (int c = 0; c < 4; ++c) afl[g][c] = pL[RS * c * LDK + 4 * g];
           }
           accT E;
 #pragma unroll
@@ -908,9 +927,15 @@ __device__ __forceinline__ void quad_ell_mfma_body(const EngineView& ev, const d
           }
           if (want_sums) {
 #pragma unroll
-            for (int t = 0; t < KKT; ++t)
+            for (int t = 0; t < FT; ++t)
 #pragma unroll
               for (int c = 0; c < 4; ++c) acc[t] = X::mfma(afrag[t][c], E[c], acc[t]);
+            if constexpr (LG > 0) {
+#pragma unroll
+              for (int g = 0; g < LG; ++g)
+#pragma unroll
+                for (int c = 0; c < 4; ++c) accl[g] = __builtin_amdgcn_mfma_f64_4x4x4f64((double)afl[g][c], (double)E[c], accl[g], 0, 0, 0);
+            }
           }
         }
       }
@@ -920,22 +945,29 @@ __device__ __forceinline__ void quad_ell_mfma_body(const EngineView& ev, const d
     if (want_sums && ook) {
       if (ROLE == 0) {
 #pragma unroll
-        for (int t = 0; t < KKT; ++t)
+        for (int t = 0; t < FT; ++t)
 #pragma unroll
           for (int q = 0; q < 4; ++q) {
             const int kk = 16 * t + X::row(lg, q);
             if (kk < K2) ev.gCpart[((long long)r * N + oi) * K2 + kk] = (double)acc[t][q];
           }
+#pragma unroll
+        for (int g = 0; g < LG; ++g) {                          // (result lane = column + 16 row: row lg of group g)
+          const int kk = 16 * FT + 4 * g + lg;
+          if (kk < K2) ev.gCpart[((long long)r * N + oi) * K2 + kk] = accl[g];
+        }
       } else {
         const long long gi = (long long)r * Q * K + oi;        // [r][k][q]: the 16 nodes of the tile are contiguous
+        auto put = [&](const int kk, const double v) {
+          if (kk < K) ev.gmuq[gi + (long long)kk * Q] = -v * LN2;
+          else if (kk < K2) ev.gvarq[gi + (long long)(kk - K) * Q] = -v * LN2;
+        };
 #pragma unroll
-        for (int t = 0; t < KKT; ++t)
+        for (int t = 0; t < FT; ++t)
 #pragma unroll
-          for (int q = 0; q < 4; ++q) {
-            const int kk = 16 * t + X::row(lg, q);
-            if (kk < K) ev.gmuq[gi + (long long)kk * Q] = -(double)acc[t][q] * LN2;
-            else if (kk < K2) ev.gvarq[gi + (long long)(kk - K) * Q] = -(double)acc[t][q] * LN2;
-          }
+          for (int q = 0; q < 4; ++q) put(16 * t + X::row(lg, q), (double)acc[t][q]);
+#pragma unroll
+        for (int g = 0; g < LG; ++g) put(16 * FT + 4 * g + lg, accl[g]);
       }
     }
     if (ROLE == 0 && want_sums) {
