@@ -166,6 +166,7 @@ struct EngineView {
   double* Kzz; double* L; double* Linv;
   double* a; double* ut; double* Vt; double* klpart;   // klpart [R*K]
   double* muq; double* varq; double* gmuq; double* gvarq;
+  long long glat2;            // != 0: gmuq / gvarq of this evaluation are the sum of two planes this many doubles apart (k_quad_ell_fused)
   double* P0; double* P1; double* Tpart;           // spike partials
   double* gCspk;                                   // [R][N][K] spike part of dC per trial (segment, or its first part)
   double* gCspkB;                                  // [R][N][K] second part of segments cut by a chunk boundary / cut to fill a tile: VALID

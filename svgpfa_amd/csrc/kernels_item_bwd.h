@@ -476,13 +476,22 @@ __device__ __forceinline__ void load_factors_tp(const EngineView& ev, const Late
 
 // Nodes [n0, n0 + cnt) of a node list -> LDS, padded to a multiple of `quant` nodes: a padded node repeats the chunk's first
 // time with zero adjoints (it adds exact zeros to every sum).
+// p2 != 0: the adjoints arrive in two planes p2 doubles apart (the fused ELL kernel's neuron groups: kernels_mfma.h
+// k_quad_ell_fused), added here in plane order.
 __device__ __forceinline__ void stage_nodes(double* tql, double* gml, double* gvl, const double* tqr, const double* gmq,
-                                            const double* gvq, int n0, int cnt, int quant, int tid, int nth) {
+                                            const double* gvq, int n0, int cnt, int quant, int tid, int nth,
+                                            const long long p2 = 0) {
   const int np = (cnt + quant - 1) / quant * quant;
   for (int i = tid; i < np; i += nth) {
     const bool ok = i < cnt;
     const int src = n0 + (ok ? i : 0);
-    const double t = tqr[src], x = gmq[src], y = gvq[src];
+    const double t = tqr[src];
+    double x = gmq[src], y = gvq[src];
+    if (p2) {                                          // (block-uniform)
+      const double x2 = gmq[src + p2], y2 = gvq[src + p2];
+      x += x2;
+      y += y2;
+    }
     tql[i] = t;
     gml[i] = ok ? x : 0.0;
     gvl[i] = ok ? y : 0.0;
@@ -550,7 +559,7 @@ __device__ __forceinline__ void item_bwd_body(const EngineView& ev, const int r,
     load_factors_tp<NT>(ev, m, r, Li, Vl, ul, zl);
     // the first chunk of the quadrature nodes, requested with the factors (the barrier in front of phase 1 publishes it)
     stage_nodes(tql, gml, gvl, ev.tq + (long long)r * Q, ev.gmuq + ((long long)r * K + k) * Q,
-                ev.gvarq + ((long long)r * K + k) * Q, 0, Q < QC ? Q : QC, nquant, tid, NTHB);
+                ev.gvarq + ((long long)r * K + k) * Q, 0, Q < QC ? Q : QC, nquant, tid, NTHB, ev.glat2);
   } else if (tid < MP) {
     ul[tid] = 0.0;
     zl[tid] = 0.0;
@@ -631,7 +640,7 @@ __device__ __forceinline__ void item_bwd_body(const EngineView& ev, const int r,
       const int cnt = (Qs - n0 < QC) ? Qs - n0 : QC;
       if (seg | n0) {                            // (the first chunk of the quadrature nodes was staged at the top)
         __syncthreads();
-        stage_nodes(tql, gml, gvl, tqr, gmq, gvq, n0, cnt, nquant, tid, NTHB);
+        stage_nodes(tql, gml, gvl, tqr, gmq, gvq, n0, cnt, nquant, tid, NTHB, seg ? 0 : ev.glat2);
         __syncthreads();
       }
       const int ntiles = (cnt + 15) >> 4;
@@ -840,7 +849,7 @@ __device__ __forceinline__ void item_bwd_body(const EngineView& ev, const int r,
       const int cnt = (Qs - n0 < QC) ? Qs - n0 : QC;
       if (seg | n0) {                            // (the first chunk of the quadrature nodes was staged at the top)
         __syncthreads();
-        stage_nodes(tql, gml, gvl, tqr, gmq, gvq, n0, cnt, nquant, tid, NTHB);
+        stage_nodes(tql, gml, gvl, tqr, gmq, gvq, n0, cnt, nquant, tid, NTHB, seg ? 0 : ev.glat2);
         __syncthreads();
       }
       // A team without a tile in the chunk's last step works on padding: nodes with zero adjoints (stage_nodes) that add

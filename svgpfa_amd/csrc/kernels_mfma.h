@@ -1018,3 +1018,362 @@ __global__ __launch_bounds__(512) void k_quad_ell_mfma(EngineView ev, const doub
                                                        blockIdx.x, sm);
   }
 }
+
+// ------------------------------------------------------------------------- k_quad_ell_fused  (round 5)
+// Both sums of the quadrature term from ONE evaluation of E (fp64; dC / dd AND the latent adjoints wanted; N <= 32 NG
+// neurons, 2K <= 20).  The two roles of k_quad_ell_mfma each run the h product (KS MFMAs) and the four exponentials of a lane
+// for every (node tile, neuron tile) pair -- 5 of 13 + 5 matrix instructions and 68 of ~70 vector instructions per pair and
+// role at the north-star shape.  Here a block is (trial, GROUP of <= NG neuron tiles); a pair is evaluated as role 1 does
+// (E^T in accumulator layout: rows = neurons, columns = nodes):
+//   latent adjoints   [gmu | gvar]^T += [C | C^2/2]^T E^T           E^T is the B operand as it stands (contraction over rows)
+//   dC / dd           [A1 | A2]^T    += [mu | var]^T E              E = the tile TRANSPOSED through 2 KB of the wave's LDS (four
+//                                                                   ds_write_b64 + four ds_read_b64 per lane instead of the
+//                                                                   second h product and its exponentials); the accumulators
+//                                                                   of all NG neuron tiles stay in registers across the
+//                                                                   wave's node tiles (NG (KS + 1) doubles per lane)
+// Both operand matrices of the block sit in LDS (the group's [C | C^2/2] and ALL nodes' [mu | var] of the trial), so a wave
+// can take any pair: the block's QT ng pairs, in node-major order, are dealt over the waves in equal contiguous RANGES (13 x 7
+// pairs over four waves: 23 / 23 / 23 / 22 -- whole node tiles per wave would be 28 / 21 / 21 / 21).  A node tile cut by a
+// range boundary has its latent adjoints in two waves: the second part (the start of the later wave's range) goes to an LDS
+// slot, the first part's owner (it ends its range there, accumulators still in registers) adds the slot behind the loop's
+// barrier.  The waves' partial [A1 | A2] / column sums are added in wave order through LDS behind the loop (the looped
+// matrix's region).  What leaves the block complete: dC / dd rows of the group's neurons, the ELL partial; what leaves it
+// PARTIAL over the groups: the latent adjoints of the trial's nodes -- group g writes plane g of gmuq / gvarq (R K Q doubles
+// each: 8 MB at the north-star shape) and k_item_bwd's node staging adds the planes (EngineView::glat2).
+// Host: QT >= waves per block (a range then spans at least one whole tile's worth of pairs: no tile is cut twice).
+#ifndef SV_ELLF_DIAG
+#define SV_ELLF_DIAG 0      // diagnosis builds (wrong results): 1 no pair loop, 2 no reduction / output behind the loop
+#endif
+#ifndef SV_ELLF_CLK
+#define SV_ELLF_CLK 0       // diagnosis builds: 1 = threads 0 / 192 of three blocks print cycle stamps of the phases (device printf)
+#endif
+#define SV_ECK(i) do { if (SV_ELLF_CLK) eck[i] = wall_clock64(); } while (0)
+#define SV_ELLF_TRS 18      // row stride of the transpose tile: like LDK = 4 KS + 2, the transposed reads (18 li + lg) of a 32-lane group hit 64 different banks
+template <int KS, int NG>
+__device__ __forceinline__ void quad_ell_fused_body(const EngineView& ev, const double* C, const double* d, const int ngroups,
+                                                    const int blk, double* sm) {
+  constexpr int KKP = 4 * KS, LDK = KKP + 2, TRS = SV_ELLF_TRS;
+  constexpr int FT = KS / 4, LG = KS % 4, FTA = FT > 0 ? FT : 1, LGA = LG > 0 ? LG : 1;
+  constexpr int NACC = 4 * FT + LG;                  // accumulator doubles per lane of one [16 x 2K] sum
+  const double L2E = 1.4426950408889634074, LN2 = 0.69314718055994530942;
+  const int K = ev.K, N = ev.N, Q = ev.Q, K2 = 2 * K;
+  const int QT = (Q + 15) >> 4, NTl = (N + 15) >> 4;
+  const int r = blk / ngroups, grp = blk - r * ngroups;
+  const int g0 = (NTl * grp) / ngroups, ng = (NTl * (grp + 1)) / ngroups - g0;      // this group's neuron tiles (host: <= NG)
+  const int n0 = 16 * g0, nrow = (N - n0 < 16 * ng) ? N - n0 : 16 * ng;
+  const int tid = threadIdx.x, lane = tid & 63, li = lane & 15, lg = lane >> 4;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int NTH = blockDim.x, NW = NTH >> 6;
+  double* TR = sm;                                   // NW x 16 TRS    per wave: the transpose tile
+  double* SL = TR + NW * 16 * TRS;                   // (NW - 1) x NACC x 64   second parts of cut node tiles
+  double* red = SL + (NW - 1) * NACC * 64;           // 8
+  double* LM = red + 8;                              // 16 NG x LDK    log2e [C | C^2/2] of the group's neurons
+  double* lv = LM + 16 * NG * LDK;                   // 16 NG          log2e d_n (padding: the exponent offset)
+  double* MQ = lv + 16 * NG;                         // 16 QT x LDK    [mu | var] of the trial's nodes
+  double* wql = MQ + 16 * QT * LDK;                  // 16 QT          node weights (padding: 0)
+  double* EP = LM;                                   // behind the loop, over the operand matrices: the waves' partial sums
+  long long eck[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  SV_ECK(0);
+  // ---- staging: every element of the operand regions is written exactly once (values, or the zeros of the padding).
+  // Thread maps without an integer division per element (a first version spent as many vector instructions on index
+  // arithmetic outside the pair loop as the loop itself took: SQ_INSTS_VALU of the profile against the loop's count):
+  // C rows 16 at a time with lane & 15 = column (K <= 10 of 16 lanes load), nodes one per thread with the K loads unrolled.
+  for (int i = tid; i < 16 * NG; i += NTH) lv[i] = (i < nrow) ? d[n0 + i] * L2E : SV_ELL_OFF;
+  for (int i = tid; i < 16 * QT; i += NTH) wql[i] = (i < Q) ? ev.wq[(long long)r * Q + i] : 0.0;
+  {
+    // (all global loads of a thread -- its C elements and its nodes' statistics -- are requested before the first LDS store:
+    // batches of four with their stores in between were five exposed memory latencies per block, 10 us of the kernel)
+    const int c = tid & 15, rb = tid >> 4, RPI = NTH >> 4;          // column, row within a pass, rows per pass
+    constexpr int CP = (16 * NG + 15) / 16;                         // passes at 16 rows each (NTH >= 256 takes fewer)
+    const double* s0 = C + (long long)n0 * K;
+    double cv[CP];
+#pragma unroll
+    for (int u = 0; u < CP; ++u) {
+      const int row = u * RPI + rb;
+      cv[u] = (row < nrow && c < K) ? s0[row * K + c] : 0.0;
+    }
+    const double* m0 = ev.muq + (long long)r * Q * K;               // [k][q]: K runs of Q contiguous nodes
+    const double* m1 = ev.varq + (long long)r * Q * K;
+    for (int node = tid; node < 16 * QT; node += NTH) {
+      const bool ok = node < Q;
+      double v0[2 * KS], v1[2 * KS];                                // (K <= 2 KS)
+#pragma unroll
+      for (int u = 0; u < 2 * KS; ++u) {
+        const bool in = ok && u < K;
+        v0[u] = in ? m0[u * Q + node] : 0.0;
+        v1[u] = in ? m1[u * Q + node] : 0.0;
+      }
+      double* row = MQ + node * LDK;
+#pragma unroll
+      for (int u = 0; u < 2 * KS; ++u)
+        if (u < K) {
+          row[u] = v0[u];
+          row[K + u] = v1[u];
+        }
+      for (int cc = K2; cc < LDK; ++cc) row[cc] = 0.0;
+    }
+#pragma unroll
+    for (int u = 0; u < CP; ++u) {
+      const int row = u * RPI + rb;
+      if (row < 16 * NG) {
+        if (c < K) {
+          LM[row * LDK + c] = cv[u] * L2E;
+          LM[row * LDK + K + c] = 0.5 * cv[u] * cv[u] * L2E;
+        } else if (K2 + (c - K) < LDK) {
+          LM[row * LDK + K2 + (c - K)] = 0.0;                       // the row's padding columns (LDK - 2K <= 4 <= 16 - K)
+        }
+      }
+    }
+  }
+  SV_ECK(1);
+  __syncthreads();
+  SV_ECK(2);
+
+  d4 dacc[NG][FTA];
+  double daccl[NG][LGA], ddacc[NG];
+#pragma unroll
+  for (int lt = 0; lt < NG; ++lt) {
+#pragma unroll
+    for (int t = 0; t < FTA; ++t) dacc[lt][t] = (d4){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int g = 0; g < LGA; ++g) daccl[lt][g] = 0.0;
+    ddacc[lt] = 0.0;
+  }
+  double esum = 0.0;
+  double* tr = TR + wave * 16 * TRS;
+  const long long plane = (long long)grp * ev.R * Q * K;              // this group's plane of the latent adjoints
+  // this wave's range of the block's pairs (node-major)
+  const int P = QT * ng;
+  const int p0 = (P * wave) / NW, p1 = (P * (wave + 1)) / NW;
+  const int qa = p0 / ng, lta = p0 - qa * ng;                            // first pair
+  const int qb = (p1 - 1) / ng, ltb = (p1 - 1) - qb * ng + 1;            // last pair (+ 1)
+  d4 acc[FTA];
+  double accl[LGA];
+  auto put_tile = [&](const int q) {                                    // acc / accl -> the group's plane of gmuq / gvarq
+    const int oi = 16 * q + li;
+    if (oi < Q) {
+      const long long gi = plane + (long long)r * Q * K + oi;          // [r][k][q]: the 16 nodes of the tile are contiguous
+      auto put = [&](const int kk, const double v) {
+        if (kk < K) ev.gmuq[gi + (long long)kk * Q] = -v * LN2;
+        else if (kk < K2) ev.gvarq[gi + (long long)(kk - K) * Q] = -v * LN2;
+      };
+#pragma unroll
+      for (int t = 0; t < FT; ++t)
+#pragma unroll
+        for (int qq = 0; qq < 4; ++qq) put(16 * t + lg + 4 * qq, acc[t][qq]);
+#pragma unroll
+      for (int g = 0; g < LG; ++g) put(16 * FT + 4 * g + lg, accl[g]);
+    }
+  };
+  bool keep = false;                                  // the last node tile of the range is cut: its first part stays in acc
+  for (int q = qa; q <= qb && p0 < p1; ++q) {
+    const int lo = (q == qa) ? lta : 0, hi = (SV_ELLF_DIAG == 1) ? 0 : ((q == qb) ? ltb : ng);
+    const double* mq = MQ + 16 * q * LDK;
+    const double ov = wql[16 * q + li];
+    double bfrag[KS];                                 // the tile's nodes as the B operand of the h product
+#pragma unroll
+    for (int c = 0; c < KS; ++c) bfrag[c] = mq[li * LDK + 4 * c + lg];
+    double am[FTA][4], aml[LGA][4];                   // the same nodes, transposed: the A operand of the dC product
+#pragma unroll
+    for (int t = 0; t < FT; ++t)
+#pragma unroll
+      for (int c = 0; c < 4; ++c) am[t][c] = mq[(lg + 4 * c) * LDK + 16 * t + li];
+#pragma unroll
+    for (int g = 0; g < LG; ++g)
+#pragma unroll
+      for (int c = 0; c < 4; ++c) aml[g][c] = mq[(lg + 4 * c) * LDK + 16 * FT + 4 * g + (li & 3)];
+#pragma unroll
+    for (int t = 0; t < FTA; ++t) acc[t] = (d4){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int g = 0; g < LGA; ++g) accl[g] = 0.0;
+    double colsum = 0.0;
+#pragma unroll
+    for (int lt = 0; lt < NG; ++lt) {
+      if (lt >= lo && lt < hi) {                      // (wave-uniform)
+        const double* pA = LM + (16 * lt + li) * LDK + lg;
+        const double* pT = LM + (16 * lt + lg) * LDK + li;
+        const double* pL = LM + (16 * lt + lg) * LDK + 16 * FT + (li & 3);
+        const double* pv = lv + 16 * lt + lg;
+        d4 h = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int c = 0; c < KS; ++c) h = __builtin_amdgcn_mfma_f64_16x16x4f64(lds_frag(pA + 4 * c), bfrag[c], h, 0, 0, 0);
+        double afrag[FTA][4], afl[LGA][4];
+#pragma unroll
+        for (int t = 0; t < FT; ++t)
+#pragma unroll
+          for (int c = 0; c < 4; ++c) afrag[t][c] = pT[4 * c * LDK + 16 * t];
+#pragma unroll
+        for (int g = 0; g < LG; ++g)
+#pragma unroll
+          for (int c = 0; c < 4; ++c) afl[g][c] = pL[4 * c * LDK + 4 * g];
+        double E[4];
+#pragma unroll
+        for (int qq = 0; qq < 4; ++qq) {
+          E[qq] = ov * sv_exp2_neg(h[qq] + pv[4 * qq]);       // E^T[neuron lg + 4 qq][node li]
+          colsum += E[qq];
+          tr[(lg + 4 * qq) * TRS + li] = E[qq];
+        }
+        // (one wavefront's LDS instructions execute in order: the transposed reads see the writes above, and the next pair's
+        // writes cannot pass these reads -- only the COMPILER has to be kept from moving them, hence no s_waitcnt-carrying fence)
+        asm volatile("" ::: "memory");
+        double ET[4];                                 // E[node lg + 4 c][neuron li]
+#pragma unroll
+        for (int c = 0; c < 4; ++c) ET[c] = lds_frag(tr + li * TRS + lg + 4 * c);
+        asm volatile("" ::: "memory");
+#pragma unroll
+        for (int t = 0; t < FT; ++t)
+#pragma unroll
+          for (int c = 0; c < 4; ++c) acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(afrag[t][c], E[c], acc[t], 0, 0, 0);
+#pragma unroll
+        for (int g = 0; g < LG; ++g)
+#pragma unroll
+          for (int c = 0; c < 4; ++c) accl[g] = __builtin_amdgcn_mfma_f64_4x4x4f64(afl[g][c], E[c], accl[g], 0, 0, 0);
+        ddacc[lt] += (ET[0] + ET[1]) + (ET[2] + ET[3]);
+#pragma unroll
+        for (int t = 0; t < FT; ++t)
+#pragma unroll
+          for (int c = 0; c < 4; ++c) dacc[lt][t] = __builtin_amdgcn_mfma_f64_16x16x4f64(am[t][c], ET[c], dacc[lt][t], 0, 0, 0);
+#pragma unroll
+        for (int g = 0; g < LG; ++g)
+#pragma unroll
+          for (int c = 0; c < 4; ++c) daccl[lt][g] = __builtin_amdgcn_mfma_f64_4x4x4f64(aml[g][c], ET[c], daccl[lt][g], 0, 0, 0);
+      }
+    }
+    esum += colsum;
+    if (lo == 0 && hi == ng) {
+      put_tile(q);                                    // a whole node tile
+    } else if (lo > 0) {                              // the second part of a tile cut by the range boundary in front of this wave
+      double* sl = SL + (wave - 1) * NACC * 64 + lane;
+#pragma unroll
+      for (int t = 0; t < FT; ++t)
+#pragma unroll
+        for (int qq = 0; qq < 4; ++qq) sl[(4 * t + qq) * 64] = acc[t][qq];
+#pragma unroll
+      for (int g = 0; g < LG; ++g) sl[(4 * FT + g) * 64] = accl[g];
+    } else {
+      keep = true;                                    // the first part: finished behind the barrier (q == qb, the loop ends)
+    }
+  }
+  SV_ECK(3);
+  __syncthreads();                                    // every wave is done with the operand matrices; the slots are written
+  SV_ECK(4);
+  if (keep) {
+    const double* sl = SL + wave * NACC * 64 + lane;
+#pragma unroll
+    for (int t = 0; t < FT; ++t)
+#pragma unroll
+      for (int qq = 0; qq < 4; ++qq) acc[t][qq] += sl[(4 * t + qq) * 64];
+#pragma unroll
+    for (int g = 0; g < LG; ++g) accl[g] += sl[(4 * FT + g) * 64];
+    put_tile(qb);
+  }
+  // ---- the waves' partial [A1 | A2] rows and column sums.  Neuron tile lt is summed, in wave order, and written by wave
+  // lt % NW: every wave stores the partials of the tiles it does not own as register images over the operand matrices (dead
+  // since the barrier), one barrier, the owners add.  (Round 5, first version: the waves added their partials one after the
+  // other into one buffer, four barriers with one wave working at a time -- 13 of the kernel's 85 us.)
+  if (SV_ELLF_DIAG == 2) {
+#pragma unroll
+    for (int lt = 0; lt < NG; ++lt) asm volatile("" ::"v"(dacc[lt][0][0]), "v"(daccl[lt][0]), "v"(ddacc[lt]));
+    return;
+  }
+  double* DD = EP + (NW - 1) * NG * NACC * 64;        // [wave][NG][16] column sums
+#pragma unroll
+  for (int lt = 0; lt < NG; ++lt) {
+    if (lt < ng) {
+      const int o = lt % NW;
+      if (o != wave) {
+        double* sl = EP + (lt * (NW - 1) + (wave < o ? wave : wave - 1)) * NACC * 64 + lane;
+#pragma unroll
+        for (int t = 0; t < FT; ++t)
+#pragma unroll
+          for (int qq = 0; qq < 4; ++qq) sl[(4 * t + qq) * 64] = dacc[lt][t][qq];
+#pragma unroll
+        for (int g = 0; g < LG; ++g) sl[(4 * FT + g) * 64] = daccl[lt][g];
+      }
+      const double sdd = grp4_sum(ddacc[lt]);
+      if (lg == 0) DD[(wave * NG + lt) * 16 + li] = sdd;
+    }
+  }
+  SV_ECK(5);
+  __syncthreads();
+  SV_ECK(6);
+#pragma unroll
+  for (int lt = 0; lt < NG; ++lt) {
+    if (lt < ng && lt % NW == wave) {
+      d4 tot4[FTA];
+      double totl[LGA];
+      for (int w = 0; w < NW; ++w) {
+        const double* sl = EP + (lt * (NW - 1) + (w < wave ? w : w - 1)) * NACC * 64 + lane;
+#pragma unroll
+        for (int t = 0; t < FT; ++t)
+#pragma unroll
+          for (int qq = 0; qq < 4; ++qq) {
+            const double v = (w == wave) ? dacc[lt][t][qq] : sl[(4 * t + qq) * 64];
+            tot4[t][qq] = (w == 0) ? v : tot4[t][qq] + v;
+          }
+#pragma unroll
+        for (int g = 0; g < LG; ++g) {
+          const double v = (w == wave) ? daccl[lt][g] : sl[(4 * FT + g) * 64];
+          totl[g] = (w == 0) ? v : totl[g] + v;
+        }
+      }
+      const int n = n0 + 16 * lt + li;
+      if (n < N) {
+        double* dst = ev.gCpart + ((long long)r * N + n) * K2;
+#pragma unroll
+        for (int t = 0; t < FT; ++t)
+#pragma unroll
+          for (int qq = 0; qq < 4; ++qq) {
+            const int kk = 16 * t + lg + 4 * qq;
+            if (kk < K2) dst[kk] = tot4[t][qq];
+          }
+#pragma unroll
+        for (int g = 0; g < LG; ++g) {
+          const int kk = 16 * FT + 4 * g + lg;
+          if (kk < K2) dst[kk] = totl[g];
+        }
+        if (lg == 0) {
+          double sdd = DD[lt * 16 + li];
+          for (int w = 1; w < NW; ++w) sdd += DD[(w * NG + lt) * 16 + li];
+          ev.gdpart[(long long)r * N + n] = -sdd;
+        }
+      }
+    }
+  }
+  const double tot = block_sum(esum, red);
+  if (tid == 0) ev.ellq[blk] = -tot;
+  if (SV_ELLF_CLK) {
+    SV_ECK(7);
+    if ((blk == 5 || blk == 300 || blk == 800) && (tid == 0 || tid == 192))
+      printf("ellf blk %d tid %d start %lld: staged %lld barrier %lld loop %lld barrier %lld partials %lld barrier %lld end %lld (10 ns ticks)\n",
+             blk, tid, eck[0], eck[1] - eck[0], eck[2] - eck[0], eck[3] - eck[0], eck[4] - eck[0], eck[5] - eck[0], eck[6] - eck[0],
+             eck[7] - eck[0]);
+  }
+}
+
+#define SV_ELLF_NG 7        // neuron tiles per group of the fused ELL kernel (accumulators: NG (KS + 1) doubles per lane)
+#define SV_ELLF_KSMAX 5     // 2K <= 20 (KS = 6 takes 255 registers and spills four)
+#define SV_ELLF_NW 4        // waves per block
+__host__ __device__ constexpr int sv_ellf_lds_doubles(int KS, int QT) {
+  const int nacc = 4 * (KS / 4) + KS % 4, ldk = 4 * KS + 2;
+  const int operands = 16 * SV_ELLF_NG * ldk + 16 * SV_ELLF_NG + 16 * QT * ldk + 16 * QT;
+  const int partials = (SV_ELLF_NW - 1) * SV_ELLF_NG * nacc * 64 + SV_ELLF_NW * SV_ELLF_NG * 16;     // the epilogue's, over the operands
+  return SV_ELLF_NW * 16 * SV_ELLF_TRS + (SV_ELLF_NW - 1) * nacc * 64 + 8 + (operands > partials ? operands : partials);
+}
+template <int KS>
+__global__ __launch_bounds__(64 * SV_ELLF_NW, 2) void k_quad_ell_fused(EngineView ev, const double* C, const double* d,
+                                                                       int ngroups, int ncomb, int comb_full) {
+  extern __shared__ double sm[];
+  const int nell = ev.R * ngroups;
+  if ((int)blockIdx.x >= nell) {                       // rider blocks: the spike moments' combine (as in k_quad_ell_mfma)
+    const int nwb = (int)blockDim.x >> 6, wave = (int)threadIdx.x >> 6;
+    const int item = ((int)blockIdx.x - nell) * nwb + wave;
+    if (item < ncomb) {
+      double* lds = sm + wave * SV_COMB_LDS;
+      if (comb_full & 1) spike_comb_item<true>(ev, item, lds, (comb_full >> 1) & 1);
+      else spike_comb_item<false>(ev, item, lds, 0);
+    }
+    return;
+  }
+  quad_ell_fused_body<KS, SV_ELLF_NG>(ev, C, d, ngroups, blockIdx.x, sm);
+}

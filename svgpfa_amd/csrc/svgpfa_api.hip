@@ -33,6 +33,7 @@ struct svgpfa_engine {
   int ell_parts = 0, KKT = 1;  // ell_parts > 0: MFMA GEMM form of the quadrature term
   int ell_lc[2] = {0, 0};      // looped tiles resident in LDS per role (fewer than all: streamed in chunks)
   int ell_nw = 4;              // waves per block of the ELL kernels
+  int ellf_groups = 0;         // > 0: evaluations that want dC / dd AND latent adjoints run k_quad_ell_fused with this many neuron groups per trial
   int times_nw = 4;            // waves per block of k_times_fwd (SVGPFA_TIMES_NW, up to SV_TIMES_MAXTH / 64)
   int tile_nw = 4;             // waves per block of k_item_bwd = NT x teams (a multiple of NT, at most 4)
   long long totM = 0, totMM = 0, totTT = 0;  // R*sum M, R*sum M^2, R*sum M(M+1)/2
@@ -145,6 +146,16 @@ static size_t lds_qell_mfma(const svgpfa_engine* e, int role) { return lds_qell_
     case 13: { constexpr int KS_ = 13; __VA_ARGS__; } break; case 14: { constexpr int KS_ = 14; __VA_ARGS__; } break; \
     case 15: { constexpr int KS_ = 15; __VA_ARGS__; } break; default: { constexpr int KS_ = 16; __VA_ARGS__; } break; \
   }
+// the fused ELL kernel exists for 2K <= 20 (SV_ELLF_KSMAX)
+#define DISPATCH_KSF(ks, ...)                                                                           \
+  switch (ks) {                                                                                         \
+    case 1: { constexpr int KS_ = 1; __VA_ARGS__; } break;   case 2: { constexpr int KS_ = 2; __VA_ARGS__; } break;   \
+    case 3: { constexpr int KS_ = 3; __VA_ARGS__; } break;   case 4: { constexpr int KS_ = 4; __VA_ARGS__; } break;   \
+    default: { constexpr int KS_ = 5; __VA_ARGS__; } break;  \
+  }
+static size_t lds_qell_fused(int KS, int Q) {      // (the rider blocks' combine area fits below it)
+  return std::max((size_t)sv_ellf_lds_doubles(KS, (Q + 15) / 16), (size_t)SV_ELLF_NW * SV_COMB_LDS) * sizeof(double);
+}
 static size_t lds_prep_mfma(int NT) {
   size_t MP = 16 * NT, LD = MP + 2;
   return (2 * MP * LD + NT + 64 + SV_PRE_LDS) * 8;
@@ -221,8 +232,16 @@ int svgpfa_create(const svgpfa_dims* d, int device, svgpfa_engine** out) {
   DALLOC(e, v.Kzz, e->totMM); DALLOC(e, v.L, e->totMM); DALLOC(e, v.Linv, e->totTT);
   DALLOC(e, v.a, e->totM); DALLOC(e, v.ut, e->totM); DALLOC(e, v.Vt, e->totTT); DALLOC(e, v.klpart, (size_t)v.R * v.K);
   size_t rqk = (size_t)v.R * v.Q * v.K;
-  DALLOC(e, v.muq, rqk); DALLOC(e, v.varq, rqk); DALLOC(e, v.gmuq, rqk); DALLOC(e, v.gvarq, rqk);
   e->KKT = (2 * v.K + 3) / 4;   // KS: k-steps of the h product
+  // (the fused ELL kernel's neuron groups each write a plane of the latent adjoints: kernels_mfma.h k_quad_ell_fused)
+  const int ellf_groups_max = ((v.N + 15) / 16 + SV_ELLF_NG - 1) / SV_ELLF_NG;
+  // (shape limits: 2K <= 20, at most two groups of SV_ELLF_NG neuron tiles, at least one node tile per wave, both operand
+  // matrices of a block within half of a CU's LDS)
+  const bool ellf_can = e->precision == SVGPFA_PRECISION_FP64 && e->KKT <= SV_ELLF_KSMAX && ellf_groups_max <= 2 &&
+                        (v.Q + 15) / 16 >= SV_ELLF_NW && lds_qell_fused(e->KKT, v.Q) <= 80 * 1024;
+  const size_t gplanes = (ellf_can && ellf_groups_max == 2) ? 2 : 1;
+  DALLOC(e, v.muq, rqk); DALLOC(e, v.varq, rqk); DALLOC(e, v.gmuq, gplanes * rqk); DALLOC(e, v.gvarq, gplanes * rqk);
+  v.glat2 = 0;
   // blocks per trial of the ELL kernels: every block re-stages the trial's looped operand in LDS, so fewer blocks
   // per trial are cheaper as long as the grid still fills the chip (measured on cfg3: 1 -> 151 us, 4 -> 168 us)
   e->ell_parts = std::min(4, std::max(1, (383 + v.R) / v.R));
@@ -246,7 +265,7 @@ int svgpfa_create(const svgpfa_dims* d, int device, svgpfa_engine** out) {
   v.ncd = v.R;
   v.nell = v.R * e->ell_parts;
   DALLOC(e, v.gCpart, (size_t)v.ncd * v.N * 2 * v.K); DALLOC(e, v.gdpart, (size_t)v.ncd * v.N);
-  DALLOC(e, v.ellq, (size_t)v.nell);
+  DALLOC(e, v.ellq, (size_t)std::max(v.nell, 2 * v.R));
   DALLOC(e, v.ells, (size_t)v.R * v.K); DALLOC(e, v.gthitem, (size_t)v.R * v.K * 2);
   DALLOC(e, v.Mseg, (size_t)v.N * v.K);
   // class path of the spike pass: class table, per-(class, trial) parameters, per-(trial, latent) switch and sums
@@ -309,6 +328,14 @@ int svgpfa_create(const svgpfa_dims* d, int device, svgpfa_engine** out) {
     e->grid_pair = std::max(8, (prop.multiProcessorCount * std::max(1, bp)) & ~7);
   }
 
+  {
+    // The fused ELL kernel (one evaluation of E for both sums) where its grid fills the chip: below that the two roles' finer
+    // blocks (ell_parts per trial and role) do.  SVGPFA_ELL_FUSED=0|1 overrides the size rule (never the shape limits).
+    const char* ef = getenv("SVGPFA_ELL_FUSED");
+    const bool want = ef ? atoi(ef) != 0 : ((long long)v.R * ellf_groups_max >= e->n_cu);
+    e->ellf_groups = (want && ellf_can) ? ellf_groups_max : 0;
+  }
+
   int rc = 0;
   if (e->NT == 2) rc = allow_lds(e, (k_build_mfma<2>), sv_build_mfma_lds(2, v.K, true));
   else if (e->NT == 3) rc = allow_lds(e, (k_build_mfma<3>), sv_build_mfma_lds(3, v.K, true));
@@ -328,6 +355,10 @@ int svgpfa_create(const svgpfa_dims* d, int device, svgpfa_engine** out) {
                 if (!rc) rc = allow_lds(e, (k_quad_ell_mfma<KS_, 2, double>), std::max(lds_qell_mfma(e, 0), lds_qell_mfma(e, 1))));
   }
   if (rc) return rc;
+  if (e->ellf_groups > 0) {
+    DISPATCH_KSF(e->KKT, rc = allow_lds(e, (k_quad_ell_fused<KS_>), lds_qell_fused(e->KKT, e->v.Q)));
+    if (rc) return rc;
+  }
   HIPCHK(e, sv_allow_ell_cls(e->KKT));     // k_ell_cls (small shards) on THIS device
   return SVGPFA_OK;
 }
@@ -757,6 +788,16 @@ static int launch_quad_ell(svgpfa_engine* e, hipStream_t st, const double* C, co
   return SVGPFA_OK;
 }
 
+// dC / dd and the latent adjoints from one evaluation of E (k_quad_ell_fused): R * groups blocks of four waves, riders as above
+static int launch_quad_ell_fused(svgpfa_engine* e, hipStream_t st, const EngineView& ve, const double* C, const double* d,
+                                 int ncomb, int comb_full) {
+  const unsigned nrb = ncomb > 0 ? (unsigned)((ncomb + SV_ELLF_NW - 1) / SV_ELLF_NW) : 0u;
+  DISPATCH_KSF(e->KKT, hipLaunchKernelGGL((k_quad_ell_fused<KS_>), dim3((unsigned)(ve.R * e->ellf_groups) + nrb), dim3(64 * SV_ELLF_NW),
+                                          lds_qell_fused(e->KKT, e->v.Q), st, ve, C, d, e->ellf_groups, ncomb, comb_full));
+  HIPCHK(e, hipGetLastError());
+  return SVGPFA_OK;
+}
+
 static int launch_times(svgpfa_engine* e, hipStream_t st, const double* times, const long long* toff, int nper, double* mu,
                         double* var, long long os_r, long long os_t, long long os_k, int want_var) {
   EngineView& v = e->v;
@@ -943,6 +984,13 @@ static int enqueue_elbo(svgpfa_engine* e, const PtrTable& pt, const ElboPlan& pl
   const bool comb_rides = e->comb_ride && !merged && pl.run_spike && e->cls_on && v.ntiles > 0 && !v.comb_fold;
   EngineView ve = v;               // this evaluation's view: the number of ELL partials follows the blocks per trial
   if (merged) ve.nell = v.R * parts_m;
+  // dC / dd and latent adjoints both wanted, at a size whose grid fills the chip: the fused ELL kernel, whose neuron groups
+  // each write a plane of the latent adjoints (k_item_bwd adds them) and an ELL partial
+  const bool ell_fused = !merged && e->ellf_groups > 0 && (mask & 2u) && pl.want_lat;
+  if (ell_fused) {
+    ve.nell = v.R * e->ellf_groups;
+    ve.glat2 = (e->ellf_groups == 2) ? (long long)v.R * v.Q * v.K : 0;
+  }
   if (pl.run_spike) {
     const int evp = timing_begin(e, 0, sm);
     if (merged) {
@@ -963,8 +1011,11 @@ static int enqueue_elbo(svgpfa_engine* e, const PtrTable& pt, const ElboPlan& pl
   }
   // ---- quadrature chain (f64 MFMA): posterior statistics at the nodes -> ELL term and its adjoints
   if (!e->front && (rc = launch_times_quad(e, sm))) return rc;
-  if (!merged && (rc = launch_quad_ell(e, sm, C, d, (mask & 2u) ? 1 : 0, pl.want_lat ? 1 : 0, comb_rides ? v.R * v.K : 0,
-                                       (pl.full ? 1 : 0) | ((pl.full && (mask & 4u)) ? 2 : 0)))) return rc;
+  const int comb_fl = (pl.full ? 1 : 0) | ((pl.full && (mask & 4u)) ? 2 : 0);
+  if (ell_fused) {
+    if ((rc = launch_quad_ell_fused(e, sm, ve, C, d, comb_rides ? v.R * v.K : 0, comb_fl))) return rc;
+  } else if (!merged && (rc = launch_quad_ell(e, sm, C, d, (mask & 2u) ? 1 : 0, pl.want_lat ? 1 : 0, comb_rides ? v.R * v.K : 0,
+                                              comb_fl))) return rc;
   // ---- per-item adjoints + backward + the fixed-order cross-trial reductions in one kernel
   const int evb = timing_begin(e, 1, sm);
   if (mask & (4u | 8u)) {

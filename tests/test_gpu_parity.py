@@ -184,7 +184,9 @@ def test_not_positive_definite_raises():
                                  {"SVGPFA_PAIR_RIDE": "0", "SVGPFA_ELL_CLS": "0", "SVGPFA_RBF_SERIES": "0"},
                                  {"SVGPFA_CLS_FUSED": "0", "SVGPFA_RBF_SERIES": "0"},
                                  {"SVGPFA_COMB_FOLD": "0", "SVGPFA_ELL_CLS": "0"},      # the combine rides in the ELL kernel's launch
-                                 {"SVGPFA_COMB_FOLD": "0", "SVGPFA_ELL_CLS": "0", "SVGPFA_CLS_FUSED": "0", "SVGPFA_COMB_RIDE": "0"}],
+                                 {"SVGPFA_COMB_FOLD": "0", "SVGPFA_ELL_CLS": "0", "SVGPFA_CLS_FUSED": "0", "SVGPFA_COMB_RIDE": "0"},
+                                 {"SVGPFA_ELL_FUSED": "1", "SVGPFA_ELL_CLS": "0"},      # both sums of the quadrature term from one evaluation of E
+                                 {"SVGPFA_ELL_FUSED": "1", "SVGPFA_ELL_CLS": "0", "SVGPFA_COMB_FOLD": "0"}],
                          ids=lambda e: "-".join(f"{k[7:].lower()}{v}" for k, v in e.items()))
 def test_launch_switches_agree_with_the_default(monkeypatch, env):
     """Every launch-strategy switch of the engine (README.md, environment) at its non-default values against the default
@@ -198,7 +200,7 @@ def test_launch_switches_agree_with_the_default(monkeypatch, env):
         prob["theta"][k] = prob["theta"][k] * np.array([lsc, psc][:len(prob["theta"][k])])
     outs = []
     for e in ({}, env):
-        for var in ("SVGPFA_COMB_FOLD", "SVGPFA_TILE_NW", "SVGPFA_CLS_FUSED", "SVGPFA_ELL_PARTS", "SVGPFA_TIMES_NW", "SVGPFA_FRONT", "SVGPFA_BUILD", "SVGPFA_ELL_CLS", "SVGPFA_PAIR_RIDE", "SVGPFA_RBF_SERIES", "SVGPFA_COMB_RIDE", "SVGPFA_ELL_NW"):
+        for var in ("SVGPFA_COMB_FOLD", "SVGPFA_TILE_NW", "SVGPFA_CLS_FUSED", "SVGPFA_ELL_PARTS", "SVGPFA_TIMES_NW", "SVGPFA_FRONT", "SVGPFA_BUILD", "SVGPFA_ELL_CLS", "SVGPFA_PAIR_RIDE", "SVGPFA_RBF_SERIES", "SVGPFA_COMB_RIDE", "SVGPFA_ELL_NW", "SVGPFA_ELL_FUSED"):
             monkeypatch.delenv(var, raising=False)
         if "SVGPFA_RBF_SERIES" in env:             # both runs with the RBF latents pair by pair: the rider has work to do
             monkeypatch.setenv("SVGPFA_RBF_SERIES", env["SVGPFA_RBF_SERIES"])
@@ -214,6 +216,36 @@ def test_launch_switches_agree_with_the_default(monkeypatch, env):
     tol = 1e-10 if "SVGPFA_BUILD" in env else 1e-12       # (another factorisation order: rounding of the Cholesky itself)
     for a, b in zip(outs[0], outs[1]):
         assert rel_err(b, a) < tol
+
+
+@pytest.mark.parametrize("N,K,Q", [(200, 10, 200), (130, 3, 70), (97, 7, 64), (224, 1, 129), (40, 4, 333)],
+                         ids=lambda v: str(v))
+def test_fused_quadrature_ell_agrees_with_the_two_roles(monkeypatch, N, K, Q):
+    """k_quad_ell_fused (dC / dd and the latent adjoints from one evaluation of E; its blocks deal (node tile, neuron tile)
+    pairs over the waves in ranges that cut node tiles, its neuron groups write planes of the latent adjoints that k_item_bwd
+    adds) against k_quad_ell_mfma's two roles and the oracle: one and two neuron groups, ragged last tiles in both
+    dimensions, 2K = 2 .. 20 (whole 16-row tiles and left-over groups of four rows), node tiles from 4 (the fewest it takes)
+    to 21.  On small problems the size rule keeps the two roles; SVGPFA_ELL_FUSED=1 forces the fused kernel."""
+    from oracle import svgpfa_oracle as orc
+    prob = synthetic.make_problem(R=3, N=N, K=K, M=[9 + 3 * (k % 4) for k in range(K)], kernels="mix", seed=31 + N, n_quad=Q,
+                                  rate=8.0, jitter=1.0)
+    outs = []
+    for fused in ("0", "1"):
+        monkeypatch.setenv("SVGPFA_ELL_FUSED", fused)
+        monkeypatch.setenv("SVGPFA_ELL_CLS", "0")
+        eng, P = _engine(prob)
+        for mask in (15, 3):                          # all groups; the value with the variational and embedding groups only
+            shared, gm, gc, gz = eng.elbo(P["mean"], P["cholVecs"], P["C"], P["d"], mask)
+            eng.sync()
+            outs.append([shared.cpu().numpy()] + [t.cpu().numpy() for t in (gm or []) + (gc or []) + (gz or [])])
+        eng.close()
+    ref = orc.elbo_and_grads(orc.from_numpy_problem(prob), 15)
+    for o in (outs[0], outs[2]):
+        assert abs(o[0][0] - float(ref["elbo"])) <= 1e-9 * abs(float(ref["elbo"]))
+        for k in range(K):
+            assert rel_err(o[1 + k], ref["g_mean"][k][:, :, 0].numpy()) < 1e-7
+    for a, b in zip(outs[0] + outs[1], outs[2] + outs[3]):
+        assert rel_err(b, a) < 1e-12
 
 
 @pytest.mark.parametrize("Ms", [[10, 24, 9, 30, 11], [9, 16, 12]], ids=["M<=32", "M<=16"])
