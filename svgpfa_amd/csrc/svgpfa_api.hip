@@ -60,7 +60,9 @@ struct svgpfa_engine {
   // through the same queues and barrier packets -- all removed in round 4)
   // Both kinds of class (with / without time-weighted moments) in ONE launch: default up to R K = 4096 items (one launch
   // boundary -- a drained chip -- less: one rank's shard of cfg3, ms per evaluation, two kernels -> one: 2-way 0.405 -> 0.386,
-  // 4-way 0.266 -> 0.249, 8-way 0.198 -> 0.176; at the full 5 000 items 0.655 / 0.659).  SVGPFA_CLS_FUSED=0 / 1 forces it.
+  // 4-way 0.266 -> 0.249, 8-way 0.198 -> 0.176; at the full 5 000 items 0.655 / 0.659 in round 3, 62 -> 52 us of class kernels
+  // in round 5: cls_single_kernel).  -1: one kernel at every size, and up to 4 096 items the ELL blocks in the same launch
+  // (k_ell_cls); SVGPFA_CLS_FUSED=1: both at every size; 0: two class kernels, launches apart.
   int cls_fused = -1;
   int n_cu = 256;                               // compute units of the device
   bool ell_cls = true;                          // small shards: ELL blocks and class items in one launch (SVGPFA_ELL_CLS=0: off)
@@ -887,9 +889,15 @@ static void launch_pair_pass(svgpfa_engine* e, hipStream_t sk, bool full, bool w
 // rest; both stride fixed grids over work lists that live on the device.
 // one launch for all classes of the class path (shards), or the classes with time-weighted moments (periodic, when Z / theta
 // gradients are wanted) in a kernel of their own
-static bool cls_one_launch(const svgpfa_engine* e) {
+static bool cls_one_launch(const svgpfa_engine* e) {      // ... and, with it, the small-shard launch k_ell_cls
   return e->cls_fused == 1 || (e->cls_fused < 0 && (long long)e->v.R * e->v.K <= 4096);
 }
+// The class kernels of their own launch: both kinds of class in ONE kernel at every size unless SVGPFA_CLS_FUSED=0 (round 5:
+// at the north-star size 52 us against 32 + 30 for the two launches, measured once the time-weighted moments were carried
+// for the kernel-parameter gradient only.  Its workers take their (tile, class) items by stride: handed out by ticket --
+// one counter 245 us, 60 ns per atomic serialised across the XCDs; 256 counters, one per group of eight workers, 53.5 us --
+// they are no faster, so the SIMDs' unequal item counts are not what the kernel waits for.)
+static bool cls_single_kernel(const svgpfa_engine* e) { return e->cls_fused != 0; }
 
 // The pair-by-pair pass rides in the class kernel's launch (fp64, class path running: cls_pair_rider) instead of taking a
 // launch of its own; SVGPFA_PAIR_RIDE=0 keeps the launch.
@@ -904,7 +912,7 @@ static int launch_spike_pass(svgpfa_engine* e, hipStream_t sk, bool full, bool w
   const unsigned gc = (unsigned)std::min<long long>((long long)v.ntiles * v.K, e->grid_cls);
   const bool ride = pair_rides(e);
   if (v.ntiles > 0 && e->cls_on) {
-    const bool fused = cls_one_launch(e);
+    const bool fused = cls_single_kernel(e);
     const bool tw = !fused && (fl & 2) && v.ntype[SV_PERIODIC] > 0;      // a launch for the classes with time-weighted moments
     const int dc = (full && want_c) ? 1 : 0;
     if (dc && !have_w) HIPCHK(e, sv_launch_spike_pre(v, sk));
