@@ -1000,12 +1000,8 @@ __global__ __launch_bounds__(512) void k_quad_ell_mfma(EngineView ev, const doub
   const int nell = nb0 + (ROLE == 2 ? ev.R * parts : 0);
   if ((int)blockIdx.x >= nell) {                       // rider blocks (only launched with ncomb > 0)
     const int nwb = (int)blockDim.x >> 6, wave = (int)threadIdx.x >> 6;
-    const int item = ((int)blockIdx.x - nell) * nwb + wave;
-    if (item < ncomb) {
-      double* lds = sm + wave * SV_COMB_LDS;
-      if (comb_full & 1) spike_comb_item<true>(ev, item, lds, (comb_full >> 1) & 1);      // (bit 0: full, bit 1: time-weighted moments)
-      else spike_comb_item<false>(ev, item, lds, 0);
-    }
+    const int unit = ((int)blockIdx.x - nell) * nwb + wave;
+    sv_comb_rider(ev, unit, ncomb, comb_full, sm, wave);      // (bit 0: full, bit 1: time-weighted moments, bit 2: two items per wave)
     return;
   }
   if (ROLE == 2) {
@@ -1367,12 +1363,7 @@ __global__ __launch_bounds__(64 * SV_ELLF_NW, 2) void k_quad_ell_fused(EngineVie
   const int nell = ev.R * ngroups;
   if ((int)blockIdx.x >= nell) {                       // rider blocks: the spike moments' combine (as in k_quad_ell_mfma)
     const int nwb = (int)blockDim.x >> 6, wave = (int)threadIdx.x >> 6;
-    const int item = ((int)blockIdx.x - nell) * nwb + wave;
-    if (item < ncomb) {
-      double* lds = sm + wave * SV_COMB_LDS;
-      if (comb_full & 1) spike_comb_item<true>(ev, item, lds, (comb_full >> 1) & 1);
-      else spike_comb_item<false>(ev, item, lds, 0);
-    }
+    sv_comb_rider(ev, ((int)blockIdx.x - nell) * nwb + wave, ncomb, comb_full, sm, wave);
     return;
   }
   quad_ell_fused_body<KS, SV_ELLF_NG>(ev, C, d, ngroups, blockIdx.x, sm);

@@ -431,7 +431,8 @@ static_assert(SV_CLS_SLICE >= sv_pair_lds_doubles(true), "a class worker's LDS s
 //   T1 (periodic) = sum_j a_j sum_n e_n [cos(n phi_j) Bt_n - sin(n phi_j) At_n - z_j Ss]
 // -> P0t / P1t [r][sum M], Tt [r][k][2]: what k_item_bwd's gather reads for this item.  grid = R K blocks of 64 threads.
 template <bool FULL>
-__global__ __launch_bounds__(64) void k_spike_comb(EngineView ev, int tw) {
-  __shared__ double lds[SV_COMB_LDS];
-  spike_comb_item<FULL>(ev, blockIdx.x, lds, tw);
+__global__ __launch_bounds__(64) void k_spike_comb(EngineView ev, int tw, int pairs) {
+  __shared__ double lds[2 * SV_COMB_LDS];
+  if (pairs) spike_comb_pair<FULL>(ev, 2 * (int)blockIdx.x, ev.R * ev.K, lds, tw);      // (M <= 32: two items per wave)
+  else spike_comb_item<FULL>(ev, blockIdx.x, lds, tw);
 }

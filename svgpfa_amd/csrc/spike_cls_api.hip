@@ -33,9 +33,11 @@ hipError_t sv_launch_spike_cls(const EngineView& v, const double* C, int nv, int
   return hipGetLastError();
 }
 
-hipError_t sv_launch_spike_comb(const EngineView& v, int full, hipStream_t s) {      // full: bit 0 full, bit 1 time-weighted moments
-  if (full & 1) hipLaunchKernelGGL(k_spike_comb<true>, dim3(v.R * v.K), dim3(64), 0, s, v, (full >> 1) & 1);
-  else hipLaunchKernelGGL(k_spike_comb<false>, dim3(v.R * v.K), dim3(64), 0, s, v, 0);
+hipError_t sv_launch_spike_comb(const EngineView& v, int full, hipStream_t s) {      // full: bit 0 full, bit 1 time-weighted moments, bit 2 two items per wave
+  const int pairs = (full >> 2) & 1;
+  const dim3 grid(pairs ? (v.R * v.K + 1) / 2 : v.R * v.K);
+  if (full & 1) hipLaunchKernelGGL(k_spike_comb<true>, grid, dim3(64), 0, s, v, (full >> 1) & 1, pairs);
+  else hipLaunchKernelGGL(k_spike_comb<false>, grid, dim3(64), 0, s, v, 0, pairs);
   return hipGetLastError();
 }
 

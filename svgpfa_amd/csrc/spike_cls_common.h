@@ -384,3 +384,122 @@ __device__ __forceinline__ void spike_comb_item(const EngineView& ev, const int 
     }
   }
 }
+
+// Two items per wavefront (round 5; M <= 32): lanes 0 .. 31 combine item0, lanes 32 .. 63 item0 + 1 -- the per-inducing-point
+// half of spike_comb_item keeps 32 of its 64 lanes busy at most, and as riders of the ELL kernels the combine's blocks hold a
+// CU's LDS two at a time: half the waves are half the rounds.  Same sums in the same order as spike_comb_item (the half-wave
+// sum adds the two rows of 16 exactly as wave_sum adds them to two rows of zeros).  lds: 2 SV_COMB_LDS doubles.
+template <bool FULL>
+__device__ __forceinline__ void spike_comb_pair(const EngineView& ev, const int item0, const int nitems, double* lds, const int tw) {
+  const int lane = threadIdx.x & 63, hl = lane & 31, half = lane >> 5, K = ev.K;
+  double* Fs = lds + half * SV_COMB_LDS;   // SV_ACOLS moments
+  double* cf = Fs + SV_ACOLS;              // 3 x (SV_FH + 1) coefficients
+  const bool there = item0 + half < nitems;
+  const int item = there ? item0 + half : item0;
+  const SpikeItem it = ev.sitem[item];
+  const bool live = there && it.H >= 0;
+  if (!__any(live)) return;
+  const int r = item / K, k = item % K;
+  const LatentMeta m = ev.meta[k];
+  const int M = m.M;
+  const int H = live ? it.H : -1;          // (a half without an item runs empty loops)
+  const double sc = it.sc, t0 = it.t0;
+  const KPar p = make_kpar(m, ev.theta + 2 * k);
+  const bool TW = FULL && tw && m.ktype == SV_PERIODIC;
+  const int NV = TW ? 4 : 2, ncol = NV * (H + 1);
+  const int tl0 = ev.tile_first[r], tl1 = ev.tile_first[r + 1];
+  double zj = t0, aj = 0.0;
+  if (live && hl < M) {
+    zj = ev.Zs[m.offM + (long long)r * M + hl];
+    aj = ev.a[m.offM + (long long)r * M + hl];
+  }
+  {   // the series coefficients of this half's latent (cls_coefficients with 32 lanes)
+    constexpr int NF = SV_FH + 2;
+    if (m.ktype == SV_PERIODIC) {
+      const double* tab = ev.four + (size_t)k * SV_FROWS * NF;
+      for (int n = hl; n <= H; n += 32) {
+        cf[n] = tab[n];
+        cf[(SV_FH + 1) + n] = tab[NF + n];
+        cf[2 * (SV_FH + 1) + n] = tab[2 * NF + n];
+      }
+    } else {
+      const double PI = 3.14159265358979323846, h = p.h;
+      const double L = 4.0 / sc, q = PI * PI / (h * L * L), w = 2.0 * PI / L, c0 = sqrt(PI / h) / L;
+      for (int n = hl; n <= H; n += 32) {
+        const double cn = (n ? 2.0 : 1.0) * c0 * exp(-q * (double)n * (double)n);
+        cf[n] = cn;
+        cf[(SV_FH + 1) + n] = cn * (0.5 / h - q * (double)n * (double)n / h);
+        cf[2 * (SV_FH + 1) + n] = (double)n * w * cn * (0.5 / h);
+      }
+    }
+  }
+  for (int c = hl; c < ncol; c += 32) {
+    double s = 0.0;
+    for (int t = tl0; t < tl1; t += 8) {            // eight tiles' partials in flight, added in tile order
+      double v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = ev.Apart[((long long)(t + u < tl1 ? t + u : t) * K + k) * SV_ACOLS + c];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) s += (t + u < tl1) ? v[u] : 0.0;
+    }
+    Fs[c] = s;
+  }
+  lds_wave_fence();
+  double t0acc = 0.0, t1acc = 0.0;
+  if (live && hl < M) {
+    double sphi, cphi;
+    sv_sincos_quarter((zj - t0) * sc, sphi, cphi);
+    const double* cN = cf;
+    const double* gN = cf + (SV_FH + 1);
+    const double* eN = cf + 2 * (SV_FH + 1);
+    double cj = 1.0, sj = 0.0, P0 = 0.0, P1 = 0.0, d0 = 0.0, d1 = 0.0;
+    for (int n = 0; n <= H; ++n) {
+      const double An = Fs[n * NV + 0], Bn = Fs[n * NV + 1];
+      const double Cc = fma(cj, An, sj * Bn), Ss = fma(cj, Bn, -(sj * An));
+      P0 = fma(cN[n], Cc, P0);
+      if (FULL) {
+        const double en = eN[n];
+        P1 = fma(en, Ss, P1);
+        d0 = fma(gN[n], Cc, d0);
+        if (TW) d1 = fma(en, fma(cj, Fs[n * NV + 3], -(sj * Fs[n * NV + 2])) - zj * Ss, d1);
+      }
+      const double tq = cj * cphi - sj * sphi;
+      sj = fma(sj, cphi, cj * sphi);
+      cj = tq;
+    }
+    const long long o = (long long)r * ev.sumM + m.colM + hl;
+    ev.P0t[o] = P0;
+    if (FULL) {
+      ev.P1t[o] = P1;
+      t0acc = aj * d0;
+      t1acc = aj * d1;
+    }
+  }
+  if (FULL) {
+    double ts0 = row16_sum(t0acc), ts1 = row16_sum(t1acc);
+    ts0 += __shfl_xor(ts0, 16, 64);
+    ts1 += __shfl_xor(ts1, 16, 64);
+    if (hl == 0 && live) {
+      ev.Tt[(long long)item * 2 + 0] = ts0;
+      ev.Tt[(long long)item * 2 + 1] = ts1;
+    }
+  }
+}
+
+// One rider wave of an ELL kernel: its unit of the combine -- one item, or (flags bit 2, M <= 32) two.  flags: bit 0 full,
+// bit 1 time-weighted moments.  sm: the block's dynamic LDS, a wave's area is SV_COMB_LDS doubles per item.
+__device__ __forceinline__ void sv_comb_rider(const EngineView& ev, const int unit, const int ncomb, const int flags, double* sm,
+                                              const int wave) {
+  if (flags & 4) {
+    const int item0 = 2 * unit;
+    if (item0 < ncomb) {
+      double* lds = sm + wave * 2 * SV_COMB_LDS;
+      if (flags & 1) spike_comb_pair<true>(ev, item0, ncomb, lds, (flags >> 1) & 1);
+      else spike_comb_pair<false>(ev, item0, ncomb, lds, 0);
+    }
+  } else if (unit < ncomb) {
+    double* lds = sm + wave * SV_COMB_LDS;
+    if (flags & 1) spike_comb_item<true>(ev, unit, lds, (flags >> 1) & 1);
+    else spike_comb_item<false>(ev, unit, lds, 0);
+  }
+}

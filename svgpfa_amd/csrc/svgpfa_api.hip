@@ -65,6 +65,7 @@ struct svgpfa_engine {
   // (k_ell_cls); SVGPFA_CLS_FUSED=1: both at every size; 0: two class kernels, launches apart.
   int cls_fused = -1;
   int n_cu = 256;                               // compute units of the device
+  bool comb_pairs = true;                       // the spike moments' combine with two items per wave where M <= 32 (SVGPFA_COMB_PAIRS=0: one)
   bool ell_cls = true;                          // small shards: ELL blocks and class items in one launch (SVGPFA_ELL_CLS=0: off)
   bool comb_ride = true;                        // the moments' combine rides in the ELL kernel's launch at full size (SVGPFA_COMB_RIDE=0: own launch)
   bool pair_ride = true;                        // the pair-by-pair pass rides in the class kernels' launch (SVGPFA_PAIR_RIDE=0: own launch)
@@ -156,7 +157,7 @@ static size_t lds_qell_mfma(const svgpfa_engine* e, int role) { return lds_qell_
     default: { constexpr int KS_ = 5; __VA_ARGS__; } break;  \
   }
 static size_t lds_qell_fused(int KS, int Q) {      // (the rider blocks' combine area fits below it)
-  return std::max((size_t)sv_ellf_lds_doubles(KS, (Q + 15) / 16), (size_t)SV_ELLF_NW * SV_COMB_LDS) * sizeof(double);
+  return std::max((size_t)sv_ellf_lds_doubles(KS, (Q + 15) / 16), (size_t)SV_ELLF_NW * 2 * SV_COMB_LDS) * sizeof(double);
 }
 static size_t lds_prep_mfma(int NT) {
   size_t MP = 16 * NT, LD = MP + 2;
@@ -301,6 +302,8 @@ int svgpfa_create(const svgpfa_dims* d, int device, svgpfa_engine** out) {
     v.rbf_series = (rs && atoi(rs) == 0) ? 0 : 1;
     const char* mp = getenv("SVGPFA_SERIES_MIN_PAIRS");
     if (mp) e->series_min_pairs = atof(mp);
+    const char* cp = getenv("SVGPFA_COMB_PAIRS");
+    e->comb_pairs = !(cp && atoi(cp) == 0);
     const char* ec = getenv("SVGPFA_ELL_CLS");
     e->ell_cls = !(ec && atoi(ec) == 0);
     const char* br = getenv("SVGPFA_BUILD");
@@ -764,8 +767,10 @@ static int launch_quad_ell(svgpfa_engine* e, hipStream_t st, const double* C, co
   // role 0 (dC, dd and the ELL value; its column sums give sum E) and role 1 (latent adjoints) share a launch when both are
   // wanted; the latent adjoints alone (E-step closure) are role-1 blocks only, which then write the ELL value themselves
   dim3 gm(v.R * e->ell_parts), bm(64 * e->ell_nw);
-  const unsigned nrb = ncomb > 0 ? (unsigned)((ncomb + e->ell_nw - 1) / e->ell_nw) : 0u;      // rider blocks
-  const size_t lrid = ncomb > 0 ? (size_t)e->ell_nw * SV_COMB_LDS * sizeof(double) : 0;
+  // rider blocks: one item per wave, or two (comb_full bit 2: M <= 32, sv_comb_pairs)
+  const int per = (comb_full & 4) ? 2 : 1;
+  const unsigned nrb = ncomb > 0 ? (unsigned)((ncomb + per * e->ell_nw - 1) / (per * e->ell_nw)) : 0u;
+  const size_t lrid = ncomb > 0 ? (size_t)e->ell_nw * per * SV_COMB_LDS * sizeof(double) : 0;
   const bool f32 = e->precision == SVGPFA_PRECISION_MIXED;
   if (want_lat) {
     const size_t l2 = std::max(std::max(lds_qell_mfma(e, 0), lds_qell_mfma(e, 1)), lrid);
@@ -793,7 +798,8 @@ static int launch_quad_ell(svgpfa_engine* e, hipStream_t st, const double* C, co
 // dC / dd and the latent adjoints from one evaluation of E (k_quad_ell_fused): R * groups blocks of four waves, riders as above
 static int launch_quad_ell_fused(svgpfa_engine* e, hipStream_t st, const EngineView& ve, const double* C, const double* d,
                                  int ncomb, int comb_full) {
-  const unsigned nrb = ncomb > 0 ? (unsigned)((ncomb + SV_ELLF_NW - 1) / SV_ELLF_NW) : 0u;
+  const int per = (comb_full & 4) ? 2 : 1;
+  const unsigned nrb = ncomb > 0 ? (unsigned)((ncomb + per * SV_ELLF_NW - 1) / (per * SV_ELLF_NW)) : 0u;
   DISPATCH_KSF(e->KKT, hipLaunchKernelGGL((k_quad_ell_fused<KS_>), dim3((unsigned)(ve.R * e->ellf_groups) + nrb), dim3(64 * SV_ELLF_NW),
                                           lds_qell_fused(e->KKT, e->v.Q), st, ve, C, d, e->ellf_groups, ncomb, comb_full));
   HIPCHK(e, hipGetLastError());
@@ -889,6 +895,9 @@ static void launch_pair_pass(svgpfa_engine* e, hipStream_t sk, bool full, bool w
 // rest; both stride fixed grids over work lists that live on the device.
 // one launch for all classes of the class path (shards), or the classes with time-weighted moments (periodic, when Z / theta
 // gradients are wanted) in a kernel of their own
+// bit 2 of the combine's flags: two (trial, latent) items per wave (every M <= 32: spike_cls_common.h spike_comb_pair);
+// SVGPFA_COMB_PAIRS=0 keeps one
+static int sv_comb_pairs(const svgpfa_engine* e) { return (e->NT <= 2 && e->comb_pairs) ? 4 : 0; }
 static bool cls_one_launch(const svgpfa_engine* e) {      // ... and, with it, the small-shard launch k_ell_cls
   return e->cls_fused == 1 || (e->cls_fused < 0 && (long long)e->v.R * e->v.K <= 4096);
 }
@@ -926,7 +935,7 @@ static int launch_spike_pass(svgpfa_engine* e, hipStream_t sk, bool full, bool w
       HIPCHK(e, sv_launch_spike_cls(v, C, 2, dc, (dc || full) ? fl : 0, ride ? 1 : 0, gr, sk));
     }
   }
-  if (!v.comb_fold && e->cls_on && !comb_rides) HIPCHK(e, sv_launch_spike_comb(v, fl, sk));
+  if (!v.comb_fold && e->cls_on && !comb_rides) HIPCHK(e, sv_launch_spike_comb(v, fl | sv_comb_pairs(e), sk));
   if (!ride) {
     launch_pair_pass(e, sk, full, want_c, C);
     HIPCHK(e, hipGetLastError());
@@ -1010,7 +1019,7 @@ static int enqueue_elbo(svgpfa_engine* e, const PtrTable& pt, const ElboPlan& pl
       const bool ride = pair_rides(e);
       HIPCHK(e, sv_launch_ell_cls(ve, C, d, e->KKT, dc, want_c ? 1 : 0, pl.want_lat ? 1 : 0, parts_m, e->ell_lc[0], e->ell_lc[1],
                                   fl, ride ? 1 : 0, workers, lds_ell, sm));
-      if (!v.comb_fold) HIPCHK(e, sv_launch_spike_comb(v, fl, sm));
+      if (!v.comb_fold) HIPCHK(e, sv_launch_spike_comb(v, fl | sv_comb_pairs(e), sm));
       if (!ride) launch_pair_pass(e, sm, full, want_c, C);
     } else {
       if ((rc = launch_spike_pass(e, sm, pl.full, (mask & 2u) != 0, C, have_w, comb_rides, (mask & 4u) != 0))) return rc;
@@ -1019,7 +1028,7 @@ static int enqueue_elbo(svgpfa_engine* e, const PtrTable& pt, const ElboPlan& pl
   }
   // ---- quadrature chain (f64 MFMA): posterior statistics at the nodes -> ELL term and its adjoints
   if (!e->front && (rc = launch_times_quad(e, sm))) return rc;
-  const int comb_fl = (pl.full ? 1 : 0) | ((pl.full && (mask & 4u)) ? 2 : 0);
+  const int comb_fl = (pl.full ? 1 : 0) | ((pl.full && (mask & 4u)) ? 2 : 0) | sv_comb_pairs(e);
   if (ell_fused) {
     if ((rc = launch_quad_ell_fused(e, sm, ve, C, d, comb_rides ? v.R * v.K : 0, comb_fl))) return rc;
   } else if (!merged && (rc = launch_quad_ell(e, sm, C, d, (mask & 2u) ? 1 : 0, pl.want_lat ? 1 : 0, comb_rides ? v.R * v.K : 0,

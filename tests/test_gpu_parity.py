@@ -185,6 +185,8 @@ def test_not_positive_definite_raises():
                                  {"SVGPFA_CLS_FUSED": "0", "SVGPFA_RBF_SERIES": "0"},
                                  {"SVGPFA_COMB_FOLD": "0", "SVGPFA_ELL_CLS": "0"},      # the combine rides in the ELL kernel's launch
                                  {"SVGPFA_COMB_FOLD": "0", "SVGPFA_ELL_CLS": "0", "SVGPFA_CLS_FUSED": "0", "SVGPFA_COMB_RIDE": "0"},
+                                 {"SVGPFA_COMB_FOLD": "0", "SVGPFA_ELL_CLS": "0", "SVGPFA_COMB_PAIRS": "0"},      # ... one item per rider wave
+                                 {"SVGPFA_COMB_FOLD": "0", "SVGPFA_ELL_CLS": "0", "SVGPFA_COMB_RIDE": "0", "SVGPFA_COMB_PAIRS": "0"},
                                  {"SVGPFA_ELL_FUSED": "1", "SVGPFA_ELL_CLS": "0"},      # both sums of the quadrature term from one evaluation of E
                                  {"SVGPFA_ELL_FUSED": "1", "SVGPFA_ELL_CLS": "0", "SVGPFA_COMB_FOLD": "0"}],
                          ids=lambda e: "-".join(f"{k[7:].lower()}{v}" for k, v in e.items()))
@@ -200,7 +202,7 @@ def test_launch_switches_agree_with_the_default(monkeypatch, env):
         prob["theta"][k] = prob["theta"][k] * np.array([lsc, psc][:len(prob["theta"][k])])
     outs = []
     for e in ({}, env):
-        for var in ("SVGPFA_COMB_FOLD", "SVGPFA_TILE_NW", "SVGPFA_CLS_FUSED", "SVGPFA_ELL_PARTS", "SVGPFA_TIMES_NW", "SVGPFA_FRONT", "SVGPFA_BUILD", "SVGPFA_ELL_CLS", "SVGPFA_PAIR_RIDE", "SVGPFA_RBF_SERIES", "SVGPFA_COMB_RIDE", "SVGPFA_ELL_NW", "SVGPFA_ELL_FUSED"):
+        for var in ("SVGPFA_COMB_FOLD", "SVGPFA_TILE_NW", "SVGPFA_CLS_FUSED", "SVGPFA_ELL_PARTS", "SVGPFA_TIMES_NW", "SVGPFA_FRONT", "SVGPFA_BUILD", "SVGPFA_ELL_CLS", "SVGPFA_PAIR_RIDE", "SVGPFA_RBF_SERIES", "SVGPFA_COMB_RIDE", "SVGPFA_ELL_NW", "SVGPFA_ELL_FUSED", "SVGPFA_COMB_PAIRS"):
             monkeypatch.delenv(var, raising=False)
         if "SVGPFA_RBF_SERIES" in env:             # both runs with the RBF latents pair by pair: the rider has work to do
             monkeypatch.setenv("SVGPFA_RBF_SERIES", env["SVGPFA_RBF_SERIES"])
