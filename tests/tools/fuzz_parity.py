@@ -1,6 +1,7 @@
 """Random small problems (shapes, kernel mixes, lengthscales, rates, trial lengths) through the engine and the oracle:
 a sweep beyond the fixed cases of tests/test_gpu_parity.py.  usage: python tests/tools/fuzz_parity.py [cases] [seed]
-[fp64|mixed]   (mixed: the tolerances of tests/test_gpu_mixed.py)"""
+[fp64|mixed] [largest N]   (mixed: the tolerances of tests/test_gpu_mixed.py; largest N: 40, above 112 the fused ELL kernel
+-- SVGPFA_ELL_FUSED=1 SVGPFA_ELL_CLS=0 on problems this small -- runs two neuron groups)"""
 import os, sys
 sys.path.insert(0, os.path.join(os.path.dirname(__file__), "..", ".."))
 sys.path.insert(0, os.path.join(os.path.dirname(__file__), ".."))
@@ -14,11 +15,12 @@ from svgpfa_amd.utils import synthetic
 n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 40
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
 precision = sys.argv[3] if len(sys.argv) > 3 else "fp64"
+n_max = int(sys.argv[4]) if len(sys.argv) > 4 else 40
 tol_s, tol_a = (1e-9, 1e-7) if precision == "fp64" else (1e-5, 1e-2)
 worst = {"scalar": 0.0, "array": 0.0}
 for c in range(n_cases):
     K = int(rng.integers(1, 7))
-    case = dict(R=int(rng.integers(1, 6)), N=int(rng.integers(1, 41)), K=K,
+    case = dict(R=int(rng.integers(1, 6)), N=int(rng.integers(1, n_max + 1)), K=K,
                 M=[int(rng.integers(1, 65)) for _ in range(K)],
                 kernels=[synthetic.RBF if rng.random() < 0.5 else synthetic.PERIODIC for _ in range(K)],
                 n_quad=int(rng.integers(8, 120)), rate=float(np.exp(rng.uniform(np.log(0.5), np.log(400.0)))),
