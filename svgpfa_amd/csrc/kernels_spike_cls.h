@@ -19,9 +19,9 @@
 //   W             (r, k): W = s2 c_n (Abar_n, Bbar_n): the posterior-mean weights a projected on the harmonics (only when
 //                 dC is wanted; needs a = Kzz^-1 m) -- a rider of k_prep's wave 0 (k_spike_pre in the statistics calls)
 //   k_spike_cls   (tile, class): U for the tile's <= 64 rows (lane = row = one (trial, neuron) segment or half of one,
-//                 harmonics in registers), A-moment partials by f64 MFMA through an LDS transpose, dC rows; one kernel per
-//                 kind of class (with / without time-weighted moments) on large problems, both in one launch on shards
-//                 (k_spike_cls_all)
+//                 harmonics in registers), A-moment partials by f64 MFMA through an LDS transpose, dC rows; both kinds of
+//                 class (with / without time-weighted moments) in one kernel, k_spike_cls_all (round 5: at every size;
+//                 SVGPFA_CLS_FUSED=0: one kernel per kind, k_spike_cls<4> then k_spike_cls<2>)
 //   k_spike_comb  (r, k): sums the tiles' partials (fixed order) and combines them per inducing point: P0, P1, T of the
 //                 item -- what k_item_bwd's gather reads.  On small shards, where every launch is one under-filled round,
 //                 the gather does this combine itself instead (ev.comb_fold; kernels_item_bwd.h gather_item_inputs): one
@@ -355,7 +355,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 8))) void
   }
 }
 
-// Both kinds of class in ONE launch (the default up to R K = 4096 items, svgpfa_engine::cls_fused): work item = (tile, class)
+// Both kinds of class in ONE launch (the default at every size, svgpfa_engine::cls_fused): work item = (tile, class)
 // over ALL classes, the item's class decides the pass it takes.  One launch boundary (a drained chip) less.
 template <int DC>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 8))) void k_spike_cls_all(EngineView ev,
