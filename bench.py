@@ -442,6 +442,9 @@ def main():
                          "cfg5: about 10-30 s of CPU work for three repetitions)")
     ap.add_argument("--cpu-reps", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--time-every", type=int, default=8,
+                    help="bracket k_item_bwd (and, half a period later, the spike pass) with HIP events in every N-th step of "
+                         "the timed region; 1 = in every step, which lengthens a 0.52-ms step by 12 us (tests/tools/timing_cost.py)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="collective backend; gloo + --single-device rehearses the N > 1 path on a one-GPU box")
     ap.add_argument("--single-device", action="store_true", help="every rank uses cuda:0 (rehearsal only)")
@@ -577,7 +580,10 @@ def main():
         step()
     drain()
     eng.sync()
-    eng.enable_timing(True)
+    # the dominant kernels' durations are measured live, by HIP events on their stream, in a SAMPLE of the timed steps: an event
+    # record is a packet of its own between two kernels, and two pairs in every step cost 12.5 us of a 0.524-ms step
+    time_every = max(1, min(args.time_every, args.steps // 4))
+    eng.enable_timing(time_every if time_every > 1 else True)
     if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
@@ -639,6 +645,8 @@ def main():
                      else "none: no committed PMC digest was taken on this device code (csrc %s)" % kernel_source_sha(),
                      "kernel": "k_item_bwd<%d, %s>" % ((max(prob["Ms"]) + 15) // 16, "true" if mask & 12 else "false"),
                      "kernel_avg_ms": item_avg_ms, "kernel_launches": item_launches,
+                     "kernel_sampling": "HIP events around the kernel in every %d%s step of the timed region" %
+                                        (time_every, {1: "st", 2: "nd", 3: "rd"}.get(time_every, "th")),
                      "executed_fp64_flops_per_launch": item_flops,
                      "note": "per-item adjoints + backward + dC / dd sums: v_mfma_f64_16x16x4_f64 (2 048 flops each, counted "
                              "from the tile structure) plus the kernel evaluations / adjoint accumulations of its "

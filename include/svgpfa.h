@@ -197,10 +197,13 @@ int svgpfa_get_ktz_spikes(svgpfa_engine* e, int32_t k, double* out);
  * disables the reuse.  The caller must change the token whenever it changes C. */
 int svgpfa_set_embedding_token(svgpfa_engine* e, uint64_t token);
 
-/* Timing hook for bench.py.  While enabled, every svgpfa_elbo call brackets its two largest kernels -- the spike-time
+/* Timing hook for bench.py.  While enabled (on = 1), every svgpfa_elbo call brackets its two largest kernels -- the spike-time
  * pass (which = 0) and k_item_bwd (which = 1) -- with hipEvent pairs on the stream each is launched on; nothing is
- * waited for at record time.  svgpfa_kernel_ms synchronises, adds up the elapsed device time of all pairs of that
- * kernel recorded since svgpfa_enable_timing(e, 1) and returns it with the launch count.
+ * waited for at record time.  on = P > 1 SAMPLES instead: k_item_bwd is bracketed in evaluations 0, P, 2P, ... since the call,
+ * the spike pass in evaluations P/2, P + P/2, ... -- at most one pair per evaluation (an event record is a packet of its own
+ * on the stream: two pairs in every evaluation lengthen a 0.52-ms evaluation by 12 us).  svgpfa_kernel_ms synchronises, adds
+ * up the elapsed device time of all pairs of that kernel recorded since svgpfa_enable_timing and returns it with the number
+ * of launches that were bracketed.
  * svgpfa_spike_kernel_ms = svgpfa_kernel_ms(e, 0, ...). */
 int svgpfa_enable_timing(svgpfa_engine* e, int on);
 int svgpfa_kernel_ms(svgpfa_engine* e, int32_t which, double* total_ms, int32_t* launches);

@@ -42,6 +42,8 @@ struct svgpfa_engine {
   bool kw_valid = false;    // EngineView::Kwc holds the whitened quadrature tiles of the current kernels and nodes
   bool kw_cache = true;     // keep them across E-step evaluations (SVGPFA_KW_CACHE=0: off)
   bool timing = false;
+  int timing_period = 1;                 // bracket the kernels of every timing_period-th evaluation (svgpfa_enable_timing)
+  unsigned long long timing_eval = 0;    // evaluations enqueued since timing was enabled
   uint64_t emb_token = 0, p0_token = 0;   // svgpfa_set_embedding_token: content id of C now / when P0 was computed
   std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool;  // event pairs, reused
   std::vector<int> ev_slot;                                // which kernel a pair brackets: 0 k_spike, 1 k_item_bwd
@@ -855,6 +857,13 @@ static int fold_events(svgpfa_engine* e) {
 
 static int timing_begin(svgpfa_engine* e, int slot, hipStream_t st) {
   if (!e->timing) return -1;
+  // sampled: an evaluation carries at most ONE pair -- k_item_bwd's on evaluations 0, P, 2P ..., the spike pass's half a period
+  // later (an event record is a packet of its own on the stream: two pairs per evaluation cost 12.5 us of a 0.524-ms
+  // evaluation, tests/tools/timing_cost.py)
+  if (e->timing_period > 1) {
+    const unsigned long long ph = (e->timing_eval - 1) % (unsigned long long)e->timing_period;
+    if (ph != (slot == 1 ? 0ull : (unsigned long long)(e->timing_period / 2))) return -1;
+  }
   if (e->ev_used >= SV_EV_POOL_MAX && fold_events(e) != SVGPFA_OK) return -1;
   if (e->ev_used == e->ev_pool.size()) {
     std::pair<hipEvent_t, hipEvent_t> pr;
@@ -962,6 +971,7 @@ static int enqueue_elbo(svgpfa_engine* e, const PtrTable& pt, const ElboPlan& pl
   int rc;
   if (!e->cls_valid && (rc = launch_classes(e))) return rc;   // spikes set after the last kernel build
   hipStream_t sm = e->stream;
+  if (e->timing) ++e->timing_eval;
   // the class path's W rides in k_prep when this evaluation's spike pass wants dC
   const bool have_w = pl.run_spike && pl.full && (mask & 2u) && e->cls_on && v.ntiles > 0;
   // whitened parameters (ut, a, Vt, KL), the class path's W and the quadrature statistics: one launch (k_front);
@@ -1276,6 +1286,8 @@ int svgpfa_set_embedding_token(svgpfa_engine* e, uint64_t token) {
 int svgpfa_enable_timing(svgpfa_engine* e, int on) {
   if (!e) return SVGPFA_ERR_INVALID;
   e->timing = on != 0;
+  e->timing_period = on > 1 ? on : 1;
+  e->timing_eval = 0;
   e->ev_used = 0;
   e->ev_tot[0] = e->ev_tot[1] = 0.0;
   e->ev_cnt[0] = e->ev_cnt[1] = 0;

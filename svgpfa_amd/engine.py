@@ -303,6 +303,8 @@ class Engine:
         self._check(self.lib.svgpfa_sync(self._h))
 
     def enable_timing(self, on=True):
+        """False / True: off / every evaluation's spike pass and k_item_bwd bracketed with hipEvent pairs; an int P > 1: every
+        P-th evaluation's k_item_bwd and, half a period later, spike pass (one pair per bracketed evaluation)."""
         self._check(self.lib.svgpfa_enable_timing(self._h, int(on)))
 
     def kernel_ms(self, which):
